@@ -1,0 +1,351 @@
+/*
+ * p2l.h — C ABI of libp2l_hip.so: the MI355X (gfx950) native hot path of the
+ * pix2latent latent-inversion inner loop.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own (it is
+ * pure Python on top of torch / pytorch_pretrained_biggan / lpips); the entry
+ * points below are what a maintainer would bind in place of
+ *
+ *   model(**input_args)                  pix2latent/optimizer/closure.py:51
+ *     -> BigGAN.forward                  pix2latent/model/biggan.py:50-58
+ *   loss_fn(out, **target_args)          pix2latent/optimizer/closure.py:55
+ *     -> ProjectionLoss.__call__         pix2latent/loss_functions.py:97-100
+ *     -> ReconstructionLoss.__call__     pix2latent/loss_functions.py:117-124
+ *     -> PerceptualLoss.__call__         pix2latent/loss_functions.py:140-148
+ *   loss.mean().backward()               pix2latent/optimizer/closure.py:58
+ *   opt.step (torch.optim.Adam)          pix2latent/optimizer/closure.py:65
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are NHWC fp32, channel pitch ("ld") given explicitly;
+ *   - nothing here allocates, frees or synchronises; every kernel is enqueued on
+ *     the hipStream_t passed in (void* so that C callers need no HIP headers);
+ *   - return value: 0 on success, negative P2L_E* on error (p2l_strerror()).
+ */
+#ifndef P2L_H_
+#define P2L_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2L_OK 0
+#define P2L_EINVAL (-1)   /* bad shape / alignment / null pointer            */
+#define P2L_ELAUNCH (-2)  /* hipLaunchKernel reported an error               */
+#define P2L_EWS (-3)      /* workspace too small                             */
+#define P2L_EUNSUP (-4)   /* combination not implemented                     */
+
+int p2l_version(void);
+const char* p2l_strerror(int rc);
+/* last hipError_t seen by a failed launch on this thread (0 if none) */
+int p2l_last_hip_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Convolution (3x3 pad 1 / 1x1), implicit GEMM on v_mfma_f32_32x32x2_f32.   */
+/* Replaces every nn.Conv2d on the path (HF BigGAN-deep GenBlock convs,      */
+/* SelfAttn 1x1s, VGG16 features) and its input-gradient.                    */
+/* ------------------------------------------------------------------------- */
+
+enum { P2L_ACT_NONE = 0, P2L_ACT_RELU = 1, P2L_ACT_TANH = 2 };
+enum { P2L_POOL_NONE = 0, P2L_POOL_MAX = 1, P2L_POOL_SUM = 2 };
+enum { P2L_PRO_NONE = 0, P2L_PRO_AFFINE_RELU = 1, P2L_PRO_AFFINE = 2 };
+
+typedef struct P2LConv {
+  /* geometry: B images, OUTPUT H x W; H, W powers of two >= 4                */
+  int32_t B, H, W;
+  int32_t Cin;      /* multiple of 16 (zero-pad weights + input otherwise)    */
+  int32_t Cout;     /* multiple of 32                                         */
+  int32_t taps;     /* 1 (1x1) or 9 (3x3, zero pad 1)                         */
+  int32_t ups;      /* 1: x is [B,H/2,W/2,*]; nearest x2 applied on the fly   */
+  int32_t x_ld;     /* floats per input pixel (>= Cin)                        */
+  /* prologue on the input operand (applied before zero padding):             */
+  /*   AFFINE_RELU: a = max(x*s[b,c] + t[b,c], 0)   (CBN+ReLU, BN+ReLU)       */
+  /*   AFFINE     : a = x*s[b,c] + t[b,c]           (LPIPS scaling layer)     */
+  int32_t pro;
+  int32_t pro_bstride; /* floats between samples in pro_s/pro_t (0 = shared)  */
+  /* epilogue: v = alpha*acc + bias[n] + res ; act ; mask ; store ; pool      */
+  float alpha;
+  int32_t act;
+  int32_t pool;     /* pooled output written to yp ([B,H/2,W/2,*], yp_ld)     */
+  int32_t y_ld, yp_ld;
+  int32_t n_store;  /* store only channels n < n_store (<= Cout)              */
+  int32_t res_ld;   /* residual pixel pitch                                   */
+  int32_t res_ups;  /* 1: residual is [B,H/2,W/2,*] read with nearest x2      */
+  int32_t mask_ld;  /* mask pixel pitch (mask > 0 keeps the value)            */
+  int32_t splitk;   /* >=1; >1 needs workspace of splitk*B*H*W*Cout floats    */
+} P2LConv;
+
+/* Weight layout expected in `w`: [taps][Cin/KC][Cout][KC] fp32 with KC = 16 for
+ * 3x3 and KC = 32 for 1x1 (Cin must be a multiple of KC): for tap t, input
+ * channel chunk q and output channel n, KC consecutive input channels.
+ * p2l_pack_conv_weight builds it (and the input-gradient copy) from OIHW. */
+size_t p2l_conv_workspace_bytes(const P2LConv* d);
+int p2l_conv_suggest_splitk(const P2LConv* d);
+int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
+                 const float* bias, const float* pro_s, const float* pro_t,
+                 const float* res, const float* mask, float* y, float* yp,
+                 void* workspace, size_t ws_bytes, void* stream);
+
+/* w_oihw is [O][I][kh][kw].  transpose_flip=0 packs the conv I->O (K_pad >= I,
+ * N_pad >= O, zero padded); transpose_flip=1 packs the conv that maps dY[O] to
+ * dX[I] (taps mirrored, channels swapped; K_pad >= O, N_pad >= I). */
+int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps, int N_pad,
+                         int K_pad, int transpose_flip, float* w_packed,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Batched GEMM fp32 (attention bmm's and their gradients).                  */
+/*   C[b] = alpha * op(A[b]) * op(B[b])  (+ C[b] if accumulate)              */
+/*   a_kmajor=0: A is [M][lda] with K contiguous; 1: A is [K][lda], M contig */
+/*   b_kmajor=0: B is [N][ldb] with K contiguous; 1: B is [K][ldb], N contig */
+/*   M % 128 == 0, N % 32 == 0, K % 16 == 0.                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct P2LGemm {
+  int32_t batch, M, N, K;
+  int32_t lda, ldb, ldc;
+  int64_t stride_a, stride_b, stride_c; /* floats between batches            */
+  int32_t a_kmajor, b_kmajor;
+  float alpha;
+  int32_t accumulate;
+} P2LGemm;
+int p2l_gemm(const P2LGemm* d, const float* A, const float* B, float* C,
+             void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Small dense layers on the conditioning vector (gen_z, CBN gain/bias).     */
+/*   y[b][n] = sum_k x[b][k] * W[k][n] + bias[n]      (W is [K][N])          */
+/*   dx[b][k] = sum_n dy[b][n] * W[k][n]                                     */
+/* ------------------------------------------------------------------------- */
+int p2l_linear_fwd(const float* x, const float* W, const float* bias, float* y,
+                   int Bn, int K, int N, void* stream);
+int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn, int K,
+                   int N, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Conditional BatchNorm folded to a per-(sample,channel) affine.            */
+/*   gain = 1 + g_raw, bias = b_raw  (g_raw/b_raw = rows of the big linear)  */
+/*   s = gain * rstd[c],  t = bias - mean[c] * s                             */
+/* bwd: dg_raw = ds*rstd - dt*mean*rstd ; db_raw = dt                        */
+/* ------------------------------------------------------------------------- */
+int p2l_cbn_fold_fwd(const float* g_raw, const float* b_raw, const float* mean,
+                     const float* rstd, float* s, float* t, int Bn, int C,
+                     int raw_ld, void* stream);
+int p2l_cbn_fold_bwd(const float* ds, const float* dt, const float* mean,
+                     const float* rstd, float* dg_raw, float* db_raw, int Bn,
+                     int C, int raw_ld, void* stream);
+
+/* Backward of a = max(x*s+t,0) given da ([B,H,W,C]):                        */
+/*   g = (x*s+t>0) ? da : 0 ; dx = g*s + skip ; ds[b,c] = sum_p g*x ;        */
+/*   dt[b,c] = sum_p g   (written at ds[b*dsdt_bstride + c]).                 */
+/* skip (optional) is the GenBlock shortcut gradient: the block-output        */
+/* gradient dY restricted to channels c < skip_C; with skip_ups=1 dY lives at */
+/* [B,2H,2W,*] and its 2x2 children are summed (nearest-x2 backward).         */
+/* Deterministic two-stage reduction; `partial` needs 2*B*nblk*C floats with  */
+/* nblk = p2l_affine_relu_bwd_nblk(H*W).  C % 64 == 0.                        */
+int p2l_affine_relu_bwd_nblk(int P);
+int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x, int x_ld,
+                        const float* s, const float* t, int st_bstride,
+                        const float* skip, int skip_ld, int skip_C, int skip_ups,
+                        float* dx, int dx_ld, float* ds, float* dt,
+                        int dsdt_bstride, float* partial, int Bn, int H, int W,
+                        int C, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Row softmax for the attention matrix and its backward.                    */
+/* ------------------------------------------------------------------------- */
+int p2l_softmax_fwd(const float* S, float* P, int64_t rows, int cols,
+                    void* stream);
+int p2l_softmax_bwd(const float* P, const float* dP, float* dS, int64_t rows,
+                    int cols, void* stream);
+
+/* 2x2 max pool backward (argmax = first max in window scan order), fused     */
+/* with an optional additive term and a ReLU mask of the un-pooled tensor:    */
+/*   dy[p,c] = ((y[p,c]==max of its quad, first hit) ? dyp[q,c] : 0)         */
+/*             + (add ? add[p,c] : 0) ;  if relu_mask: dy *= (y>0)            */
+int p2l_maxpool2_bwd(const float* y, int y_ld, const float* dyp, int dyp_ld,
+                     const float* add, int add_ld, float* dy, int dy_ld, int Bn,
+                     int H, int W, int C, int relu_mask, void* stream);
+/* dy = (y>0) ? g : 0  (plain ReLU mask, used where no pool follows) */
+int p2l_relu_mask(const float* y, int y_ld, const float* g, int g_ld, float* dy,
+                  int dy_ld, int64_t P, int C, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Image <-> NHWC16 helpers (3 channels padded to 16 floats per pixel).      */
+/* ------------------------------------------------------------------------- */
+int p2l_nchw3_to_nhwc16(const float* src, float* dst, int Bn, int H, int W,
+                        void* stream);
+int p2l_nhwc16_to_nchw3(const float* src, float* dst, int Bn, int H, int W,
+                        void* stream);
+/* d(pre-tanh) = d(img) * (1 - img^2), in place on the 16-channel gradient    */
+int p2l_tanh_bwd16(const float* img, float* dimg, int64_t P, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Losses (pix2latent/loss_functions.py:117-124, :140-148).                  */
+/* ------------------------------------------------------------------------- */
+/* Weighted L1:  loss[b] = sum_{c,p} |t-o|*w / sum_{c,p} w  (w = weight*mask) */
+/* target/weight are NCHW3 [B,3,H,W] as the Python API hands them over; img   */
+/* and dimg are NHWC16.  dimg (+)= gscale[b] * sign(o-t)*w/sum w.             */
+/* wsum[b] is written by p2l_weight_sum.                                      */
+int p2l_weight_sum(const float* weight, const float* loss_mask, float* wsum,
+                   int Bn, int HW3, void* stream);
+/* wsrc[b,p] = sum_c weight[b,c,p]*loss_mask[b,c,p]  (per-pixel LPIPS weight) */
+int p2l_weight_map(const float* weight, const float* loss_mask, float* wsrc,
+                   int Bn, int H, int W, void* stream);
+int p2l_l1_loss_nblk(int H, int W); /* floats per sample needed in `partial` */
+int p2l_l1_loss_fwd(const float* img16, const float* target, const float* weight,
+                    const float* loss_mask, const float* wsum, float* loss,
+                    float* partial, int Bn, int H, int W, void* stream);
+int p2l_l1_loss_bwd(const float* img16, const float* target, const float* weight,
+                    const float* loss_mask, const float* wsum,
+                    const float* gscale, float* dimg16, int Bn, int H, int W,
+                    int accumulate, void* stream);
+
+/* LPIPS tap (lpips.LPIPS(spatial=True) restated in oracle/lpips_ref.py):     */
+/*   nf = f / (||f||_2 + 1e-10) ; d[p] = sum_c lin[c]*(nf_o - nf_t)^2         */
+/*   partial[b][blk] = sum over the block's pixels of d[p] * wt[b,p]          */
+/* wt = adjoint-bilinear-resized per-pixel weight map, so that the sum equals */
+/* the spatially weighted sum of the bilinearly upsampled distance map.       */
+/* nft = cached normalised target features (bstride 0 = one shared target).   */
+/* C in {64,128,256,512}.  Finish with p2l_reduce_rows(div = wsum).           */
+int p2l_lpips_normalize(const float* f, float* nf, int64_t P, int C,
+                        void* stream);
+int p2l_lpips_tap_nblk(int P, int C);
+int p2l_lpips_tap_fwd(const float* f, const float* nft, int64_t nft_bstride,
+                      const float* lin, const float* wt, int64_t wt_bstride,
+                      float* loss_partial, int Bn, int P, int C, void* stream);
+/* df[b,p,c] = gscale[b] * wt[b,p] * d d[p] / d f[c]  (gscale already holds   */
+/* beta / wsum[b] * upstream grad)                                            */
+int p2l_lpips_tap_bwd(const float* f, const float* nft, int64_t nft_bstride,
+                      const float* lin, const float* wt, int64_t wt_bstride,
+                      const float* gscale, float* df, int Bn, int P, int C,
+                      void* stream);
+/* adjoint of F.interpolate(bilinear, align_corners=False) from h x w up to   */
+/* H x W: wt[b,q] = sum_p U[p,q] * wsrc[b,p]                                  */
+int p2l_bilinear_adjoint(const float* wsrc, float* wt, int Bn, int H, int W,
+                         int h, int w, void* stream);
+/* deterministic finishing reduction:                                         */
+/*   out[b] (+)= scale * sum_i partial[b][i] / (div ? div[b] : 1)             */
+int p2l_reduce_rows(const float* partial, float* out, int Bn, int n, float scale,
+                    const float* div, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused Adam over a contiguous block of per-sample leaves                    */
+/* (torch.optim.Adam defaults, closure.py:65 / variable_manager.py:231-238).  */
+/*   p,g,m,v: [n] ; step_count is the 1-based step number                     */
+/* ------------------------------------------------------------------------- */
+int p2l_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step_count,
+                  void* stream);
+int p2l_clamp(float* p, int64_t n, float lo, float hi, void* stream);
+
+/* out[b] = a[b] * scale / (div ? div[b] : 1) */
+int p2l_vec_scale_div(const float* a, const float* div, float* out, int n,
+                      float scale, void* stream);
+/* cond[b] = cat(z[b], c[b]) ; and the split of its gradient */
+int p2l_concat2(const float* z, const float* c, float* cond, int Bn, int nz,
+                int nc, void* stream);
+int p2l_split2(const float* dcond, float* dz, float* dc, int Bn, int nz, int nc,
+               void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Whole-graph plans: the native runtime that sequences the kernels above.   */
+/* Everything is enqueued on `stream`; the caller owns `ws` (workspace) and   */
+/* all parameter memory.  Pointers inside the structs are device pointers.    */
+/* ------------------------------------------------------------------------- */
+#define P2L_MAX_BLOCKS 16
+
+typedef struct P2LGenBlock {
+  int32_t cin, cout, up;
+  int32_t cbn_off[4];             /* channel offsets of bn_0..bn_3 in the CBN arrays */
+  const float* w[4];              /* packed forward weights conv_0..conv_3   */
+  const float* b[4];              /* biases                                  */
+  const float* wt[4];             /* packed input-gradient weights           */
+} P2LGenBlock;
+
+typedef struct P2LBigGAN {
+  int32_t n_blocks;               /* 12 for biggan-deep-256                  */
+  int32_t attn_before;            /* SelfAttn runs before block[attn_before] */
+  int32_t ch;                     /* channel_width (128)                     */
+  int32_t z_dim, c_dim;           /* 128, 128 -> cond = 256                  */
+  int32_t cbn_total;              /* sum of all conditional-BN channels      */
+  const float* genz_w;            /* [cond][16*16*ch] (K-major)              */
+  const float* genz_b;            /* [16*16*ch]  (output is NHWC [4,4,16ch]) */
+  const float* cbn_w;             /* [cond][2*cbn_total]: gains then biases  */
+  const float* cbn_mean;          /* [cbn_total] running mean (truncation row) */
+  const float* cbn_rstd;          /* [cbn_total] 1/sqrt(var+eps)             */
+  P2LGenBlock blocks[P2L_MAX_BLOCKS];
+  int32_t attn_ch;                /* 512                                     */
+  const float* att_w[4];          /* theta, phi, g, o packed forward         */
+  const float* att_wt[4];         /* packed input-gradient                   */
+  float gamma;
+  const float* tail_s;            /* [ch] folded unconditional BN            */
+  const float* tail_t;
+  const float* rgb_w;             /* packed 3x3 ch -> 32 (3 real)            */
+  const float* rgb_b;             /* [32]                                    */
+  const float* rgb_wt;            /* packed input-gradient 16 (3 real) -> ch */
+} P2LBigGAN;
+
+size_t p2l_biggan_ws_bytes(const P2LBigGAN* m, int Bn);
+/* z [B,z_dim], c [B,c_dim] -> img16 [B,res,res,16] (tanh output, ch 0..2)   */
+int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c, int Bn,
+                   void* ws, size_t ws_bytes, float* img16, void* stream);
+/* needs the workspace of the matching fwd; dimg16 is consumed (overwritten) */
+int p2l_biggan_bwd(const P2LBigGAN* m, int Bn, void* ws, size_t ws_bytes,
+                   const float* img16, float* dimg16, float* dz, float* dc,
+                   void* stream);
+/* debug/test hook: float offset + shape of a saved activation in ws.        */
+/* what: 0 = output of layer L (ModuleList index, SelfAttn included),        */
+/*       1 = gen_z output, 2 = folded CBN s, 3 = folded CBN t,               */
+/*       4 = d s, 5 = d t (after bwd)                                        */
+int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int L,
+                         size_t* float_off, int32_t shape[4]);
+
+typedef struct P2LVggLpips {
+  const float* w[13];             /* packed forward (conv0: Cin padded to 16) */
+  const float* b[13];
+  const float* wt[13];            /* packed input-gradient (conv0: N padded to 32,
+                                     pre-multiplied by 1/scale)               */
+  const float* lin[5];            /* [C_k] LPIPS linear weights               */
+  const float* in_s;              /* [16] scaling layer: 1/scale (0 padded)   */
+  const float* in_t;              /* [16] -shift/scale                        */
+} P2LVggLpips;
+
+/* cached, target-dependent state (caller allocates):                         */
+typedef struct P2LLossCache {
+  float* nft[5];                  /* normalised target features [B,P_k,C_k]   */
+  float* wt[5];                   /* adjoint-resized weight maps [B,P_k]      */
+  float* wsum;                    /* [B]                                      */
+} P2LLossCache;
+size_t p2l_loss_cache_floats(int Bn, int H, int W, size_t nft_off[5],
+                             size_t wt_off[5], size_t* wsum_off);
+size_t p2l_projloss_ws_bytes(int Bn, int H, int W);
+/* target/weight/loss_mask: NCHW3 [B,3,H,W] (loss_mask may be NULL)           */
+int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
+                         const float* weight, const float* loss_mask, int Bn,
+                         int H, int W, const P2LLossCache* cache, void* ws,
+                         size_t ws_bytes, void* stream);
+/* loss[b] = L1_weighted + beta * LPIPS_weighted; use_lpips=0 -> L1 only       */
+int p2l_projloss_fwd(const P2LVggLpips* v, const float* img16,
+                     const float* target, const float* weight,
+                     const float* loss_mask, const P2LLossCache* cache,
+                     float beta, int use_lpips, int Bn, int H, int W, void* ws,
+                     size_t ws_bytes, float* loss, float* loss_l1,
+                     float* loss_lpips, void* stream);
+int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
+                     const float* target, const float* weight,
+                     const float* loss_mask, const P2LLossCache* cache,
+                     float beta, int use_lpips, const float* gloss, int Bn,
+                     int H, int W, void* ws, size_t ws_bytes, float* dimg16,
+                     void* stream);
+
+/* MFMA layout self-test: C[32x32] = A[32xK] * B[Kx32] via one wave. */
+int p2l_mfma_probe(const float* A, const float* B, float* C, int K,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2L_H_ */

@@ -1,0 +1,117 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of the loss
+side of the pix2latent hot path.
+
+* l1 / l2 / masked / ReconstructionLoss / ProjectionLoss follow the reference
+  file pix2latent/loss_functions.py line by line (cited per function) and are
+  PINNED by tests/golden/losses.npz, generated from the imported reference
+  (tools/make_golden.py).
+* The LPIPS network itself is PARITY UNPINNED: `lpips>=0.1`
+  (requirements.txt:15; call sites loss_functions.py:15,131,142) and the
+  torchvision VGG16 weights are absent here.  `lpips_spatial` restates the
+  published algorithm of lpips.LPIPS(net='vgg', version='0.1', spatial=True)
+  from recall.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.
+"""
+import torch
+import torch.nn.functional as F
+
+# lpips.ScalingLayer constants [3P-recall]
+LPIPS_SHIFT = (-.030, -.088, -.188)
+LPIPS_SCALE = (.458, .448, .450)
+
+# torchvision vgg16.features conv layout; taps after relu1_2, 2_2, 3_3, 4_3, 5_3
+VGG_CFG = [(3, 64), (64, 64), 'M', (64, 128), (128, 128), 'M',
+           (128, 256), (256, 256), (256, 256), 'M',
+           (256, 512), (512, 512), (512, 512), 'M',
+           (512, 512), (512, 512), (512, 512)]
+VGG_TAPS_AFTER_CONV = (1, 3, 6, 9, 12)   # 0-based conv indices whose ReLU output is tapped
+VGG_CHNS = (64, 128, 256, 512, 512)
+
+
+def l1_loss(out, target):                       # loss_functions.py:20-22
+    return torch.abs(target - out)
+
+
+def l2_loss(out, target):                       # loss_functions.py:25-27
+    return (target - out) ** 2
+
+
+def masked_l1_loss(out, target, mask):          # loss_functions.py:41-50
+    if mask.size(0) == 1:
+        mask = mask.repeat(out.size(0), 1, 1, 1)
+    if target.size(0) == 1:
+        target = target.repeat(out.size(0), 1, 1, 1)
+    loss = l1_loss(out, target)
+    return torch.sum(loss * mask, [1, 2, 3]) / torch.sum(mask, [1, 2, 3])
+
+
+def masked_l2_loss(out, target, mask):          # loss_functions.py:53-61
+    if mask.size(0) == 1:
+        mask = mask.repeat(out.size(0), 1, 1, 1)
+    if target.size(0) == 1:
+        target = target.repeat(out.size(0), 1, 1, 1)
+    loss = l2_loss(out, target)
+    return torch.sum(loss * mask, [1, 2, 3]) / torch.sum(mask, [1, 2, 3])
+
+
+def _weighted(loss, weight, loss_mask):         # loss_functions.py:119-123 / :143-147
+    if weight is not None:
+        _w = weight if loss_mask is None else (loss_mask * weight)
+        loss = torch.sum(loss * _w, [1, 2, 3]) / torch.sum(_w, [1, 2, 3])
+    return loss
+
+
+def reconstruction_loss(output, target, weight=None, loss_mask=None, loss_type='l1'):
+    """ReconstructionLoss.__call__ (loss_functions.py:117-124)."""
+    fn = l1_loss if loss_type in ['l1', 1] else l2_loss
+    return _weighted(fn(output, target), weight, loss_mask)
+
+
+def vgg_features(Wv, x):
+    """torchvision vgg16.features sliced as lpips.pretrained_networks.vgg16 does
+    [3P-recall]: returns relu1_2, relu2_2, relu3_3, relu4_3, relu5_3."""
+    taps, ci = [], 0
+    for item in VGG_CFG:
+        if item == 'M':
+            x = F.max_pool2d(x, 2, 2)
+        else:
+            x = F.relu(F.conv2d(x, Wv['vgg.conv%d.weight' % ci], Wv['vgg.conv%d.bias' % ci], padding=1))
+            if ci in VGG_TAPS_AFTER_CONV:
+                taps.append(x)
+            ci += 1
+    return taps
+
+
+def normalize_tensor(f, eps=1e-10):
+    """lpips.normalize_tensor [3P-recall]."""
+    norm = torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True))
+    return f / (norm + eps)
+
+
+def lpips_spatial(Wv, in0, in1):
+    """lpips.LPIPS(net='vgg', spatial=True).forward(in0, in1) -> [B,1,H,W]  [3P-recall]."""
+    shift = torch.tensor(LPIPS_SHIFT).view(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE).view(1, 3, 1, 1)
+    f0 = vgg_features(Wv, (in0 - shift) / scale)
+    f1 = vgg_features(Wv, (in1 - shift) / scale)
+    val = None
+    for kk in range(len(f0)):
+        d = (normalize_tensor(f0[kk]) - normalize_tensor(f1[kk])) ** 2
+        lin = F.conv2d(d, Wv['lpips.lin%d.weight' % kk])       # [1,C,1,1], no bias
+        up = F.interpolate(lin, size=in0.shape[2:], mode='bilinear', align_corners=False)
+        val = up if val is None else val + up
+    return val
+
+
+def perceptual_loss(Wv, output, target, weight=None, loss_mask=None):
+    """PerceptualLoss.__call__ (loss_functions.py:140-148)."""
+    return _weighted(lpips_spatial(Wv, output, target), weight, loss_mask)
+
+
+def projection_loss(Wv, output, target, weight=None, loss_mask=None, beta=10):
+    """ProjectionLoss.__call__ (loss_functions.py:97-100): rec + beta * per."""
+    rec = reconstruction_loss(output, target, weight, loss_mask)
+    per = perceptual_loss(Wv, output, target, weight, loss_mask)
+    return rec + beta * per

@@ -1,0 +1,135 @@
+"""ctypes binding of libp2l_hip.so (include/p2l.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+returns an error code this module raises.  Build with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C pix2latent_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libp2l_hip.so')
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class P2LConv(C.Structure):
+    _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('Cin', C.c_int32), ('Cout', C.c_int32), ('taps', C.c_int32),
+                ('ups', C.c_int32), ('x_ld', C.c_int32), ('pro', C.c_int32),
+                ('pro_bstride', C.c_int32), ('alpha', C.c_float), ('act', C.c_int32),
+                ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
+                ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
+                ('mask_ld', C.c_int32), ('splitk', C.c_int32)]
+
+
+class P2LGemm(C.Structure):
+    _fields_ = [('batch', C.c_int32), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32),
+                ('stride_a', C.c_int64), ('stride_b', C.c_int64), ('stride_c', C.c_int64),
+                ('a_kmajor', C.c_int32), ('b_kmajor', C.c_int32), ('alpha', C.c_float),
+                ('accumulate', C.c_int32)]
+
+
+P2L_MAX_BLOCKS = 16
+
+
+class P2LGenBlock(C.Structure):
+    _fields_ = [('cin', C.c_int32), ('cout', C.c_int32), ('up', C.c_int32),
+                ('cbn_off', C.c_int32 * 4),
+                ('w', C.c_void_p * 4), ('b', C.c_void_p * 4), ('wt', C.c_void_p * 4)]
+
+
+class P2LBigGAN(C.Structure):
+    _fields_ = [('n_blocks', C.c_int32), ('attn_before', C.c_int32), ('ch', C.c_int32),
+                ('z_dim', C.c_int32), ('c_dim', C.c_int32), ('cbn_total', C.c_int32),
+                ('genz_w', C.c_void_p), ('genz_b', C.c_void_p), ('cbn_w', C.c_void_p),
+                ('cbn_mean', C.c_void_p), ('cbn_rstd', C.c_void_p),
+                ('blocks', P2LGenBlock * P2L_MAX_BLOCKS),
+                ('attn_ch', C.c_int32),
+                ('att_w', C.c_void_p * 4), ('att_wt', C.c_void_p * 4),
+                ('gamma', C.c_float),
+                ('tail_s', C.c_void_p), ('tail_t', C.c_void_p),
+                ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p), ('rgb_wt', C.c_void_p)]
+
+
+class P2LVggLpips(C.Structure):
+    _fields_ = [('w', C.c_void_p * 13), ('b', C.c_void_p * 13), ('wt', C.c_void_p * 13),
+                ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
+
+
+class P2LLossCache(C.Structure):
+    _fields_ = [('nft', C.c_void_p * 5), ('wt', C.c_void_p * 5), ('wsum', C.c_void_p)]
+
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+POOL_NONE, POOL_MAX, POOL_SUM = 0, 1, 2
+PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
+
+# every symbol include/p2l.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
+    'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd',
+    'p2l_pack_conv_weight', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
+    'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
+    'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
+    'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',
+    'p2l_weight_sum', 'p2l_weight_map', 'p2l_l1_loss_nblk', 'p2l_l1_loss_fwd',
+    'p2l_l1_loss_bwd', 'p2l_lpips_normalize', 'p2l_lpips_tap_nblk', 'p2l_lpips_tap_fwd',
+    'p2l_lpips_tap_bwd', 'p2l_bilinear_adjoint', 'p2l_reduce_rows', 'p2l_adam_step',
+    'p2l_clamp', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
+    'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
+    'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_prepare',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe',
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libp2l_hip.so once; fail loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                'libp2l_hip.so not found at %s: the HIP extension is required '
+                '(no CPU fallback). Run __graft_entry__.build().' % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.p2l_strerror.restype = C.c_char_p
+        for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
+                     'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats'):
+            getattr(_lib, name).restype = C.c_size_t
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        L = lib()
+        raise NativeError('%s failed: %s (rc=%d, hipError=%d)' % (
+            what or 'p2l call', L.p2l_strerror(rc).decode(), rc, L.p2l_last_hip_error()))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.dtype == torch.float32 and t.is_contiguous(), 'expect contiguous fp32'
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(v):
+    return C.c_float(float(v))
+
+
+def i64(v):
+    return C.c_int64(int(v))

@@ -1,0 +1,905 @@
+// HBM-bound pieces of the pix2latent hot path: conditioning linears, CBN fold,
+// activation backward + per-(sample,channel) reductions, softmax, pooling
+// backward, image layout helpers, the L1 / LPIPS loss tails and fused Adam.
+// Every reduction is a fixed-order tree (wave shuffles -> LDS -> second stage):
+// CMA-ES ranks candidates by these numbers, so no float atomics anywhere.
+#include "p2l_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// block-level fixed-order sum (256 threads), result valid in every thread
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red /*>=4*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// linear fwd: y[b][n] = sum_k x[b][k] W[k][n] + bias[n]
+// block = 64 output columns x 4 K-groups; x staged in LDS (broadcast reads)
+// ---------------------------------------------------------------------------
+template <int BG>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ W,
+    const float* __restrict__ bias, float* __restrict__ y, int Bn, int b_begin,
+    int K, int N) {
+  extern __shared__ float sm[];  // [BG][K] x slab, then [4][BG][64] reduce
+  float* xs = sm;
+  float* red = sm + BG * K;
+  const int tid = threadIdx.x, nl = tid & 63, kg = tid >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const int nb = min(BG, Bn - b_begin);
+  for (int i = tid; i < BG * K; i += 256) {
+    const int b = i / K, kk = i - b * K;
+    xs[i] = (b < nb) ? x[(size_t)(b_begin + b) * K + kk] : 0.f;
+  }
+  __syncthreads();
+  float acc[BG];
+#pragma unroll
+  for (int b = 0; b < BG; ++b) acc[b] = 0.f;
+  const int kper = K >> 2;
+  const int k0 = kg * kper;
+  if (n < N) {
+#pragma unroll 8
+    for (int kk = k0; kk < k0 + kper; ++kk) {
+      const float w = W[(size_t)kk * N + n];
+#pragma unroll
+      for (int b = 0; b < BG; ++b) acc[b] = fmaf(xs[b * K + kk], w, acc[b]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BG; ++b) red[(kg * BG + b) * 64 + nl] = acc[b];
+  __syncthreads();
+  // 256 threads finish BG*64 outputs in fixed k-group order
+  for (int i = tid; i < BG * 64; i += 256) {
+    const int b = i >> 6, c = i & 63;
+    const int nn = blockIdx.x * 64 + c;
+    if (b < nb && nn < N) {
+      float v = (red[(0 * BG + b) * 64 + c] + red[(1 * BG + b) * 64 + c]) +
+                (red[(2 * BG + b) * 64 + c] + red[(3 * BG + b) * 64 + c]);
+      if (bias) v += bias[nn];
+      y[(size_t)(b_begin + b) * N + nn] = v;
+    }
+  }
+}
+
+// linear bwd: dx[b][k] = sum_n dy[b][n] W[k][n]; one block per k
+template <int BG>
+__global__ __launch_bounds__(256) void linear_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ W,
+    float* __restrict__ dx, int Bn, int b_begin, int K, int N, int accumulate) {
+  __shared__ float red[4];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const int nb = min(BG, Bn - b_begin);
+  float acc[BG];
+#pragma unroll
+  for (int b = 0; b < BG; ++b) acc[b] = 0.f;
+  const float* wrow = W + (size_t)k * N;
+  for (int n = tid; n < N; n += 256) {
+    const float w = wrow[n];
+#pragma unroll
+    for (int b = 0; b < BG; ++b)
+      if (b < nb) acc[b] = fmaf(dy[(size_t)(b_begin + b) * N + n], w, acc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < BG; ++b) {
+    const float s = block_sum_256(acc[b], red);
+    if (tid == 0 && b < nb) {
+      float* p = dx + (size_t)(b_begin + b) * K + k;
+      *p = accumulate ? (*p + s) : s;
+    }
+  }
+}
+
+__global__ void cbn_fold_fwd_kernel(const float* g_raw, const float* b_raw,
+                                    const float* mean, const float* rstd,
+                                    float* s, float* t, int Bn, int C, int raw_ld) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * C) return;
+  const int b = i / C, c = i - b * C;
+  const float gain = 1.f + g_raw[(size_t)b * raw_ld + c];
+  const float bias = b_raw[(size_t)b * raw_ld + c];
+  const float sv = gain * rstd[c];
+  s[i] = sv;
+  t[i] = bias - mean[c] * sv;
+}
+
+__global__ void cbn_fold_bwd_kernel(const float* ds, const float* dt,
+                                    const float* mean, const float* rstd,
+                                    float* dg_raw, float* db_raw, int Bn, int C,
+                                    int raw_ld) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * C) return;
+  const int b = i / C, c = i - b * C;
+  // s = (1+g)*rstd ; t = bias - mean*s  =>  dL/dg = (ds - dt*mean)*rstd ; dL/dbias = dt
+  dg_raw[(size_t)b * raw_ld + c] = (ds[i] - dt[i] * mean[c]) * rstd[c];
+  db_raw[(size_t)b * raw_ld + c] = dt[i];
+}
+
+// ---------------------------------------------------------------------------
+// backward of a = max(x*s+t, 0):  g = mask*da ; dx = g*s + skip ; partial sums
+// grid (slab, C/64, B); block = 16 channel-float4 lanes x 16 pixel lanes
+// ---------------------------------------------------------------------------
+struct ArbK {
+  const float* da; const float* x; const float* s; const float* t;
+  const float* skip; float* dx; float* partial;
+  int da_ld, x_ld, dx_ld, skip_ld, skip_C, skip_ups, st_bstride;
+  int Bn, P, C, H, W, nblk;
+};
+constexpr int ARB_SLAB = 256;
+
+__global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
+  __shared__ f32x4 red_s[256], red_t[256];
+  const int tid = threadIdx.x, cl = tid & 15, pl = tid >> 4;
+  const int slab = blockIdx.x, c = blockIdx.y * 64 + cl * 4, b = blockIdx.z;
+  const f32x4 s4 = *reinterpret_cast<const f32x4*>(k.s + (size_t)b * k.st_bstride + c);
+  const f32x4 t4 = *reinterpret_cast<const f32x4*>(k.t + (size_t)b * k.st_bstride + c);
+  f32x4 as = {0, 0, 0, 0}, at = {0, 0, 0, 0};
+  const int p_end = min(k.P, (slab + 1) * ARB_SLAB);
+  for (int p = slab * ARB_SLAB + pl; p < p_end; p += 16) {
+    const size_t pix = (size_t)b * k.P + p;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(k.x + pix * k.x_ld + c);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(k.da + pix * k.da_ld + c);
+    f32x4 g;
+    g.x = (xv.x * s4.x + t4.x > 0.f) ? dv.x : 0.f;
+    g.y = (xv.y * s4.y + t4.y > 0.f) ? dv.y : 0.f;
+    g.z = (xv.z * s4.z + t4.z > 0.f) ? dv.z : 0.f;
+    g.w = (xv.w * s4.w + t4.w > 0.f) ? dv.w : 0.f;
+    as += g * xv;
+    at += g;
+    f32x4 o = g * s4;
+    if (k.skip && c < k.skip_C) {
+      if (k.skip_ups) {
+        const int yy = p / k.W, xx = p - yy * k.W;
+        const int W2 = 2 * k.W;
+        const size_t q = ((size_t)b * (2 * k.H) + 2 * yy) * W2 + 2 * xx;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(k.skip + q * k.skip_ld + c);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(k.skip + (q + 1) * k.skip_ld + c);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(k.skip + (q + W2) * k.skip_ld + c);
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(k.skip + (q + W2 + 1) * k.skip_ld + c);
+        o += (c0 + c1) + (c2 + c3);
+      } else {
+        o += *reinterpret_cast<const f32x4*>(k.skip + pix * k.skip_ld + c);
+      }
+    }
+    *reinterpret_cast<f32x4*>(k.dx + pix * k.dx_ld + c) = o;
+  }
+  red_s[tid] = as;
+  red_t[tid] = at;
+  __syncthreads();
+  if (pl == 0) {
+    f32x4 a = red_s[cl], bsum = red_t[cl];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      a += red_s[j * 16 + cl];
+      bsum += red_t[j * 16 + cl];
+    }
+    const size_t o = ((size_t)b * k.nblk + slab) * k.C + c;
+    *reinterpret_cast<f32x4*>(k.partial + o) = a;
+    *reinterpret_cast<f32x4*>(k.partial + (size_t)k.Bn * k.nblk * k.C + o) = bsum;
+  }
+}
+
+__global__ void arb_finish_kernel(const float* partial, float* ds, float* dt,
+                                  int Bn, int nblk, int C, int out_bstride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * C) return;
+  const int b = i / C, c = i - b * C;
+  float a = 0.f, t = 0.f;
+  const size_t half = (size_t)Bn * nblk * C;
+  for (int j = 0; j < nblk; ++j) {
+    const size_t o = ((size_t)b * nblk + j) * C + c;
+    a += partial[o];
+    t += partial[half + o];
+  }
+  ds[(size_t)b * out_bstride + c] = a;
+  dt[(size_t)b * out_bstride + c] = t;
+}
+
+// ---------------------------------------------------------------------------
+// softmax over rows of `cols` (multiple of 256, <= 2048): one wave per row
+// ---------------------------------------------------------------------------
+template <int VPL>  // float4 per lane
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* S, float* P,
+                                                          long long rows, int cols) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* sp = S + row * cols;
+  float* pp = P + row * cols;
+  f32x4 v[VPL];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(sp + (i * 64 + lane) * 4);
+    m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i].x = expf(v[i].x - m);
+    v[i].y = expf(v[i].y - m);
+    v[i].z = expf(v[i].z - m);
+    v[i].w = expf(v[i].w - m);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+    *reinterpret_cast<f32x4*>(pp + (i * 64 + lane) * 4) = v[i] * inv;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* P, const float* dP,
+                                                          float* dS, long long rows,
+                                                          int cols) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  f32x4 p[VPL], d[VPL];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    p[i] = *reinterpret_cast<const f32x4*>(P + row * cols + (i * 64 + lane) * 4);
+    d[i] = *reinterpret_cast<const f32x4*>(dP + row * cols + (i * 64 + lane) * 4);
+    dot += (p[i].x * d[i].x + p[i].y * d[i].y) + (p[i].z * d[i].z + p[i].w * d[i].w);
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+    *reinterpret_cast<f32x4*>(dS + row * cols + (i * 64 + lane) * 4) = p[i] * (d[i] - dot);
+}
+
+// ---------------------------------------------------------------------------
+// pooling / relu backward
+// ---------------------------------------------------------------------------
+__global__ void maxpool2_bwd_kernel(const float* y, int y_ld, const float* dyp,
+                                    int dyp_ld, const float* add, int add_ld,
+                                    float* dy, int dy_ld, int Bn, int H, int W,
+                                    int C, int relu_mask) {
+  // one thread per (quad, float4 channel)
+  const int C4 = C >> 2, Hh = H >> 1, Wh = W >> 1;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)Bn * Hh * Wh * C4;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4) * 4;
+  size_t q = idx / C4;
+  const int qx = (int)(q % Wh);
+  q /= Wh;
+  const int qy = (int)(q % Hh);
+  const int b = (int)(q / Hh);
+  const size_t pq = ((size_t)b * Hh + qy) * Wh + qx;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + pq * dyp_ld + c);
+  size_t pix[4];
+  f32x4 v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    pix[s] = ((size_t)b * H + 2 * qy + (s >> 1)) * W + 2 * qx + (s & 1);
+    v[s] = *reinterpret_cast<const f32x4*>(y + pix[s] * y_ld + c);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    // first maximum in window scan order (row-major), as ATen max_pool2d does
+    int arg = 0;
+    float m = v[0][e];
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+      if (v[s][e] > m) { m = v[s][e]; arg = s; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s][e] = (s == arg) ? g[e] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f32x4 r = o[s];
+    if (add) r += *reinterpret_cast<const f32x4*>(add + pix[s] * add_ld + c);
+    if (relu_mask) {
+      r.x = v[s].x > 0.f ? r.x : 0.f;
+      r.y = v[s].y > 0.f ? r.y : 0.f;
+      r.z = v[s].z > 0.f ? r.z : 0.f;
+      r.w = v[s].w > 0.f ? r.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dy + pix[s] * dy_ld + c) = r;
+  }
+}
+
+__global__ void relu_mask_kernel(const float* y, int y_ld, const float* g, int g_ld,
+                                 float* dy, int dy_ld, long long P, int C) {
+  const int C4 = C >> 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)P * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const size_t p = idx / C4;
+  const f32x4 yv = *reinterpret_cast<const f32x4*>(y + p * y_ld + c);
+  f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * g_ld + c);
+  gv.x = yv.x > 0.f ? gv.x : 0.f;
+  gv.y = yv.y > 0.f ? gv.y : 0.f;
+  gv.z = yv.z > 0.f ? gv.z : 0.f;
+  gv.w = yv.w > 0.f ? gv.w : 0.f;
+  *reinterpret_cast<f32x4*>(dy + p * dy_ld + c) = gv;
+}
+
+// ---------------------------------------------------------------------------
+// image layout helpers
+// ---------------------------------------------------------------------------
+__global__ void nchw3_to_nhwc16_kernel(const float* src, float* dst, int Bn, int HW) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * HW) return;
+  const size_t b = idx / HW, p = idx - b * HW;
+  const float* s = src + b * 3 * HW + p;
+  f32x4 z = {0, 0, 0, 0};
+  f32x4 v = {s[0], s[HW], s[2 * (size_t)HW], 0.f};
+  f32x4* d = reinterpret_cast<f32x4*>(dst + idx * 16);
+  d[0] = v; d[1] = z; d[2] = z; d[3] = z;
+}
+__global__ void nhwc16_to_nchw3_kernel(const float* src, float* dst, int Bn, int HW) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * HW) return;
+  const size_t b = idx / HW, p = idx - b * HW;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(src + idx * 16);
+  float* d = dst + b * 3 * HW + p;
+  d[0] = v.x; d[HW] = v.y; d[2 * (size_t)HW] = v.z;
+}
+__global__ void tanh_bwd16_kernel(const float* img, float* dimg, long long P) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)P) return;
+  const f32x4 o = *reinterpret_cast<const f32x4*>(img + idx * 16);
+  f32x4* dp = reinterpret_cast<f32x4*>(dimg + idx * 16);
+  f32x4 d = dp[0];
+  d.x *= (1.f - o.x * o.x);
+  d.y *= (1.f - o.y * o.y);
+  d.z *= (1.f - o.z * o.z);
+  d.w = 0.f;
+  dp[0] = d;
+}
+
+// ---------------------------------------------------------------------------
+// losses
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void weight_sum_kernel(const float* weight,
+                                                          const float* mask,
+                                                          float* wsum, int n) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* w = weight + (size_t)b * n;
+  const float* m = mask ? mask + (size_t)b * n : nullptr;
+  float acc = 0.f;
+  for (int i = tid; i < n; i += 1024) acc += m ? w[i] * m[i] : w[i];
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    wsum[b] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* img16,
+                                                     const float* target,
+                                                     const float* weight,
+                                                     const float* mask,
+                                                     float* partial, int HW) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, nblk = gridDim.x;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (p < HW) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(img16 + ((size_t)b * HW + p) * 16);
+    const size_t base = (size_t)b * 3 * HW + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float w = weight[base + (size_t)c * HW];
+      if (mask) w *= mask[base + (size_t)c * HW];
+      acc += fabsf(target[base + (size_t)c * HW] - o[c]) * w;
+    }
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[(size_t)b * nblk + blockIdx.x] = s;
+}
+
+__global__ void l1_bwd_kernel(const float* img16, const float* target,
+                              const float* weight, const float* mask,
+                              const float* wsum, const float* gscale,
+                              float* dimg16, int HW, int accumulate) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const size_t pix = (size_t)b * HW + p;
+  const f32x4 o = *reinterpret_cast<const f32x4*>(img16 + pix * 16);
+  const size_t base = (size_t)b * 3 * HW + p;
+  const float gs = gscale[b] / wsum[b];
+  f32x4 d = {0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float w = weight[base + (size_t)c * HW];
+    if (mask) w *= mask[base + (size_t)c * HW];
+    const float diff = o[c] - target[base + (size_t)c * HW];
+    const float sg = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+    d[c] = gs * sg * w;
+  }
+  f32x4* dp = reinterpret_cast<f32x4*>(dimg16 + pix * 16);
+  if (accumulate) {
+    dp[0] = dp[0] + d;
+  } else {
+    const f32x4 z = {0, 0, 0, 0};
+    dp[0] = d; dp[1] = z; dp[2] = z; dp[3] = z;
+  }
+}
+
+// LPIPS: LP lanes cooperate on one pixel, each holding C/(4*LP) float4.
+template <int C>
+struct LpipsCfg {
+  static constexpr int LP = (C / 4 >= 64) ? 64 : C / 4;
+  static constexpr int VPL = C / (4 * LP);
+  static constexpr int PPW = 64 / LP;  // pixels per wave
+};
+template <int LP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void lpips_normalize_kernel(const float* f, float* nf,
+                                                              long long P) {
+  using Cfg = LpipsCfg<C>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / Cfg::LP, ll = lane % Cfg::LP;
+  const long long p = ((long long)blockIdx.x * 4 + wave) * Cfg::PPW + sub;
+  if (p >= P) return;
+  f32x4 v[Cfg::VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < Cfg::VPL; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(f + p * C + (i * Cfg::LP + ll) * 4);
+    ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  ss = group_sum<Cfg::LP>(ss);
+  const float inv = 1.f / (sqrtf(ss) + 1e-10f);
+#pragma unroll
+  for (int i = 0; i < Cfg::VPL; ++i)
+    *reinterpret_cast<f32x4*>(nf + p * C + (i * Cfg::LP + ll) * 4) = v[i] * inv;
+}
+
+struct LpipsK {
+  const float* f; const float* nft; const float* lin; const float* wt;
+  const float* gscale; float* out;  // partial (fwd) or df (bwd)
+  long long nft_bstride, wt_bstride;
+  int Bn, P, nblk;
+};
+
+template <int C, bool BWD>
+__global__ __launch_bounds__(256) void lpips_tap_kernel(const LpipsK k) {
+  using Cfg = LpipsCfg<C>;
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / Cfg::LP, ll = lane % Cfg::LP;
+  const int p = (blockIdx.x * 4 + wave) * Cfg::PPW + sub;
+  float contrib = 0.f;
+  if (p < k.P) {
+    const float* fp = k.f + ((size_t)b * k.P + p) * C;
+    const float* tp = k.nft + (size_t)b * k.nft_bstride + (size_t)p * C;
+    f32x4 v[Cfg::VPL], tv[Cfg::VPL], lw[Cfg::VPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < Cfg::VPL; ++i) {
+      const int c = (i * Cfg::LP + ll) * 4;
+      v[i] = *reinterpret_cast<const f32x4*>(fp + c);
+      tv[i] = *reinterpret_cast<const f32x4*>(tp + c);
+      lw[i] = *reinterpret_cast<const f32x4*>(k.lin + c);
+      ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    ss = group_sum<Cfg::LP>(ss);
+    const float nrm = sqrtf(ss);
+    const float inv = 1.f / (nrm + 1e-10f);
+    const float w = k.wt[(size_t)b * k.wt_bstride + p];
+    if (!BWD) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < Cfg::VPL; ++i) {
+        const f32x4 e = v[i] * inv - tv[i];
+        const f32x4 q = lw[i] * e * e;
+        d += (q.x + q.y) + (q.z + q.w);
+      }
+      d = group_sum<Cfg::LP>(d);
+      contrib = (ll == 0) ? d * w : 0.f;
+    } else {
+      // u_c = 2 lin_c (nf_c - nt_c);  dd/df_j = u_j*inv - (sum_c u_c f_c) f_j inv^2 / nrm
+      f32x4 u[Cfg::VPL];
+      float uf = 0.f;
+#pragma unroll
+      for (int i = 0; i < Cfg::VPL; ++i) {
+        u[i] = 2.f * lw[i] * (v[i] * inv - tv[i]);
+        uf += (u[i].x * v[i].x + u[i].y * v[i].y) + (u[i].z * v[i].z + u[i].w * v[i].w);
+      }
+      uf = group_sum<Cfg::LP>(uf);
+      const float gsw = k.gscale[b] * w;
+      const float c2 = (nrm > 0.f) ? uf * inv * inv / nrm : 0.f;
+      float* dp = k.out + ((size_t)b * k.P + p) * C;
+#pragma unroll
+      for (int i = 0; i < Cfg::VPL; ++i) {
+        const f32x4 g = gsw * (u[i] * inv - c2 * v[i]);
+        *reinterpret_cast<f32x4*>(dp + (i * Cfg::LP + ll) * 4) = g;
+      }
+    }
+  }
+  if (!BWD) {
+    const float s = block_sum_256(contrib, red);
+    if (threadIdx.x == 0) k.out[(size_t)b * k.nblk + blockIdx.x] = s;
+  }
+}
+
+// adjoint of bilinear upsampling (align_corners=False) h x w -> H x W
+__global__ void bilinear_adjoint_kernel(const float* wsrc, float* wt, int H, int W,
+                                        int h, int w) {
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= h * w) return;
+  const int qy = q / w, qx = q - qy * w;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int ry = H / h, rx = W / w;
+  const int py0 = max(0, (qy - 1) * ry), py1 = min(H, (qy + 2) * ry);
+  const int px0 = max(0, (qx - 1) * rx), px1 = min(W, (qx + 2) * rx);
+  float acc = 0.f;
+  for (int py = py0; py < py1; ++py) {
+    const float fy = fmaxf(sy * (py + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0;
+    float wy = 0.f;
+    if (y0 == qy) wy += 1.f - ly;
+    if (y1 == qy) wy += ly;
+    if (wy == 0.f) continue;
+    float row = 0.f;
+    for (int px = px0; px < px1; ++px) {
+      const float fx = fmaxf(sx * (px + 0.5f) - 0.5f, 0.f);
+      const int x0 = (int)fx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - x0;
+      float wx = 0.f;
+      if (x0 == qx) wx += 1.f - lx;
+      if (x1 == qx) wx += lx;
+      if (wx != 0.f) row += wx * wsrc[((size_t)b * H + py) * W + px];
+    }
+    acc += wy * row;
+  }
+  wt[(size_t)b * h * w + q] = acc;
+}
+
+// wsrc[b][p] = sum_c weight[b][c][p] * mask[b][c][p]
+__global__ void weight_map_kernel(const float* weight, const float* mask, float* wsrc,
+                                  int HW) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const size_t base = (size_t)b * 3 * HW + p;
+  float a = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float w = weight[base + (size_t)c * HW];
+    if (mask) w *= mask[base + (size_t)c * HW];
+    a += w;
+  }
+  wsrc[(size_t)b * HW + p] = a;
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* partial,
+                                                          float* out, int n, float scale,
+                                                          const float* div,
+                                                          int accumulate) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[(size_t)b * n + i];
+  float s = block_sum_256(acc, red) * scale;
+  if (threadIdx.x == 0) {
+    if (div) s /= div[b];
+    out[b] = accumulate ? out[b] + s : s;
+  }
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n,
+                            float step_size, float beta1, float beta2, float eps,
+                            float bc2_sqrt) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  // torch.optim.Adam (single tensor): exp_avg.lerp_(grad, 1-beta1);
+  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2);
+  // denom = sqrt(exp_avg_sq)/sqrt(bc2) + eps ; p += -step_size * exp_avg/denom
+  const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+  const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+
+__global__ void clamp_kernel(float* p, long long n, float lo, float hi) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+
+__global__ void mfma_probe_kernel(const float* A, const float* B, float* C, int K) {
+  const int lane = threadIdx.x;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += 2) {
+    const float a = A[(lane & 31) * K + k + (lane >> 5)];
+    const float b = B[(k + (lane >> 5)) * 32 + (lane & 31)];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    C[row * 32 + (lane & 31)] = acc[r];
+  }
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int p2l_linear_fwd(const float* x, const float* W, const float* bias,
+                              float* y, int Bn, int K, int N, void* stream) {
+  if (!x || !W || !y || K % 4 || K > 1024 || Bn < 1) return P2L_EINVAL;
+  constexpr int BG = 16;
+  const size_t lds = (size_t)(BG * K + 4 * BG * 64) * sizeof(float);
+  for (int b0 = 0; b0 < Bn; b0 += BG) {
+    hipLaunchKernelGGL(linear_fwd_kernel<BG>, dim3(cdiv(N, 64)), dim3(256), lds,
+                       ST(stream), x, W, bias, y, Bn, b0, K, N);
+  }
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn,
+                              int K, int N, int accumulate, void* stream) {
+  if (!dy || !W || !dx || Bn < 1) return P2L_EINVAL;
+  constexpr int BG = 16;
+  for (int b0 = 0; b0 < Bn; b0 += BG)
+    hipLaunchKernelGGL(linear_bwd_kernel<BG>, dim3(K), dim3(256), 0, ST(stream), dy,
+                       W, dx, Bn, b0, K, N, accumulate);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_cbn_fold_fwd(const float* g_raw, const float* b_raw,
+                                const float* mean, const float* rstd, float* s,
+                                float* t, int Bn, int C, int raw_ld, void* stream) {
+  hipLaunchKernelGGL(cbn_fold_fwd_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0,
+                     ST(stream), g_raw, b_raw, mean, rstd, s, t, Bn, C, raw_ld);
+  return p2l_check_launch();
+}
+extern "C" int p2l_cbn_fold_bwd(const float* ds, const float* dt, const float* mean,
+                                const float* rstd, float* dg_raw, float* db_raw,
+                                int Bn, int C, int raw_ld, void* stream) {
+  hipLaunchKernelGGL(cbn_fold_bwd_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0,
+                     ST(stream), ds, dt, mean, rstd, dg_raw, db_raw, Bn, C, raw_ld);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_affine_relu_bwd_nblk(int P) { return cdiv(P, ARB_SLAB); }
+
+extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
+                                   int x_ld, const float* s, const float* t,
+                                   int st_bstride, const float* skip, int skip_ld,
+                                   int skip_C, int skip_ups, float* dx, int dx_ld,
+                                   float* ds, float* dt, int dsdt_bstride,
+                                   float* partial, int Bn, int H, int W, int C,
+                                   void* stream) {
+  if (!da || !x || !s || !t || !dx || !ds || !dt || !partial) return P2L_EINVAL;
+  if (C % 64 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
+  if (skip && (skip_ld % 4 || skip_C % 4)) return P2L_EINVAL;
+  ArbK k{};
+  k.da = da; k.x = x; k.s = s; k.t = t; k.skip = skip; k.dx = dx; k.partial = partial;
+  k.da_ld = da_ld; k.x_ld = x_ld; k.dx_ld = dx_ld; k.skip_ld = skip_ld;
+  k.skip_C = skip_C; k.skip_ups = skip_ups; k.st_bstride = st_bstride;
+  k.Bn = Bn; k.P = H * W; k.C = C; k.H = H; k.W = W;
+  k.nblk = cdiv(k.P, ARB_SLAB);
+  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0,
+                     ST(stream), k);
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0,
+                     ST(stream), partial, ds, dt, Bn, k.nblk, C, dsdt_bstride);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_softmax_fwd(const float* S, float* P, int64_t rows, int cols,
+                               void* stream) {
+  const dim3 grid(cdiv(rows, 4)), block(256);
+  if (cols == 1024) hipLaunchKernelGGL(softmax_fwd_kernel<4>, grid, block, 0, ST(stream), S, P, (long long)rows, cols);
+  else if (cols == 256) hipLaunchKernelGGL(softmax_fwd_kernel<1>, grid, block, 0, ST(stream), S, P, (long long)rows, cols);
+  else if (cols == 512) hipLaunchKernelGGL(softmax_fwd_kernel<2>, grid, block, 0, ST(stream), S, P, (long long)rows, cols);
+  else if (cols == 2048) hipLaunchKernelGGL(softmax_fwd_kernel<8>, grid, block, 0, ST(stream), S, P, (long long)rows, cols);
+  else return P2L_EUNSUP;
+  return p2l_check_launch();
+}
+extern "C" int p2l_softmax_bwd(const float* P, const float* dP, float* dS,
+                               int64_t rows, int cols, void* stream) {
+  const dim3 grid(cdiv(rows, 4)), block(256);
+  if (cols == 1024) hipLaunchKernelGGL(softmax_bwd_kernel<4>, grid, block, 0, ST(stream), P, dP, dS, (long long)rows, cols);
+  else if (cols == 256) hipLaunchKernelGGL(softmax_bwd_kernel<1>, grid, block, 0, ST(stream), P, dP, dS, (long long)rows, cols);
+  else if (cols == 512) hipLaunchKernelGGL(softmax_bwd_kernel<2>, grid, block, 0, ST(stream), P, dP, dS, (long long)rows, cols);
+  else if (cols == 2048) hipLaunchKernelGGL(softmax_bwd_kernel<8>, grid, block, 0, ST(stream), P, dP, dS, (long long)rows, cols);
+  else return P2L_EUNSUP;
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_maxpool2_bwd(const float* y, int y_ld, const float* dyp,
+                                int dyp_ld, const float* add, int add_ld, float* dy,
+                                int dy_ld, int Bn, int H, int W, int C,
+                                int relu_mask, void* stream) {
+  if (C % 4 || (H & 1) || (W & 1)) return P2L_EINVAL;
+  const size_t total = (size_t)Bn * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                     ST(stream), y, y_ld, dyp, dyp_ld, add, add_ld, dy, dy_ld, Bn, H,
+                     W, C, relu_mask);
+  return p2l_check_launch();
+}
+extern "C" int p2l_relu_mask(const float* y, int y_ld, const float* g, int g_ld,
+                             float* dy, int dy_ld, int64_t P, int C, void* stream) {
+  if (C % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(cdiv((size_t)P * (C / 4), 256)), dim3(256),
+                     0, ST(stream), y, y_ld, g, g_ld, dy, dy_ld, (long long)P, C);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_nchw3_to_nhwc16(const float* src, float* dst, int Bn, int H, int W,
+                                   void* stream) {
+  hipLaunchKernelGGL(nchw3_to_nhwc16_kernel, dim3(cdiv((size_t)Bn * H * W, 256)),
+                     dim3(256), 0, ST(stream), src, dst, Bn, H * W);
+  return p2l_check_launch();
+}
+extern "C" int p2l_nhwc16_to_nchw3(const float* src, float* dst, int Bn, int H, int W,
+                                   void* stream) {
+  hipLaunchKernelGGL(nhwc16_to_nchw3_kernel, dim3(cdiv((size_t)Bn * H * W, 256)),
+                     dim3(256), 0, ST(stream), src, dst, Bn, H * W);
+  return p2l_check_launch();
+}
+extern "C" int p2l_tanh_bwd16(const float* img, float* dimg, int64_t P, void* stream) {
+  hipLaunchKernelGGL(tanh_bwd16_kernel, dim3(cdiv(P, 256)), dim3(256), 0, ST(stream),
+                     img, dimg, (long long)P);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_weight_sum(const float* weight, const float* loss_mask, float* wsum,
+                              int Bn, int HW3, void* stream) {
+  hipLaunchKernelGGL(weight_sum_kernel, dim3(Bn), dim3(1024), 0, ST(stream), weight,
+                     loss_mask, wsum, HW3);
+  return p2l_check_launch();
+}
+extern "C" int p2l_weight_map(const float* weight, const float* loss_mask, float* wsrc,
+                              int Bn, int H, int W, void* stream) {
+  hipLaunchKernelGGL(weight_map_kernel, dim3(cdiv(H * W, 256), Bn), dim3(256), 0,
+                     ST(stream), weight, loss_mask, wsrc, H * W);
+  return p2l_check_launch();
+}
+extern "C" int p2l_l1_loss_nblk(int H, int W) { return cdiv(H * W, 256); }
+extern "C" int p2l_l1_loss_fwd(const float* img16, const float* target,
+                               const float* weight, const float* loss_mask,
+                               const float* wsum, float* loss, float* partial, int Bn,
+                               int H, int W, void* stream) {
+  const int nblk = cdiv(H * W, 256);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(nblk, Bn), dim3(256), 0, ST(stream), img16,
+                     target, weight, loss_mask, partial, H * W);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(Bn), dim3(256), 0, ST(stream), partial,
+                     loss, nblk, 1.f, wsum, 0);
+  return p2l_check_launch();
+}
+extern "C" int p2l_l1_loss_bwd(const float* img16, const float* target,
+                               const float* weight, const float* loss_mask,
+                               const float* wsum, const float* gscale, float* dimg16,
+                               int Bn, int H, int W, int accumulate, void* stream) {
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(cdiv(H * W, 256), Bn), dim3(256), 0,
+                     ST(stream), img16, target, weight, loss_mask, wsum, gscale,
+                     dimg16, H * W, accumulate);
+  return p2l_check_launch();
+}
+
+#define P2L_LPIPS_DISPATCH(CALL)        \
+  switch (C) {                          \
+    case 64: CALL(64); break;           \
+    case 128: CALL(128); break;         \
+    case 256: CALL(256); break;         \
+    case 512: CALL(512); break;         \
+    default: return P2L_EUNSUP;         \
+  }
+
+extern "C" int p2l_lpips_normalize(const float* f, float* nf, int64_t P, int C,
+                                   void* stream) {
+#define CALL(CC)                                                                   \
+  hipLaunchKernelGGL(lpips_normalize_kernel<CC>,                                   \
+                     dim3(cdiv(P, 4 * LpipsCfg<CC>::PPW)), dim3(256), 0, ST(stream), \
+                     f, nf, (long long)P)
+  P2L_LPIPS_DISPATCH(CALL)
+#undef CALL
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_lpips_tap_nblk(int P, int C) {
+  const int lp = (C / 4 >= 64) ? 64 : C / 4;
+  return cdiv(P, 4 * (64 / lp));
+}
+
+extern "C" int p2l_lpips_tap_fwd(const float* f, const float* nft,
+                                 int64_t nft_bstride, const float* lin,
+                                 const float* wt, int64_t wt_bstride,
+                                 float* loss_partial, int Bn, int P, int C,
+                                 void* stream) {
+  LpipsK k{};
+  k.f = f; k.nft = nft; k.lin = lin; k.wt = wt; k.gscale = nullptr;
+  k.out = loss_partial; k.nft_bstride = nft_bstride; k.wt_bstride = wt_bstride;
+  k.Bn = Bn; k.P = P; k.nblk = p2l_lpips_tap_nblk(P, C);
+#define CALL(CC)                                                                \
+  hipLaunchKernelGGL((lpips_tap_kernel<CC, false>), dim3(k.nblk, Bn), dim3(256), 0, \
+                     ST(stream), k)
+  P2L_LPIPS_DISPATCH(CALL)
+#undef CALL
+  return p2l_check_launch();
+}
+extern "C" int p2l_lpips_tap_bwd(const float* f, const float* nft,
+                                 int64_t nft_bstride, const float* lin,
+                                 const float* wt, int64_t wt_bstride,
+                                 const float* gscale, float* df, int Bn, int P, int C,
+                                 void* stream) {
+  LpipsK k{};
+  k.f = f; k.nft = nft; k.lin = lin; k.wt = wt; k.gscale = gscale;
+  k.out = df; k.nft_bstride = nft_bstride; k.wt_bstride = wt_bstride;
+  k.Bn = Bn; k.P = P; k.nblk = p2l_lpips_tap_nblk(P, C);
+#define CALL(CC)                                                               \
+  hipLaunchKernelGGL((lpips_tap_kernel<CC, true>), dim3(k.nblk, Bn), dim3(256), 0, \
+                     ST(stream), k)
+  P2L_LPIPS_DISPATCH(CALL)
+#undef CALL
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_bilinear_adjoint(const float* wsrc, float* wt, int Bn, int H, int W,
+                                    int h, int w, void* stream) {
+  if (H % h || W % w) return P2L_EINVAL;
+  hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv(h * w, 256), Bn), dim3(256), 0,
+                     ST(stream), wsrc, wt, H, W, h, w);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_reduce_rows(const float* partial, float* out, int Bn, int n,
+                               float scale, const float* div, int accumulate,
+                               void* stream) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(Bn), dim3(256), 0, ST(stream), partial,
+                     out, n, scale, div, accumulate);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                             float lr, float beta1, float beta2, float eps,
+                             int step_count, void* stream) {
+  if (!p || !g || !m || !v || step_count < 1) return P2L_EINVAL;
+  // same host-side double arithmetic as torch.optim.adam._single_tensor_adam
+  const double bc1 = 1.0 - pow((double)beta1, (double)step_count);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step_count);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), p, g, m,
+                     v, (long long)n, step_size, beta1, beta2, eps, bc2_sqrt);
+  return p2l_check_launch();
+}
+extern "C" int p2l_clamp(float* p, int64_t n, float lo, float hi, void* stream) {
+  hipLaunchKernelGGL(clamp_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), p,
+                     (long long)n, lo, hi);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_mfma_probe(const float* A, const float* B, float* C, int K,
+                              void* stream) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, ST(stream), A, B, C, K);
+  return p2l_check_launch();
+}

@@ -1,0 +1,723 @@
+// Native runtime of the hot path: sequences the HIP kernels of libp2l_hip into
+//   * BigGAN-deep generator forward / input-gradient backward
+//     (replaces pix2latent/model/biggan.py:58 -> HF Generator.forward and the
+//      autograd walk started by pix2latent/optimizer/closure.py:58), and
+//   * ProjectionLoss = weighted L1 + beta * weighted LPIPS-VGG16 forward/backward
+//     (replaces pix2latent/loss_functions.py:97-100,117-124,140-148).
+// Only input gradients are computed (the reference also computes and discards
+// weight gradients); target features are cached (F8).
+// No allocation, no synchronisation: one workspace arena owned by the caller,
+// every launch on the caller's stream, so a whole step can be graph-captured.
+#include "p2l_common.h"
+
+namespace {
+
+struct Arena {
+  size_t off = 0;  // in floats
+  size_t take(size_t n) {
+    const size_t o = off;
+    off += (n + 63) & ~(size_t)63;
+    return o;
+  }
+};
+
+#define RET_IF(x)          \
+  do {                     \
+    int _rc = (x);         \
+    if (_rc) return _rc;   \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// small kernels local to the plans
+// ---------------------------------------------------------------------------
+__global__ void concat2_kernel(const float* z, const float* c, float* cond, int Bn,
+                               int nz, int nc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = nz + nc;
+  if (i >= Bn * n) return;
+  const int b = i / n, j = i - b * n;
+  cond[i] = (j < nz) ? z[b * nz + j] : c[b * nc + (j - nz)];
+}
+__global__ void split2_kernel(const float* dcond, float* dz, float* dc, int Bn, int nz,
+                              int nc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = nz + nc;
+  if (i >= Bn * n) return;
+  const int b = i / n, j = i - b * n;
+  if (j < nz) dz[b * nz + j] = dcond[i];
+  else dc[b * nc + (j - nz)] = dcond[i];
+}
+__global__ void vec_scale_div_kernel(const float* a, const float* div, float* out, int n,
+                                     float scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = div ? a[i] * scale / div[i] : a[i] * scale;
+}
+
+// ---------------------------------------------------------------------------
+// conv helper
+// ---------------------------------------------------------------------------
+struct ConvCall {
+  P2LConv d{};
+  const float* x = nullptr; const float* w = nullptr; const float* bias = nullptr;
+  const float* ps = nullptr; const float* pt = nullptr; const float* res = nullptr;
+  const float* mask = nullptr; float* y = nullptr; float* yp = nullptr;
+};
+ConvCall mk_conv(int B, int H, int W, int Cin, int Cout, int taps) {
+  ConvCall c;
+  c.d.B = B; c.d.H = H; c.d.W = W; c.d.Cin = Cin; c.d.Cout = Cout; c.d.taps = taps;
+  c.d.ups = 0; c.d.x_ld = Cin; c.d.pro = P2L_PRO_NONE; c.d.pro_bstride = 0;
+  c.d.alpha = 1.f; c.d.act = P2L_ACT_NONE; c.d.pool = P2L_POOL_NONE;
+  c.d.y_ld = Cout; c.d.yp_ld = Cout; c.d.n_store = Cout; c.d.res_ld = 0;
+  c.d.res_ups = 0; c.d.mask_ld = 0; c.d.splitk = 1;
+  return c;
+}
+size_t conv_ws_floats(ConvCall& c) {
+  c.d.splitk = p2l_conv_suggest_splitk(&c.d);
+  return p2l_conv_workspace_bytes(&c.d) / sizeof(float);
+}
+int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
+  c.d.splitk = p2l_conv_suggest_splitk(&c.d);
+  return p2l_conv_fwd(&c.d, c.x, c.w, c.bias, c.ps, c.pt, c.res, c.mask, c.y, c.yp, skws,
+                      skws_floats * sizeof(float), st);
+}
+
+// ---------------------------------------------------------------------------
+// BigGAN workspace layout
+// ---------------------------------------------------------------------------
+struct BGBlockOff {
+  size_t h1, h2, h3, y;
+  int H, Ho;  // input / output resolution
+};
+struct BGLayout {
+  size_t cond, raw, s, t, ds, dt, draw, dcond;
+  size_t x0;  // gen_z output
+  BGBlockOff blk[P2L_MAX_BLOCKS];
+  // attention
+  size_t att_theta, att_phi, att_phi_p, att_g, att_g_p, att_P, att_ag, att_y;
+  int att_H;
+  // backward temporaries
+  size_t g_a, g_b, g_c;     // ping-pong gradient buffers (max activation size)
+  size_t arb_partial;
+  size_t d_theta, d_phi_p, d_phi, d_g_p, d_g, d_ag;
+  size_t skws; size_t skws_floats;
+  size_t total;
+  int out_res;
+};
+
+int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
+  if (!m || m->n_blocks < 1 || m->n_blocks > P2L_MAX_BLOCKS || B < 1) return P2L_EINVAL;
+  Arena a;
+  const int cond = m->z_dim + m->c_dim;
+  L.cond = a.take((size_t)B * cond);
+  L.raw = a.take((size_t)B * 2 * m->cbn_total);
+  L.s = a.take((size_t)B * m->cbn_total);
+  L.t = a.take((size_t)B * m->cbn_total);
+  L.ds = a.take((size_t)B * m->cbn_total);
+  L.dt = a.take((size_t)B * m->cbn_total);
+  L.draw = a.take((size_t)B * 2 * m->cbn_total);
+  L.dcond = a.take((size_t)B * cond);
+  int H = 4;
+  L.x0 = a.take((size_t)B * H * H * 16 * m->ch);
+  size_t max_act = (size_t)B * H * H * 16 * m->ch;
+  size_t max_partial = 0, max_sk = 0;
+  auto upd_sk = [&](int Hc, int Cin, int Cout, int taps) {
+    ConvCall c = mk_conv(B, Hc, Hc, Cin, Cout, taps);
+    const size_t f = conv_ws_floats(c);
+    if (f > max_sk) max_sk = f;
+  };
+  for (int i = 0; i < m->n_blocks; ++i) {
+    if (i == m->attn_before) {
+      const int C = m->attn_ch;
+      const size_t P = (size_t)H * H;
+      L.att_H = H;
+      L.att_theta = a.take(B * P * (C / 8));
+      L.att_phi = a.take(B * P * (C / 8));
+      L.att_phi_p = a.take(B * (P / 4) * (C / 8));
+      L.att_g = a.take(B * P * (C / 2));
+      L.att_g_p = a.take(B * (P / 4) * (C / 2));
+      L.att_P = a.take(B * P * (P / 4));
+      L.att_ag = a.take(B * P * (C / 2));
+      L.att_y = a.take(B * P * C);
+      L.d_theta = a.take(B * P * (C / 8));
+      L.d_phi_p = a.take(B * (P / 4) * (C / 8));
+      L.d_phi = a.take(B * P * (C / 8));
+      L.d_g_p = a.take(B * (P / 4) * (C / 2));
+      L.d_g = a.take(B * P * (C / 2));
+      L.d_ag = a.take(B * P * (C / 2));
+      if (B * P * (P / 4) > max_act) max_act = B * P * (P / 4);  // dP temp
+    }
+    const P2LGenBlock& g = m->blocks[i];
+    const int mid = g.cin / 4;
+    const int Ho = g.up ? 2 * H : H;
+    BGBlockOff& o = L.blk[i];
+    o.H = H; o.Ho = Ho;
+    o.h1 = a.take((size_t)B * H * H * mid);
+    o.h2 = a.take((size_t)B * Ho * Ho * mid);
+    o.h3 = a.take((size_t)B * Ho * Ho * mid);
+    o.y = a.take((size_t)B * Ho * Ho * g.cout);
+    const size_t acts[] = {(size_t)B * H * H * g.cin, (size_t)B * Ho * Ho * mid,
+                           (size_t)B * Ho * Ho * g.cout};
+    for (size_t v : acts) if (v > max_act) max_act = v;
+    const int nblk = p2l_affine_relu_bwd_nblk(Ho * Ho);
+    const size_t cmax = (size_t)(g.cin > mid ? g.cin : mid);
+    const size_t pf = 2 * (size_t)B * nblk * cmax;
+    if (pf > max_partial) max_partial = pf;
+    // split-K workspace for fwd and dgrad convs of this block
+    upd_sk(H, g.cin, mid, 1);  upd_sk(Ho, mid, mid, 9);  upd_sk(Ho, mid, g.cout, 1);
+    upd_sk(Ho, g.cout, mid, 1);  upd_sk(H, mid, g.cin, 1);
+    H = Ho;
+  }
+  L.out_res = H;
+  {
+    const int nblk = p2l_affine_relu_bwd_nblk(H * H);
+    const size_t pf = 2 * (size_t)B * nblk * m->ch;
+    if (pf > max_partial) max_partial = pf;
+    if ((size_t)B * H * H * m->ch > max_act) max_act = (size_t)B * H * H * m->ch;
+  }
+  L.g_a = a.take(max_act);
+  L.g_b = a.take(max_act);
+  L.g_c = a.take(max_act);
+  L.arb_partial = a.take(max_partial);
+  L.skws_floats = max_sk;
+  L.skws = a.take(max_sk ? max_sk : 64);
+  L.total = a.off;
+  return P2L_OK;
+}
+
+}  // namespace
+
+extern "C" int p2l_vec_scale_div(const float* a, const float* div, float* out, int n,
+                                 float scale, void* stream) {
+  hipLaunchKernelGGL(vec_scale_div_kernel, dim3(cdiv(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, div, out, n, scale);
+  return p2l_check_launch();
+}
+extern "C" int p2l_concat2(const float* z, const float* c, float* cond, int Bn, int nz,
+                           int nc, void* stream) {
+  hipLaunchKernelGGL(concat2_kernel, dim3(cdiv(Bn * (nz + nc), 256)), dim3(256), 0,
+                     (hipStream_t)stream, z, c, cond, Bn, nz, nc);
+  return p2l_check_launch();
+}
+extern "C" int p2l_split2(const float* dcond, float* dz, float* dc, int Bn, int nz,
+                          int nc, void* stream) {
+  hipLaunchKernelGGL(split2_kernel, dim3(cdiv(Bn * (nz + nc), 256)), dim3(256), 0,
+                     (hipStream_t)stream, dcond, dz, dc, Bn, nz, nc);
+  return p2l_check_launch();
+}
+
+extern "C" size_t p2l_biggan_ws_bytes(const P2LBigGAN* m, int Bn) {
+  BGLayout L;
+  if (bg_layout(m, Bn, L)) return 0;
+  return L.total * sizeof(float);
+}
+
+extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Lidx,
+                                    size_t* float_off, int32_t shape[4]) {
+  BGLayout L;
+  RET_IF(bg_layout(m, Bn, L));
+  if (what == 1) {
+    *float_off = L.x0; shape[0] = Bn; shape[1] = 4; shape[2] = 4; shape[3] = 16 * m->ch;
+    return P2L_OK;
+  }
+  if (what >= 2 && what <= 5) {
+    *float_off = what == 2 ? L.s : what == 3 ? L.t : what == 4 ? L.ds : L.dt;
+    shape[0] = Bn; shape[1] = 1; shape[2] = 1; shape[3] = m->cbn_total;
+    return P2L_OK;
+  }
+  if (what != 0) return P2L_EINVAL;
+  // ModuleList index -> block index (SelfAttn occupies index attn_before)
+  int idx = 0;
+  for (int i = 0; i < m->n_blocks; ++i) {
+    if (i == m->attn_before) {
+      if (idx == Lidx) {
+        *float_off = L.att_y; shape[0] = Bn; shape[1] = L.att_H; shape[2] = L.att_H;
+        shape[3] = m->attn_ch;
+        return P2L_OK;
+      }
+      ++idx;
+    }
+    if (idx == Lidx) {
+      *float_off = L.blk[i].y; shape[0] = Bn; shape[1] = L.blk[i].Ho;
+      shape[2] = L.blk[i].Ho; shape[3] = m->blocks[i].cout;
+      return P2L_OK;
+    }
+    ++idx;
+  }
+  return P2L_EINVAL;
+}
+
+extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c, int B,
+                              void* ws, size_t ws_bytes, float* img16, void* st) {
+  BGLayout L;
+  RET_IF(bg_layout(m, B, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !z || !c || !img16) return P2L_EWS;
+  float* W = (float*)ws;
+  const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
+  float* skws = W + L.skws;
+
+  RET_IF(p2l_concat2(z, c, W + L.cond, B, m->z_dim, m->c_dim, st));
+  RET_IF(p2l_linear_fwd(W + L.cond, m->cbn_w, nullptr, W + L.raw, B, cond, 2 * CT, st));
+  RET_IF(p2l_cbn_fold_fwd(W + L.raw, W + L.raw + CT, m->cbn_mean, m->cbn_rstd, W + L.s,
+                          W + L.t, B, CT, 2 * CT, st));
+  RET_IF(p2l_linear_fwd(W + L.cond, m->genz_w, m->genz_b, W + L.x0, B, cond,
+                        16 * 16 * m->ch, st));
+
+  const float* x = W + L.x0;
+  int Cx = 16 * m->ch;
+  for (int i = 0; i < m->n_blocks; ++i) {
+    if (i == m->attn_before) {
+      const int C = m->attn_ch, H = L.att_H, P = H * H;
+      if (C != Cx) return P2L_EINVAL;
+      ConvCall th = mk_conv(B, H, H, C, C / 8, 1);
+      th.x = x; th.w = m->att_w[0]; th.y = W + L.att_theta;
+      RET_IF(run_conv(th, skws, L.skws_floats, st));
+      ConvCall ph = mk_conv(B, H, H, C, C / 8, 1);
+      ph.x = x; ph.w = m->att_w[1]; ph.y = W + L.att_phi; ph.yp = W + L.att_phi_p;
+      ph.d.pool = P2L_POOL_MAX;
+      RET_IF(run_conv(ph, skws, L.skws_floats, st));
+      ConvCall gg = mk_conv(B, H, H, C, C / 2, 1);
+      gg.x = x; gg.w = m->att_w[2]; gg.y = W + L.att_g; gg.yp = W + L.att_g_p;
+      gg.d.pool = P2L_POOL_MAX;
+      RET_IF(run_conv(gg, skws, L.skws_floats, st));
+      // S = theta^T phi  -> [B, P, P/4]
+      P2LGemm g1{};
+      g1.batch = B; g1.M = P; g1.N = P / 4; g1.K = C / 8;
+      g1.lda = C / 8; g1.ldb = C / 8; g1.ldc = P / 4;
+      g1.stride_a = (int64_t)P * (C / 8); g1.stride_b = (int64_t)(P / 4) * (C / 8);
+      g1.stride_c = (int64_t)P * (P / 4);
+      g1.a_kmajor = 0; g1.b_kmajor = 0; g1.alpha = 1.f; g1.accumulate = 0;
+      RET_IF(p2l_gemm(&g1, W + L.att_theta, W + L.att_phi_p, W + L.att_P, st));
+      RET_IF(p2l_softmax_fwd(W + L.att_P, W + L.att_P, (int64_t)B * P, P / 4, st));
+      // attn_g[p, :] = sum_k P[p,k] g[k, :]
+      P2LGemm g2{};
+      g2.batch = B; g2.M = P; g2.N = C / 2; g2.K = P / 4;
+      g2.lda = P / 4; g2.ldb = C / 2; g2.ldc = C / 2;
+      g2.stride_a = (int64_t)P * (P / 4); g2.stride_b = (int64_t)(P / 4) * (C / 2);
+      g2.stride_c = (int64_t)P * (C / 2);
+      g2.a_kmajor = 0; g2.b_kmajor = 1; g2.alpha = 1.f; g2.accumulate = 0;
+      RET_IF(p2l_gemm(&g2, W + L.att_P, W + L.att_g_p, W + L.att_ag, st));
+      ConvCall oc = mk_conv(B, H, H, C / 2, C, 1);
+      oc.x = W + L.att_ag; oc.w = m->att_w[3]; oc.y = W + L.att_y;
+      oc.d.alpha = m->gamma; oc.res = x; oc.d.res_ld = C;
+      RET_IF(run_conv(oc, skws, L.skws_floats, st));
+      x = W + L.att_y;
+    }
+    const P2LGenBlock& g = m->blocks[i];
+    const BGBlockOff& o = L.blk[i];
+    if (g.cin != Cx) return P2L_EINVAL;
+    const int mid = g.cin / 4;
+    // conv_0 : relu(cbn_0(x)) 1x1 cin -> mid
+    ConvCall c0 = mk_conv(B, o.H, o.H, g.cin, mid, 1);
+    c0.x = x; c0.w = g.w[0]; c0.bias = g.b[0]; c0.y = W + o.h1;
+    c0.d.pro = P2L_PRO_AFFINE_RELU; c0.d.pro_bstride = CT;
+    c0.ps = W + L.s + g.cbn_off[0]; c0.pt = W + L.t + g.cbn_off[0];
+    RET_IF(run_conv(c0, skws, L.skws_floats, st));
+    // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
+    ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
+    c1.x = W + o.h1; c1.w = g.w[1]; c1.bias = g.b[1]; c1.y = W + o.h2; c1.d.ups = g.up;
+    c1.d.pro = P2L_PRO_AFFINE_RELU; c1.d.pro_bstride = CT;
+    c1.ps = W + L.s + g.cbn_off[1]; c1.pt = W + L.t + g.cbn_off[1];
+    RET_IF(run_conv(c1, skws, L.skws_floats, st));
+    ConvCall c2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
+    c2.x = W + o.h2; c2.w = g.w[2]; c2.bias = g.b[2]; c2.y = W + o.h3;
+    c2.d.pro = P2L_PRO_AFFINE_RELU; c2.d.pro_bstride = CT;
+    c2.ps = W + L.s + g.cbn_off[2]; c2.pt = W + L.t + g.cbn_off[2];
+    RET_IF(run_conv(c2, skws, L.skws_floats, st));
+    // conv_3 : 1x1 mid -> cout, + shortcut (channel-truncated, nearest x2)
+    ConvCall c3 = mk_conv(B, o.Ho, o.Ho, mid, g.cout, 1);
+    c3.x = W + o.h3; c3.w = g.w[3]; c3.bias = g.b[3]; c3.y = W + o.y;
+    c3.d.pro = P2L_PRO_AFFINE_RELU; c3.d.pro_bstride = CT;
+    c3.ps = W + L.s + g.cbn_off[3]; c3.pt = W + L.t + g.cbn_off[3];
+    c3.res = x; c3.d.res_ld = g.cin; c3.d.res_ups = g.up;
+    RET_IF(run_conv(c3, skws, L.skws_floats, st));
+    x = W + o.y;
+    Cx = g.cout;
+  }
+  if (Cx != m->ch) return P2L_EINVAL;
+  // tail: relu(bn(x)) -> conv_to_rgb (3 of ch outputs) -> tanh, NHWC16
+  ConvCall rc = mk_conv(B, L.out_res, L.out_res, m->ch, 32, 9);
+  rc.x = x; rc.w = m->rgb_w; rc.bias = m->rgb_b; rc.y = img16;
+  rc.d.pro = P2L_PRO_AFFINE_RELU; rc.d.pro_bstride = 0; rc.ps = m->tail_s; rc.pt = m->tail_t;
+  rc.d.act = P2L_ACT_TANH; rc.d.y_ld = 16; rc.d.n_store = 16;
+  RET_IF(run_conv(rc, skws, L.skws_floats, st));
+  return P2L_OK;
+}
+
+extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_bytes,
+                              const float* img16, float* dimg16, float* dz, float* dc,
+                              void* st) {
+  BGLayout L;
+  RET_IF(bg_layout(m, B, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !img16 || !dimg16 || !dz || !dc)
+    return P2L_EWS;
+  float* W = (float*)ws;
+  const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
+  float* skws = W + L.skws;
+  float* part = W + L.arb_partial;
+  float* ga = W + L.g_a;   // gradient w.r.t. the current layer's output
+  float* gb = W + L.g_b;   // scratch
+  float* gc = W + L.g_c;   // scratch
+
+  const int R = L.out_res;
+  RET_IF(p2l_tanh_bwd16(img16, dimg16, (int64_t)B * R * R, st));
+  {
+    // conv_to_rgb input-gradient, then the unconditional BN+ReLU backward.
+    ConvCall c = mk_conv(B, R, R, 16, m->ch, 9);
+    c.x = dimg16; c.w = m->rgb_wt; c.y = gb;
+    RET_IF(run_conv(c, skws, L.skws_floats, st));
+    const float* xlast = W + L.blk[m->n_blocks - 1].y;
+    // ds/dt of the tail BN feed nothing (no conditioning): park them in `draw`.
+    RET_IF(p2l_affine_relu_bwd(gb, m->ch, xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr,
+                               0, 0, 0, ga, m->ch, W + L.draw,
+                               W + L.draw + (size_t)B * m->ch, m->ch, part, B, R, R, m->ch,
+                               st));
+  }
+  for (int i = m->n_blocks - 1; i >= 0; --i) {
+    const P2LGenBlock& g = m->blocks[i];
+    const BGBlockOff& o = L.blk[i];
+    const int mid = g.cin / 4;
+    const float* xin;
+    if (i == m->attn_before) xin = W + L.att_y;
+    else if (i == 0) xin = W + L.x0;
+    else xin = W + L.blk[i - 1].y;
+
+    // conv_3 input-gradient: dy[cout] -> [mid]; then relu(cbn_3) backward
+    ConvCall d3 = mk_conv(B, o.Ho, o.Ho, g.cout, mid, 1);
+    d3.x = ga; d3.w = g.wt[3]; d3.y = gb;
+    RET_IF(run_conv(d3, skws, L.skws_floats, st));
+    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h3, mid, W + L.s + g.cbn_off[3],
+                               W + L.t + g.cbn_off[3], CT, nullptr, 0, 0, 0, gc, mid,
+                               W + L.ds + g.cbn_off[3], W + L.dt + g.cbn_off[3], CT, part,
+                               B, o.Ho, o.Ho, mid, st));
+    // conv_2
+    ConvCall d2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
+    d2.x = gc; d2.w = g.wt[2]; d2.y = gb;
+    RET_IF(run_conv(d2, skws, L.skws_floats, st));
+    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h2, mid, W + L.s + g.cbn_off[2],
+                               W + L.t + g.cbn_off[2], CT, nullptr, 0, 0, 0, gc, mid,
+                               W + L.ds + g.cbn_off[2], W + L.dt + g.cbn_off[2], CT, part,
+                               B, o.Ho, o.Ho, mid, st));
+    // conv_1 (+ nearest-x2 backward = 2x2 sum pool fused in the epilogue)
+    ConvCall d1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
+    d1.x = gc; d1.w = g.wt[1];
+    if (g.up) { d1.d.pool = P2L_POOL_SUM; d1.yp = gb; d1.y = nullptr; }
+    else d1.y = gb;
+    RET_IF(run_conv(d1, skws, L.skws_floats, st));
+    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h1, mid, W + L.s + g.cbn_off[1],
+                               W + L.t + g.cbn_off[1], CT, nullptr, 0, 0, 0, gc, mid,
+                               W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT, part,
+                               B, o.H, o.H, mid, st));
+    // conv_0, then relu(cbn_0) backward + shortcut gradient from dy (= ga)
+    ConvCall d0 = mk_conv(B, o.H, o.H, mid, g.cin, 1);
+    d0.x = gc; d0.w = g.wt[0]; d0.y = gb;
+    RET_IF(run_conv(d0, skws, L.skws_floats, st));
+    const int skipC = (g.cin != g.cout) ? g.cin / 2 : g.cin;
+    RET_IF(p2l_affine_relu_bwd(gb, g.cin, xin, g.cin, W + L.s + g.cbn_off[0],
+                               W + L.t + g.cbn_off[0], CT, ga, g.cout, skipC, g.up, gc,
+                               g.cin, W + L.ds + g.cbn_off[0], W + L.dt + g.cbn_off[0], CT,
+                               part, B, o.H, o.H, g.cin, st));
+    { float* tmp = ga; ga = gc; gc = tmp; }
+
+    if (i == m->attn_before) {
+      // ---- SelfAttn backward; ga = d out [B,H,H,C] ------------------------
+      const int C = m->attn_ch, H = L.att_H, P = H * H;
+      const float* x = (i == 0) ? W + L.x0 : W + L.blk[i - 1].y;
+      (void)x;
+      // d attn_g = gamma * dgrad(o_conv)(dy)
+      ConvCall dob = mk_conv(B, H, H, C, C / 2, 1);
+      dob.x = ga; dob.w = m->att_wt[3]; dob.y = W + L.d_ag; dob.d.alpha = m->gamma;
+      RET_IF(run_conv(dob, skws, L.skws_floats, st));
+      // dP[p,k] = sum_c d_ag[p,c] g_p[k,c]
+      P2LGemm q1{};
+      q1.batch = B; q1.M = P; q1.N = P / 4; q1.K = C / 2;
+      q1.lda = C / 2; q1.ldb = C / 2; q1.ldc = P / 4;
+      q1.stride_a = (int64_t)P * (C / 2); q1.stride_b = (int64_t)(P / 4) * (C / 2);
+      q1.stride_c = (int64_t)P * (P / 4);
+      q1.alpha = 1.f;
+      RET_IF(p2l_gemm(&q1, W + L.d_ag, W + L.att_g_p, gb, st));
+      // d g_p[k,c] = sum_p P[p,k] d_ag[p,c]
+      P2LGemm q2{};
+      q2.batch = B; q2.M = P / 4; q2.N = C / 2; q2.K = P;
+      q2.lda = P / 4; q2.ldb = C / 2; q2.ldc = C / 2;
+      q2.stride_a = (int64_t)P * (P / 4); q2.stride_b = (int64_t)P * (C / 2);
+      q2.stride_c = (int64_t)(P / 4) * (C / 2);
+      q2.a_kmajor = 1; q2.b_kmajor = 1; q2.alpha = 1.f;
+      RET_IF(p2l_gemm(&q2, W + L.att_P, W + L.d_ag, W + L.d_g_p, st));
+      // dS = softmax backward (in place in gb)
+      RET_IF(p2l_softmax_bwd(W + L.att_P, gb, gb, (int64_t)B * P, P / 4, st));
+      // d theta[p,d] = sum_k dS[p,k] phi_p[k,d]
+      P2LGemm q3{};
+      q3.batch = B; q3.M = P; q3.N = C / 8; q3.K = P / 4;
+      q3.lda = P / 4; q3.ldb = C / 8; q3.ldc = C / 8;
+      q3.stride_a = (int64_t)P * (P / 4); q3.stride_b = (int64_t)(P / 4) * (C / 8);
+      q3.stride_c = (int64_t)P * (C / 8);
+      q3.b_kmajor = 1; q3.alpha = 1.f;
+      RET_IF(p2l_gemm(&q3, gb, W + L.att_phi_p, W + L.d_theta, st));
+      // d phi_p[k,d] = sum_p dS[p,k] theta[p,d]
+      P2LGemm q4{};
+      q4.batch = B; q4.M = P / 4; q4.N = C / 8; q4.K = P;
+      q4.lda = P / 4; q4.ldb = C / 8; q4.ldc = C / 8;
+      q4.stride_a = (int64_t)P * (P / 4); q4.stride_b = (int64_t)P * (C / 8);
+      q4.stride_c = (int64_t)(P / 4) * (C / 8);
+      q4.a_kmajor = 1; q4.b_kmajor = 1; q4.alpha = 1.f;
+      RET_IF(p2l_gemm(&q4, gb, W + L.att_theta, W + L.d_phi_p, st));
+      // max-pool backward for phi and g
+      RET_IF(p2l_maxpool2_bwd(W + L.att_phi, C / 8, W + L.d_phi_p, C / 8, nullptr, 0,
+                              W + L.d_phi, C / 8, B, H, H, C / 8, 0, st));
+      RET_IF(p2l_maxpool2_bwd(W + L.att_g, C / 2, W + L.d_g_p, C / 2, nullptr, 0,
+                              W + L.d_g, C / 2, B, H, H, C / 2, 0, st));
+      // dx = dy + theta^T-grad + phi-grad + g-grad (chained residual, in place)
+      ConvCall t1 = mk_conv(B, H, H, C / 8, C, 1);
+      t1.x = W + L.d_theta; t1.w = m->att_wt[0]; t1.y = ga; t1.res = ga; t1.d.res_ld = C;
+      RET_IF(run_conv(t1, skws, L.skws_floats, st));
+      ConvCall t2 = mk_conv(B, H, H, C / 8, C, 1);
+      t2.x = W + L.d_phi; t2.w = m->att_wt[1]; t2.y = ga; t2.res = ga; t2.d.res_ld = C;
+      RET_IF(run_conv(t2, skws, L.skws_floats, st));
+      ConvCall t3 = mk_conv(B, H, H, C / 2, C, 1);
+      t3.x = W + L.d_g; t3.w = m->att_wt[2]; t3.y = ga; t3.res = ga; t3.d.res_ld = C;
+      RET_IF(run_conv(t3, skws, L.skws_floats, st));
+    }
+  }
+  // ga = d gen_z output [B, 16*16*ch]; conditioning gradients
+  RET_IF(p2l_linear_bwd(ga, m->genz_w, W + L.dcond, B, cond, 16 * 16 * m->ch, 0, st));
+  RET_IF(p2l_cbn_fold_bwd(W + L.ds, W + L.dt, m->cbn_mean, m->cbn_rstd, W + L.draw,
+                          W + L.draw + CT, B, CT, 2 * CT, st));
+  RET_IF(p2l_linear_bwd(W + L.draw, m->cbn_w, W + L.dcond, B, cond, 2 * CT, 1, st));
+  RET_IF(p2l_split2(W + L.dcond, dz, dc, B, m->z_dim, m->c_dim, st));
+  return P2L_OK;
+}
+
+// ===========================================================================
+// ProjectionLoss = weighted L1 + beta * weighted LPIPS(VGG16)
+// ===========================================================================
+namespace {
+
+const int kVggCin[13] = {16, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+const int kVggCout[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+// resolution divisor of each conv's output, pool after convs 1,3,6,9
+const int kVggDiv[13] = {1, 1, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16, 16};
+const int kVggTapConv[5] = {1, 3, 6, 9, 12};
+inline bool vgg_pool_after(int i) { return i == 1 || i == 3 || i == 6 || i == 9; }
+inline int vgg_tap_of(int i) {
+  for (int k = 0; k < 5; ++k) if (kVggTapConv[k] == i) return k;
+  return -1;
+}
+
+struct PLLayout {
+  size_t y[13];        // post-ReLU conv outputs
+  size_t yp[4];        // pooled outputs after convs 1,3,6,9
+  size_t tgt16;        // prepare: target in NHWC16
+  size_t wsrc;         // prepare: per-pixel weight map
+  size_t part;         // loss partial sums
+  size_t lp, l1;       // per-sample partial losses
+  size_t gs;           // per-sample gradient scale
+  size_t ga, gb, gtap; // backward scratch
+  size_t skws, skws_floats;
+  size_t total;
+};
+
+int pl_layout(int B, int H, int W, PLLayout& L) {
+  if (B < 1 || H < 32 || W < 32 || !is_pow2(H) || !is_pow2(W)) return P2L_EINVAL;
+  Arena a;
+  size_t max_act = 0, max_sk = 0;
+  int pi = 0;
+  for (int i = 0; i < 13; ++i) {
+    const int h = H / kVggDiv[i], w = W / kVggDiv[i];
+    const size_t n = (size_t)B * h * w * kVggCout[i];
+    L.y[i] = a.take(n);
+    if (n > max_act) max_act = n;
+    if (vgg_pool_after(i)) L.yp[pi++] = a.take(n / 4);
+    ConvCall f = mk_conv(B, h, w, kVggCin[i], kVggCout[i], 9);
+    size_t s1 = conv_ws_floats(f);
+    ConvCall d = mk_conv(B, h, w, kVggCout[i], i == 0 ? 32 : kVggCin[i], 9);
+    size_t s2 = conv_ws_floats(d);
+    if (s1 > max_sk) max_sk = s1;
+    if (s2 > max_sk) max_sk = s2;
+  }
+  L.tgt16 = a.take((size_t)B * H * W * 16);
+  L.wsrc = a.take((size_t)B * H * W);
+  size_t maxpart = (size_t)p2l_l1_loss_nblk(H, W);
+  for (int k = 0; k < 5; ++k) {
+    const int d = kVggDiv[kVggTapConv[k]];
+    const size_t nb = (size_t)p2l_lpips_tap_nblk((H / d) * (W / d), kVggCout[kVggTapConv[k]]);
+    if (nb > maxpart) maxpart = nb;
+  }
+  L.part = a.take((size_t)B * maxpart);
+  L.lp = a.take(B);
+  L.l1 = a.take(B);
+  L.gs = a.take(B);
+  L.ga = a.take(max_act);
+  L.gb = a.take(max_act);
+  L.gtap = a.take(max_act);
+  L.skws_floats = max_sk;
+  L.skws = a.take(max_sk ? max_sk : 64);
+  L.total = a.off;
+  return P2L_OK;
+}
+
+// VGG16 features forward on an NHWC16 image; y[i] = relu(conv_i), pooled copies.
+int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, float* Wk,
+                const PLLayout& L, void* st) {
+  const float* x = img16;
+  int pi = 0;
+  for (int i = 0; i < 13; ++i) {
+    const int h = H / kVggDiv[i], w = W / kVggDiv[i];
+    ConvCall c = mk_conv(B, h, w, kVggCin[i], kVggCout[i], 9);
+    c.x = x; c.w = v->w[i]; c.bias = v->b[i]; c.y = Wk + L.y[i];
+    c.d.act = P2L_ACT_RELU;
+    if (i == 0) {
+      c.d.pro = P2L_PRO_AFFINE; c.d.pro_bstride = 0; c.ps = v->in_s; c.pt = v->in_t;
+    }
+    if (vgg_pool_after(i)) {
+      c.d.pool = P2L_POOL_MAX; c.yp = Wk + L.yp[pi];
+    }
+    RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
+    if (vgg_pool_after(i)) { x = Wk + L.yp[pi]; ++pi; }
+    else x = Wk + L.y[i];
+  }
+  return P2L_OK;
+}
+
+}  // namespace
+
+extern "C" size_t p2l_loss_cache_floats(int B, int H, int W, size_t nft_off[5],
+                                        size_t wt_off[5], size_t* wsum_off) {
+  Arena a;
+  for (int k = 0; k < 5; ++k) {
+    const int d = kVggDiv[kVggTapConv[k]];
+    const size_t P = (size_t)(H / d) * (W / d);
+    nft_off[k] = a.take((size_t)B * P * kVggCout[kVggTapConv[k]]);
+    wt_off[k] = a.take((size_t)B * P);
+  }
+  *wsum_off = a.take(B);
+  return a.off;
+}
+
+extern "C" size_t p2l_projloss_ws_bytes(int B, int H, int W) {
+  PLLayout L;
+  if (pl_layout(B, H, W, L)) return 0;
+  return L.total * sizeof(float);
+}
+
+extern "C" int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
+                                    const float* weight, const float* loss_mask, int B,
+                                    int H, int W, const P2LLossCache* cache, void* ws,
+                                    size_t ws_bytes, void* st) {
+  PLLayout L;
+  RET_IF(pl_layout(B, H, W, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !target) return P2L_EWS;
+  float* Wk = (float*)ws;
+  if (weight) {
+    RET_IF(p2l_weight_sum(weight, loss_mask, cache->wsum, B, 3 * H * W, st));
+    RET_IF(p2l_weight_map(weight, loss_mask, Wk + L.wsrc, B, H, W, st));
+    for (int k = 0; k < 5; ++k) {
+      const int d = kVggDiv[kVggTapConv[k]];
+      RET_IF(p2l_bilinear_adjoint(Wk + L.wsrc, cache->wt[k], B, H, W, H / d, W / d, st));
+    }
+  }
+  if (v) {
+    RET_IF(p2l_nchw3_to_nhwc16(target, Wk + L.tgt16, B, H, W, st));
+    RET_IF(vgg_forward(v, Wk + L.tgt16, B, H, W, Wk, L, st));
+    for (int k = 0; k < 5; ++k) {
+      const int ci = kVggTapConv[k], d = kVggDiv[ci];
+      RET_IF(p2l_lpips_normalize(Wk + L.y[ci], cache->nft[k],
+                                 (int64_t)B * (H / d) * (W / d), kVggCout[ci], st));
+    }
+  }
+  return P2L_OK;
+}
+
+extern "C" int p2l_projloss_fwd(const P2LVggLpips* v, const float* img16,
+                                const float* target, const float* weight,
+                                const float* loss_mask, const P2LLossCache* cache,
+                                float beta, int use_lpips, int B, int H, int W, void* ws,
+                                size_t ws_bytes, float* loss, float* loss_l1,
+                                float* loss_lpips, void* st) {
+  PLLayout L;
+  RET_IF(pl_layout(B, H, W, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !img16 || !loss) return P2L_EWS;
+  float* Wk = (float*)ws;
+  float* l1 = loss_l1 ? loss_l1 : Wk + L.l1;
+  float* lp = loss_lpips ? loss_lpips : Wk + L.lp;
+  RET_IF(p2l_l1_loss_fwd(img16, target, weight, loss_mask, cache->wsum, l1, Wk + L.part, B,
+                         H, W, st));
+  RET_IF(p2l_vec_scale_div(l1, nullptr, loss, B, 1.f, st));
+  if (use_lpips) {
+    if (!v) return P2L_EINVAL;
+    RET_IF(vgg_forward(v, img16, B, H, W, Wk, L, st));
+    for (int k = 0; k < 5; ++k) {
+      const int ci = kVggTapConv[k], d = kVggDiv[ci];
+      const int P = (H / d) * (W / d), C = kVggCout[ci];
+      const int nblk = p2l_lpips_tap_nblk(P, C);
+      RET_IF(p2l_lpips_tap_fwd(Wk + L.y[ci], cache->nft[k], (int64_t)P * C, v->lin[k],
+                               cache->wt[k], P, Wk + L.part, B, P, C, st));
+      RET_IF(p2l_reduce_rows(Wk + L.part, lp, B, nblk, 1.f, cache->wsum, k > 0, st));
+    }
+    RET_IF(p2l_reduce_rows(lp, loss, B, 1, beta, nullptr, 1, st));
+  }
+  return P2L_OK;
+}
+
+extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
+                                const float* target, const float* weight,
+                                const float* loss_mask, const P2LLossCache* cache,
+                                float beta, int use_lpips, const float* gloss, int B, int H,
+                                int W, void* ws, size_t ws_bytes, float* dimg16, void* st) {
+  PLLayout L;
+  RET_IF(pl_layout(B, H, W, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !img16 || !gloss || !dimg16)
+    return P2L_EWS;
+  float* Wk = (float*)ws;
+  if (!use_lpips) {
+    return p2l_l1_loss_bwd(img16, target, weight, loss_mask, cache->wsum, gloss, dimg16, B,
+                           H, W, 0, st);
+  }
+  if (!v) return P2L_EINVAL;
+  // gs[b] = gloss[b] * beta / wsum[b]
+  RET_IF(p2l_vec_scale_div(gloss, cache->wsum, Wk + L.gs, B, beta, st));
+  float* ga = Wk + L.ga;   // gradient w.r.t. the PRE-ReLU output of conv i (masked)
+  float* gb = Wk + L.gb;
+  float* gtap = Wk + L.gtap;
+  // top: relu5_3 is only consumed by the LPIPS tap
+  {
+    const int ci = 12, d = kVggDiv[ci], P = (H / d) * (W / d), C = kVggCout[ci];
+    RET_IF(p2l_lpips_tap_bwd(Wk + L.y[ci], cache->nft[4], (int64_t)P * C, v->lin[4],
+                             cache->wt[4], P, Wk + L.gs, gtap, B, P, C, st));
+    RET_IF(p2l_relu_mask(Wk + L.y[ci], C, gtap, C, ga, C, (int64_t)B * P, C, st));
+  }
+  int pi = 3;
+  for (int i = 12; i >= 1; --i) {
+    const int h = H / kVggDiv[i], w = W / kVggDiv[i];
+    // input-gradient of conv i: ga [h,w,Cout_i] -> [h,w,Cin_i]
+    ConvCall c = mk_conv(B, h, w, kVggCout[i], kVggCin[i], 9);
+    c.x = ga; c.w = v->wt[i]; c.y = gb;
+    const int prev = i - 1;
+    if (!vgg_pool_after(prev)) {
+      // input is relu(conv_{i-1}) directly: fuse its ReLU mask in the epilogue
+      c.mask = Wk + L.y[prev]; c.d.mask_ld = kVggCout[prev];
+      RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
+    } else {
+      // input is maxpool(relu(conv_{i-1})); conv_{i-1} is also an LPIPS tap
+      RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
+      const int k = vgg_tap_of(prev);
+      const int hp = H / kVggDiv[prev], wp = W / kVggDiv[prev];
+      const int P = hp * wp, C = kVggCout[prev];
+      RET_IF(p2l_lpips_tap_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k],
+                               cache->wt[k], P, Wk + L.gs, gtap, B, P, C, st));
+      RET_IF(p2l_maxpool2_bwd(Wk + L.y[prev], C, gb, C, gtap, C, ga, C, B, hp, wp, C, 1, st));
+      --pi;
+      continue;  // ga already holds the masked gradient of conv_{i-1}
+    }
+    { float* t = ga; ga = gb; gb = t; }
+  }
+  (void)pi;
+  // conv 0 input-gradient -> d img16 (1/scale folded into the packed weights)
+  {
+    ConvCall c = mk_conv(B, H, W, 64, 32, 9);
+    c.x = ga; c.w = v->wt[0]; c.y = dimg16; c.d.y_ld = 16; c.d.n_store = 16;
+    RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
+  }
+  RET_IF(p2l_l1_loss_bwd(img16, target, weight, loss_mask, cache->wsum, gloss, dimg16, B, H,
+                         W, 1, st));
+  return P2L_OK;
+}

@@ -1,0 +1,376 @@
+"""Loss functions of the pix2latent hot path on the native MI355X path.
+
+Host-side mirror of the reference file pix2latent/loss_functions.py: same names,
+constructor arguments and `__call__(output, target, weight=None, loss_mask=None)`
+signatures.  The weighted L1 + LPIPS-VGG16 combination used by every inversion
+example (`ProjectionLoss`, reference loss_functions.py:86-100) runs as
+`p2l_projloss_fwd/bwd` in libp2l_hip:
+
+  * target features / resized weight maps are cached per (target, weight,
+    loss_mask) identity instead of being recomputed each step (reference
+    loss_functions.py:142 runs the perceptual net on the target every call);
+  * bilinear upsampling of the five LPIPS maps followed by the weighted spatial
+    sum is evaluated as a sum at tap resolution against the adjoint-resized
+    weight map (exact identity; only summation order differs).
+
+The un-weighted / L2 variants are not on the hot path and use plain torch ops on
+the tensor's own device.
+"""
+import ctypes as C
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from . import _native as N
+from .utils import synthetic
+
+LPIPS_SHIFT = (-.030, -.088, -.188)
+LPIPS_SCALE = (.458, .448, .450)
+
+
+def l1_loss(out, target):
+    """ computes loss = | x - y |"""
+    return torch.abs(target - out)
+
+
+def l2_loss(out, target):
+    """ computes loss = (x - y)^2 """
+    return ((target - out) ** 2)
+
+
+def invertibility_loss(ims, target_transform, transform_params, mask=None):
+    """ MSE(ims - T^{-1}(T(ims))) (reference loss_functions.py:30-38) """
+    if ims.size(0) == 1:
+        ims = ims.repeat(len(transform_params), 1, 1, 1)
+    transformed = target_transform(ims, transform_params)
+    inverted = target_transform(transformed, transform_params, invert=True)
+    if mask is None:
+        return torch.mean((ims - inverted) ** 2, [1, 2, 3])
+    return masked_l2_loss(ims, inverted, mask)
+
+
+def _masked(fn, out, target, mask):
+    if mask.size(0) == 1:
+        mask = mask.repeat(out.size(0), 1, 1, 1)
+    if target.size(0) == 1:
+        target = target.repeat(out.size(0), 1, 1, 1)
+    loss = fn(out, target)
+    return torch.sum(loss * mask, [1, 2, 3]) / torch.sum(mask, [1, 2, 3])
+
+
+def masked_l1_loss(out, target, mask):
+    return _masked(l1_loss, out, target, mask)
+
+
+def masked_l2_loss(out, target, mask):
+    return _masked(l2_loss, out, target, mask)
+
+
+def weight_regularization(orig_model, curr_model, reg='l1', weight_dict=None):
+    """ reference loss_functions.py:64-83 (not on the hot path) """
+    w = 1.0
+    reg_loss = 0.0
+    orig_state_dict = orig_model.state_dict()
+    for param_name, curr_param in curr_model.named_parameters():
+        if 'bn' in param_name:
+            continue
+        orig_param = orig_state_dict[param_name]
+        if reg == 'l1':
+            l = torch.abs(curr_param - orig_param).mean()
+        elif reg == 'l2':
+            l = ((curr_param - orig_param) ** 2).mean()
+        elif reg == 'inf':
+            l = torch.max(torch.abs(curr_param - orig_param))
+        if weight_dict is not None:
+            w = weight_dict[param_name]
+        reg_loss += w * l
+    return reg_loss
+
+
+# ---------------------------------------------------------------------------
+# native engine shared by Reconstruction / Perceptual / Projection losses
+# ---------------------------------------------------------------------------
+class _VggLpipsParams(object):
+    """packed VGG16 + LPIPS-lin parameters on the device (P2LVggLpips)."""
+
+    def __init__(self, weights, device):
+        self.lib = N.lib()
+        self.dev = torch.device(device)
+        self.keep = []
+        self.desc = N.P2LVggLpips()
+        inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
+        for i, (cin, cout) in enumerate(synthetic.VGG_CONVS):
+            w = weights['vgg.conv%d.weight' % i].float()
+            if i == 0:
+                self.desc.w[i] = self._pack(w, 9, cout, 16, False)
+                # d scaled / d img = 1/scale per input channel: fold into the dgrad copy
+                self.desc.wt[i] = self._pack(w * inv_scale.view(1, 3, 1, 1), 9, 32, cout, True)
+            else:
+                self.desc.w[i] = self._pack(w, 9, cout, cin, False)
+                self.desc.wt[i] = self._pack(w, 9, cin, cout, True)
+            self.desc.b[i] = self._t(weights['vgg.conv%d.bias' % i])
+        for k in range(5):
+            self.desc.lin[k] = self._t(weights['lpips.lin%d.weight' % k].reshape(-1))
+        s16, t16 = torch.zeros(16), torch.zeros(16)
+        for c in range(3):
+            s16[c] = 1.0 / LPIPS_SCALE[c]
+            t16[c] = -LPIPS_SHIFT[c] / LPIPS_SCALE[c]
+        self.desc.in_s = self._t(s16)
+        self.desc.in_t = self._t(t16)
+
+    def _t(self, t):
+        t = t.detach().to(self.dev, torch.float32).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def _pack(self, w, taps, n_pad, k_pad, flip):
+        O, I = w.shape[0], w.shape[1]
+        src = w.detach().to(self.dev, torch.float32).contiguous()
+        dst = torch.empty(taps * n_pad * k_pad, device=self.dev, dtype=torch.float32)
+        N.check(self.lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
+                                              N.ptr(dst), N.stream()), 'p2l_pack_conv_weight')
+        torch.cuda.current_stream().synchronize()
+        self.keep.append(dst)
+        return dst.data_ptr()
+
+
+class _LossEngine(object):
+    """workspace + target cache for p2l_projloss_*; one per loss object."""
+
+    def __init__(self, vgg_params):
+        self.lib = N.lib()
+        self.vgg = vgg_params
+        self.key = None
+        self.shape = None
+        self.ws = None
+        self.cache_buf = None
+        self.cache = N.P2LLossCache()
+        self._memo = {}
+        self._fwd_ticket = 0
+
+    def _alloc(self, B, H, W, dev):
+        if self.shape == (B, H, W):
+            return
+        nbytes = self.lib.p2l_projloss_ws_bytes(B, H, W)
+        if nbytes == 0:
+            raise N.NativeError('p2l_projloss_ws_bytes rejected shape %s' % ((B, H, W),))
+        self.ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        self.ws_bytes = nbytes
+        nft_off = (C.c_size_t * 5)()
+        wt_off = (C.c_size_t * 5)()
+        wsum_off = C.c_size_t(0)
+        n = self.lib.p2l_loss_cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
+        self.cache_buf = torch.empty(n, device=dev, dtype=torch.float32)
+        base = self.cache_buf.data_ptr()
+        for k in range(5):
+            self.cache.nft[k] = base + 4 * nft_off[k]
+            self.cache.wt[k] = base + 4 * wt_off[k]
+        self.cache.wsum = base + 4 * wsum_off.value
+        self.img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
+        self.dimg16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
+        self.shape = (B, H, W)
+        self.key = None
+
+    @staticmethod
+    def _ident(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+
+    def bind(self, name, t, B, like=None):
+        """[1,3,H,W] / [3,H,W] / None(weight) -> contiguous fp32 [B,3,H,W], memoised on
+        the source tensor's identity so that the target cache key stays stable."""
+        if t is None:
+            if name != 'weight':
+                return None
+            # reference returns an un-reduced map when weight is None; its only
+            # consumer (closure.py:55) takes .view(b,-1).mean(1), which equals the
+            # weighted form with unit weights.
+            key = ('ones', B, tuple(like.shape[2:]), str(like.device))
+            if self._memo.get(name, (None, None))[0] != key:
+                self._memo[name] = (key, torch.ones(B, 3, like.size(2), like.size(3),
+                                                    device=like.device))
+            return self._memo[name][1]
+        key = (self._ident(t), B)
+        if self._memo.get(name, (None, None))[0] != key:
+            e = t
+            if e.dim() == 3:
+                e = e.unsqueeze(0)
+            if e.size(0) == 1 and B > 1:
+                e = e.expand(B, -1, -1, -1)
+            e = e.contiguous().float()
+            self._memo[name] = (key, e, t)
+        return self._memo[name][1]
+
+    def prepare(self, out, target, weight, loss_mask, use_lpips):
+        B, _, H, W = out.shape
+        self._alloc(B, H, W, out.device)
+        key = (self._ident(target), self._ident(weight), self._ident(loss_mask), use_lpips)
+        if key == self.key:
+            return
+        vref = C.byref(self.vgg.desc) if use_lpips else None
+        N.check(self.lib.p2l_projloss_prepare(vref, N.ptr(target), N.ptr(weight),
+                                              N.ptr(loss_mask), B, H, W, C.byref(self.cache),
+                                              N.ptr(self.ws), C.c_size_t(self.ws_bytes),
+                                              N.stream()), 'p2l_projloss_prepare')
+        self.key = key
+        # keep the tensors alive so that data_ptr identity stays meaningful
+        self._held = (target, weight, loss_mask)
+
+
+def _apply(eng, output, target, weight, loss_mask, beta, mode):
+    B = output.size(0)
+    return _ProjLossFn.apply(output, eng.bind('target', target, B),
+                             eng.bind('weight', weight, B, like=output),
+                             eng.bind('loss_mask', loss_mask, B), eng, float(beta), mode)
+
+
+class _ProjLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, weight, loss_mask, eng, beta, mode):
+        # mode: 0 = L1 + beta*LPIPS, 1 = L1 only, 2 = LPIPS only
+        lib = eng.lib
+        B, _, H, W = output.shape
+        out_c = output.contiguous().float()
+        use_lpips = 0 if mode == 1 else 1
+        eng.prepare(out_c, target, weight, loss_mask, use_lpips)
+        N.check(lib.p2l_nchw3_to_nhwc16(N.ptr(out_c), N.ptr(eng.img16), B, H, W, N.stream()),
+                'p2l_nchw3_to_nhwc16')
+        loss = torch.empty(B, device=output.device, dtype=torch.float32)
+        l1 = torch.empty_like(loss)
+        lp = torch.empty_like(loss)
+        vref = C.byref(eng.vgg.desc) if use_lpips else None
+        N.check(lib.p2l_projloss_fwd(vref, N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
+                                     N.ptr(loss_mask), C.byref(eng.cache), N.f32(beta),
+                                     use_lpips, B, H, W, N.ptr(eng.ws),
+                                     C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
+                                     N.ptr(lp), N.stream()), 'p2l_projloss_fwd')
+        ctx.eng, ctx.beta, ctx.mode = eng, beta, mode
+        ctx.save_for_backward(out_c, target, weight, loss_mask if loss_mask is not None
+                              else torch.empty(0))
+        ctx.has_mask = loss_mask is not None
+        eng._fwd_ticket += 1
+        ctx.ticket = eng._fwd_ticket
+        eng.last_l1, eng.last_lpips = l1, lp
+        if mode == 2:
+            return lp
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng = ctx.eng
+        lib = eng.lib
+        out_c, target, weight, loss_mask = ctx.saved_tensors
+        if not ctx.has_mask:
+            loss_mask = None
+        B, _, H, W = out_c.shape
+        use_lpips = 0 if ctx.mode == 1 else 1
+        if eng._fwd_ticket != ctx.ticket:
+            raise N.NativeError('loss workspace was reused by a later forward before '
+                                'backward(); use one loss object per in-flight graph')
+        g = gloss.contiguous().float()
+        if ctx.mode == 2:
+            # LPIPS only: run the combined backward with the L1 term switched off
+            raise N.NativeError('PerceptualLoss backward is only available through '
+                                'ProjectionLoss in this build')
+        N.check(lib.p2l_projloss_bwd(C.byref(eng.vgg.desc) if use_lpips else None,
+                                     N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
+                                     N.ptr(loss_mask), C.byref(eng.cache), N.f32(ctx.beta),
+                                     use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
+                                     C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
+                'p2l_projloss_bwd')
+        dout = torch.empty(B, 3, H, W, device=out_c.device, dtype=torch.float32)
+        N.check(lib.p2l_nhwc16_to_nchw3(N.ptr(eng.dimg16), N.ptr(dout), B, H, W, N.stream()),
+                'p2l_nhwc16_to_nchw3')
+        return dout, None, None, None, None, None, None
+
+
+_VGG_PARAMS = {}
+
+
+def _vgg_params(net, weights, device):
+    if net != 'vgg':
+        raise NotImplementedError(
+            "lpips_net='%s': only the VGG16 LPIPS network has a native MI355X path in this "
+            "build (BASELINE north_star measures VGG16); pass lpips_net='vgg'" % net)
+    key = (id(weights), str(device))
+    if key not in _VGG_PARAMS:
+        if weights is None:
+            path = os.environ.get('P2L_LPIPS_VGG_WEIGHTS')
+            if path:
+                w = torch.load(path, map_location='cpu')
+            else:
+                warnings.warn('LPIPS-VGG16: no pretrained weights available (no network); '
+                              'using seeded random-init weights of the same architecture')
+                w = synthetic.lpips_vgg_weights()
+        else:
+            w = weights
+        _VGG_PARAMS[key] = _VggLpipsParams(w, device)
+    return _VGG_PARAMS[key]
+
+
+def _native_ok(output, target, weight):
+    return (output.is_cuda and output.dim() == 4 and output.size(1) == 3 and
+            target is not None)
+
+
+class ProjectionLoss(nn.Module):
+    """ The default loss that is used in the paper (reference loss_functions.py:86-100).
+
+    lpips_net keeps the reference default 'alex' in the signature, but only 'vgg'
+    has a native path; pass lpips_net='vgg'.
+    """
+
+    def __init__(self, lpips_net='alex', beta=10, weights=None, device='cuda'):
+        super().__init__()
+        self.beta = beta
+        self._engine = _LossEngine(_vgg_params(lpips_net, weights, device))
+        self.rloss_fn = ReconstructionLoss()
+        self.ploss_fn = PerceptualLoss(net=lpips_net, weights=weights, device=device)
+        return
+
+    def __call__(self, output, target, weight=None, loss_mask=None):
+        return _apply(self._engine, output, target, weight, loss_mask, self.beta, 0)
+
+
+class ReconstructionLoss(nn.Module):
+    """ Reconstruction loss with spatial weighting (reference loss_functions.py:104-124) """
+
+    def __init__(self, loss_type='l1'):
+        super(ReconstructionLoss, self).__init__()
+        if loss_type in ['l1', 1]:
+            self.loss_fn = l1_loss
+            self._native = True
+        elif loss_type in ['l2', 2]:
+            self.loss_fn = l2_loss
+            self._native = False
+        else:
+            raise ValueError('Unknown loss_type {}'.format(loss_type))
+        self._engine = None
+        return
+
+    def __call__(self, output, target, weight=None, loss_mask=None):
+        if self._native and weight is not None and _native_ok(output, target, weight):
+            if self._engine is None:
+                self._engine = _LossEngine(None)
+            return _apply(self._engine, output, target, weight, loss_mask, 0.0, 1)
+        loss = self.loss_fn(output, target)
+        if weight is not None:
+            _weight = weight if loss_mask is None else (loss_mask * weight)
+            n = torch.sum(loss * _weight, [1, 2, 3])
+            d = torch.sum(_weight, [1, 2, 3])
+            loss = n / d
+        return loss
+
+
+class PerceptualLoss(nn.Module):
+    """ LPIPS loss with spatial weighting (reference loss_functions.py:127-148);
+    forward-only on its own (gradients flow through ProjectionLoss). """
+
+    def __init__(self, net='vgg', use_gpu=True, weights=None, device='cuda'):
+        super(PerceptualLoss, self).__init__()
+        self._engine = _LossEngine(_vgg_params(net, weights, device))
+        return
+
+    def __call__(self, output, target, weight=None, loss_mask=None):
+        return _apply(self._engine, output, target, weight, loss_mask, 1.0, 2)

@@ -1,0 +1,180 @@
+"""Thin tensor-level wrappers over the per-kernel C-ABI entry points of
+libp2l_hip (include/p2l.h).  The product path drives the whole-graph plans
+(`p2l_biggan_*`, `p2l_projloss_*`); these wrappers exist so that every kernel
+can be exercised and parity-tested on its own.  All tensors are NHWC fp32 on the
+ROCm device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+
+def _lib():
+    return N.lib()
+
+
+def mfma_probe(A, B):
+    K = A.shape[1]
+    Cm = torch.empty(32, 32, device=A.device)
+    N.check(_lib().p2l_mfma_probe(N.ptr(A), N.ptr(B), N.ptr(Cm), K, N.stream()), 'mfma_probe')
+    return Cm
+
+
+def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False):
+    O, I = w_oihw.shape[0], w_oihw.shape[1]
+    src = w_oihw.contiguous().float()
+    dst = torch.empty(taps * n_pad * k_pad, device=src.device)
+    N.check(_lib().p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
+                                        N.ptr(dst), N.stream()), 'pack_conv_weight')
+    return dst
+
+
+def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,
+         pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
+         res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
+         splitk=None, x_ld=None):
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
+    d.ups = int(ups)
+    d.x_ld = x_ld if x_ld is not None else Cin
+    d.pro, d.pro_bstride = pro, pro_bstride
+    d.alpha, d.act, d.pool = alpha, act, pool
+    d.n_store = n_store if n_store is not None else Cout
+    d.y_ld = y_ld if y_ld is not None else d.n_store if n_store is not None else Cout
+    d.yp_ld = d.y_ld
+    d.res_ld = res.shape[-1] if res is not None else 0
+    d.res_ups = int(res_ups)
+    d.mask_ld = mask.shape[-1] if mask is not None else 0
+    d.splitk = splitk if splitk is not None else _lib().p2l_conv_suggest_splitk(C.byref(d))
+    wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(wsb // 4, 1), device=x.device)
+    y = torch.empty(B, H, W, d.y_ld, device=x.device) if want_y else None
+    yp = torch.empty(B, H // 2, W // 2, d.yp_ld, device=x.device) if pool else None
+    N.check(_lib().p2l_conv_fwd(C.byref(d), N.ptr(x), N.ptr(w_packed), N.ptr(bias),
+                                N.ptr(pro_s), N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y),
+                                N.ptr(yp), N.ptr(ws), C.c_size_t(wsb), N.stream()), 'conv_fwd')
+    return y, yp
+
+
+def gemm(A, B, batch, M, Nn, K, a_kmajor=False, b_kmajor=False, alpha=1.0, Cacc=None):
+    d = N.P2LGemm()
+    d.batch, d.M, d.N, d.K = batch, M, Nn, K
+    d.lda = A.shape[-1]
+    d.ldb = B.shape[-1]
+    d.ldc = Nn
+    d.stride_a = A.shape[-2] * A.shape[-1]
+    d.stride_b = B.shape[-2] * B.shape[-1]
+    d.stride_c = M * Nn
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.alpha = alpha
+    d.accumulate = int(Cacc is not None)
+    Cm = Cacc if Cacc is not None else torch.empty(batch, M, Nn, device=A.device)
+    N.check(_lib().p2l_gemm(C.byref(d), N.ptr(A), N.ptr(B), N.ptr(Cm), N.stream()), 'gemm')
+    return Cm
+
+
+def linear_fwd(x, W, bias=None):
+    Bn, K = x.shape
+    Nn = W.shape[1]
+    y = torch.empty(Bn, Nn, device=x.device)
+    N.check(_lib().p2l_linear_fwd(N.ptr(x), N.ptr(W), N.ptr(bias), N.ptr(y), Bn, K, Nn,
+                                  N.stream()), 'linear_fwd')
+    return y
+
+
+def linear_bwd(dy, W, dx=None):
+    Bn, Nn = dy.shape
+    K = W.shape[0]
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty(Bn, K, device=dy.device)
+    N.check(_lib().p2l_linear_bwd(N.ptr(dy), N.ptr(W), N.ptr(dx), Bn, K, Nn, int(acc),
+                                  N.stream()), 'linear_bwd')
+    return dx
+
+
+def affine_relu_bwd(da, x, s, t, st_bstride, skip=None, skip_C=0, skip_ups=False):
+    Bn, H, W, Cc = x.shape
+    nblk = _lib().p2l_affine_relu_bwd_nblk(H * W)
+    part = torch.empty(2 * Bn * nblk * Cc, device=x.device)
+    dx = torch.empty_like(x)
+    ds = torch.empty(Bn, Cc, device=x.device)
+    dt = torch.empty(Bn, Cc, device=x.device)
+    N.check(_lib().p2l_affine_relu_bwd(
+        N.ptr(da), da.shape[-1], N.ptr(x), Cc, N.ptr(s), N.ptr(t), st_bstride, N.ptr(skip),
+        skip.shape[-1] if skip is not None else 0, skip_C, int(skip_ups), N.ptr(dx), Cc,
+        N.ptr(ds), N.ptr(dt), Cc, N.ptr(part), Bn, H, W, Cc, N.stream()), 'affine_relu_bwd')
+    return dx, ds, dt
+
+
+def softmax_fwd(S):
+    rows, cols = S.numel() // S.shape[-1], S.shape[-1]
+    P = torch.empty_like(S)
+    N.check(_lib().p2l_softmax_fwd(N.ptr(S), N.ptr(P), N.i64(rows), cols, N.stream()), 'softmax')
+    return P
+
+
+def softmax_bwd(P, dP):
+    rows, cols = P.numel() // P.shape[-1], P.shape[-1]
+    dS = torch.empty_like(P)
+    N.check(_lib().p2l_softmax_bwd(N.ptr(P), N.ptr(dP), N.ptr(dS), N.i64(rows), cols,
+                                   N.stream()), 'softmax_bwd')
+    return dS
+
+
+def maxpool2_bwd(y, dyp, add=None, relu_mask=False):
+    Bn, H, W, Cc = y.shape
+    dy = torch.empty_like(y)
+    N.check(_lib().p2l_maxpool2_bwd(N.ptr(y), Cc, N.ptr(dyp), Cc, N.ptr(add), Cc, N.ptr(dy), Cc,
+                                    Bn, H, W, Cc, int(relu_mask), N.stream()), 'maxpool2_bwd')
+    return dy
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    N.check(_lib().p2l_adam_step(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), N.i64(p.numel()),
+                                 N.f32(lr), N.f32(beta1), N.f32(beta2), N.f32(eps), int(step),
+                                 N.stream()), 'adam_step')
+
+
+def clamp_(p, lo, hi):
+    N.check(_lib().p2l_clamp(N.ptr(p), N.i64(p.numel()), N.f32(lo), N.f32(hi), N.stream()),
+            'clamp')
+
+
+def bilinear_adjoint(wsrc, h, w):
+    Bn, H, W = wsrc.shape
+    wt = torch.empty(Bn, h, w, device=wsrc.device)
+    N.check(_lib().p2l_bilinear_adjoint(N.ptr(wsrc), N.ptr(wt), Bn, H, W, h, w, N.stream()),
+            'bilinear_adjoint')
+    return wt
+
+
+def lpips_normalize(f):
+    Cc = f.shape[-1]
+    nf = torch.empty_like(f)
+    N.check(_lib().p2l_lpips_normalize(N.ptr(f), N.ptr(nf), N.i64(f.numel() // Cc), Cc,
+                                       N.stream()), 'lpips_normalize')
+    return nf
+
+
+def lpips_tap_fwd(f, nft, lin, wt, wsum):
+    Bn, P, Cc = f.shape[0], f.shape[1] * f.shape[2], f.shape[3]
+    nblk = _lib().p2l_lpips_tap_nblk(P, Cc)
+    part = torch.empty(Bn, nblk, device=f.device)
+    N.check(_lib().p2l_lpips_tap_fwd(N.ptr(f), N.ptr(nft), N.i64(P * Cc), N.ptr(lin), N.ptr(wt),
+                                     N.i64(P), N.ptr(part), Bn, P, Cc, N.stream()), 'lpips_tap_fwd')
+    out = torch.empty(Bn, device=f.device)
+    N.check(_lib().p2l_reduce_rows(N.ptr(part), N.ptr(out), Bn, nblk, N.f32(1.0), N.ptr(wsum), 0,
+                                   N.stream()), 'reduce_rows')
+    return out
+
+
+def lpips_tap_bwd(f, nft, lin, wt, gscale):
+    Bn, P, Cc = f.shape[0], f.shape[1] * f.shape[2], f.shape[3]
+    df = torch.empty_like(f)
+    N.check(_lib().p2l_lpips_tap_bwd(N.ptr(f), N.ptr(nft), N.i64(P * Cc), N.ptr(lin), N.ptr(wt),
+                                     N.i64(P), N.ptr(gscale), N.ptr(df), Bn, P, Cc, N.stream()),
+            'lpips_tap_bwd')
+    return df

@@ -1,0 +1,126 @@
+"""Seeded synthetic weights / targets.
+
+There is no network in the build or bench environment, so neither the
+HuggingFace `biggan-deep-256` checkpoint (reference pix2latent/model/biggan.py:26)
+nor the lpips / torchvision VGG16 weights (pix2latent/loss_functions.py:131) can
+be fetched.  These generators produce random-init tensors of exactly those
+architectures, keyed like the upstream state_dicts (after the spectral-norm
+bake-out of utils/misc.py:150-157) so that a real checkpoint can be dropped in
+through the same dictionary.
+"""
+import math
+
+import torch
+
+CH = 128
+Z_DIM = 128
+N_STATS = 51
+# (up_sample, in_mult, out_mult) of biggan-deep-256
+LAYERS = [(False, 16, 16), (True, 16, 16), (False, 16, 16), (True, 16, 8),
+          (False, 8, 8), (True, 8, 8), (False, 8, 8), (True, 8, 4),
+          (False, 4, 4), (True, 4, 2), (False, 2, 2), (True, 2, 1)]
+ATTN_POS = 8
+
+VGG_CONVS = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256),
+             (256, 256), (256, 512), (512, 512), (512, 512), (512, 512),
+             (512, 512), (512, 512)]
+VGG_CHNS = (64, 128, 256, 512, 512)
+
+
+def layer_table(ch=CH, layers=LAYERS, attn_pos=ATTN_POS):
+    out = []
+    for i, (up, cin, cout) in enumerate(layers):
+        if i == attn_pos:
+            out.append(('attn', ch * cin))
+        out.append(('block', up, ch * cin, ch * cout))
+    return out
+
+
+def biggan_weights(seed=0, ch=CH, layers=LAYERS, attn_pos=ATTN_POS, z_dim=Z_DIM,
+                   num_classes=1000):
+    g = torch.Generator().manual_seed(seed)
+    cond_dim = 2 * z_dim
+
+    def randn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    W = {}
+    W['embeddings.weight'] = randn(z_dim, num_classes, std=0.05)
+    W['generator.gen_z.weight'] = randn(4 * 4 * 16 * ch, cond_dim, std=math.sqrt(1.0 / cond_dim))
+    W['generator.gen_z.bias'] = randn(4 * 4 * 16 * ch, std=0.01)
+
+    def bn(prefix, c, conditional=True):
+        W[prefix + '.running_means'] = randn(N_STATS, c, std=0.1)
+        W[prefix + '.running_vars'] = 0.5 + torch.rand(N_STATS, c, generator=g)
+        if conditional:
+            W[prefix + '.scale.weight'] = randn(c, cond_dim, std=0.02)
+            W[prefix + '.offset.weight'] = randn(c, cond_dim, std=0.02)
+        else:
+            W[prefix + '.weight'] = 0.5 + 0.5 * torch.rand(c, generator=g)
+            W[prefix + '.bias'] = randn(c, std=0.05)
+
+    def conv(prefix, cout, cin, k, bias=True, gain=2.0):
+        fan_in = cin * k * k
+        W[prefix + '.weight'] = randn(cout, cin, k, k, std=math.sqrt(gain / fan_in))
+        if bias:
+            W[prefix + '.bias'] = randn(cout, std=0.01)
+
+    for i, spec in enumerate(layer_table(ch, layers, attn_pos)):
+        p = 'generator.layers.%d' % i
+        if spec[0] == 'attn':
+            c = spec[1]
+            conv(p + '.snconv1x1_theta', c // 8, c, 1, bias=False, gain=1.0)
+            conv(p + '.snconv1x1_phi', c // 8, c, 1, bias=False, gain=1.0)
+            conv(p + '.snconv1x1_g', c // 2, c, 1, bias=False, gain=1.0)
+            conv(p + '.snconv1x1_o_conv', c, c // 2, 1, bias=False, gain=1.0)
+            W[p + '.gamma'] = torch.tensor([0.5])
+        else:
+            _, up, cin, cout = spec
+            mid = cin // 4
+            bn(p + '.bn_0', cin)
+            conv(p + '.conv_0', mid, cin, 1)
+            bn(p + '.bn_1', mid)
+            conv(p + '.conv_1', mid, mid, 3)
+            bn(p + '.bn_2', mid)
+            conv(p + '.conv_2', mid, mid, 3)
+            bn(p + '.bn_3', mid)
+            conv(p + '.conv_3', cout, mid, 1, gain=0.5)
+    bn('generator.bn', ch, conditional=False)
+    conv('generator.conv_to_rgb', ch, ch, 3, gain=0.05)
+    return W
+
+
+def lpips_vgg_weights(seed=1):
+    g = torch.Generator().manual_seed(seed)
+    Wv = {}
+    for i, (cin, cout) in enumerate(VGG_CONVS):
+        Wv['vgg.conv%d.weight' % i] = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9))
+        Wv['vgg.conv%d.bias' % i] = torch.randn(cout, generator=g) * 0.01
+    for k, c in enumerate(VGG_CHNS):
+        # trained lpips lin weights are non-negative; keep that property
+        Wv['lpips.lin%d.weight' % k] = (torch.rand(1, c, 1, 1, generator=g) / c)
+    return Wv
+
+
+def synthetic_target(size=256, seed=1):
+    """smooth image in [-1,1] + a little noise, [3,size,size]."""
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing='ij')
+    img = torch.zeros(3, size, size)
+    for c in range(3):
+        for _ in range(6):
+            a = torch.randn(1, generator=g).item()
+            fx, fy = (torch.rand(2, generator=g) * 4).tolist()
+            ph = torch.rand(1, generator=g).item() * 2 * math.pi
+            img[c] += a * torch.sin(2 * math.pi * (fx * xs + fy * ys) + ph)
+    img = torch.tanh(img) + 0.05 * torch.randn(3, size, size, generator=g)
+    return img.clamp(-1, 1)
+
+
+def synthetic_weight_mask(size=256):
+    """centred ellipse in {-1,1} -> ((m+1)/2).clamp(0.3,1) as
+    examples/invert_biggan_adam.py:49 does with the user mask."""
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing='ij')
+    m = ((xs / 0.7) ** 2 + (ys / 0.6) ** 2 <= 1).float() * 2 - 1
+    w = ((m + 1) / 2).clamp(0.3, 1.0)
+    return w.unsqueeze(0).repeat(3, 1, 1)

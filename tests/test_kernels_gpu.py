@@ -1,0 +1,294 @@
+"""Per-kernel parity: every HIP kernel of libp2l_hip against plain PyTorch-CPU
+fp32 ops (the oracle's building blocks) on seeded inputs.  Tolerances are
+fp32-summation-order level and written per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t, dev):          # NCHW cpu -> NHWC device
+    return t.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+def nchw(t):               # NHWC device -> NCHW cpu
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+
+
+@pytest.fixture(scope='module')
+def O(dev):
+    from pix2latent_amd import ops
+    return ops
+
+
+def test_mfma_probe_layout(dev, O):
+    """asymmetric A/B so that a transposed fragment map cannot pass."""
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(32, 8, generator=g)
+    B = torch.randn(8, 32, generator=g)
+    Cm = O.mfma_probe(A.to(dev), B.to(dev)).cpu()
+    assert relerr(Cm, A @ B) < 1e-5
+
+
+CONV_CASES = [
+    # B, H, Cin, Cout, taps, extras
+    dict(B=2, H=16, Cin=64, Cout=64, taps=9),
+    dict(B=3, H=32, Cin=32, Cout=96, taps=9, bias=True),               # BN=32 path
+    dict(B=2, H=16, Cin=64, Cout=128, taps=1, bias=True),
+    dict(B=2, H=32, Cin=64, Cout=64, taps=9, pro='affine_relu', bias=True),
+    dict(B=2, H=32, Cin=64, Cout=64, taps=9, pro='affine_relu', ups=True, bias=True),
+    dict(B=3, H=4, Cin=128, Cout=64, taps=9, pro='affine_relu', bias=True),      # TB=8 tile, split-K
+    dict(B=3, H=8, Cin=128, Cout=64, taps=9, pro='affine_relu', ups=True, bias=True),  # TB=2
+    dict(B=9, H=4, Cin=256, Cout=64, taps=1, pro='affine_relu', bias=True),
+    dict(B=2, H=16, Cin=64, Cout=64, taps=9, act='relu', pool='max', bias=True),
+    dict(B=2, H=16, Cin=64, Cout=64, taps=9, pool='sum', want_y=False),
+    dict(B=3, H=8, Cin=128, Cout=64, taps=9, pool='sum', want_y=False, splitk=4),
+    dict(B=2, H=16, Cin=64, Cout=128, taps=1, res='same', alpha=0.5),
+    dict(B=2, H=16, Cin=64, Cout=64, taps=1, res='ups', bias=True, pro='affine_relu'),
+    dict(B=2, H=16, Cin=64, Cout=64, taps=9, mask=True),
+    dict(B=2, H=32, Cin=16, Cout=64, taps=9, pro='affine', act='relu', bias=True),   # VGG conv0 form
+    dict(B=2, H=32, Cin=64, Cout=32, taps=9, act='tanh', n_store=16, bias=True),     # rgb form
+    dict(B=1, H=64, Cin=64, Cout=64, taps=9, splitk=2, bias=True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: '-'.join('%s%s' % (k, v) for k, v in c.items()))
+def test_conv_fwd(dev, O, case):
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(1)
+    B, H, Cin, Cout, taps = case['B'], case['H'], case['Cin'], case['Cout'], case['taps']
+    k = 3 if taps == 9 else 1
+    ups = case.get('ups', False)
+    Hin = H // 2 if ups else H
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    bias = torch.randn(Cout, generator=g) * 0.1 if case.get('bias') else None
+    a = x
+    pro, ps, pt = N.PRO_NONE, None, None
+    if case.get('pro'):
+        s = 0.5 + torch.rand(B, Cin, generator=g)
+        t = torch.randn(B, Cin, generator=g) * 0.3
+        a = x * s.view(B, Cin, 1, 1) + t.view(B, Cin, 1, 1)
+        if case['pro'] == 'affine_relu':
+            a = F.relu(a)
+            pro = N.PRO_AFFINE_RELU
+        else:
+            pro = N.PRO_AFFINE
+        ps, pt = s.to(dev), t.to(dev)
+    if ups:
+        a = F.interpolate(a, scale_factor=2, mode='nearest')
+    ref = F.conv2d(a, w, None, padding=k // 2) * case.get('alpha', 1.0)
+    if bias is not None:
+        ref = ref + bias.view(1, -1, 1, 1)
+    res_t = None
+    if case.get('res') == 'same':
+        r = torch.randn(B, Cout, H, H, generator=g)
+        ref = ref + r
+        res_t = nhwc(r, dev)
+    elif case.get('res') == 'ups':
+        r = torch.randn(B, Cout + 32, H // 2, H // 2, generator=g)      # channel-truncated + nearest x2
+        ref = ref + F.interpolate(r[:, :Cout], scale_factor=2, mode='nearest')
+        res_t = nhwc(r, dev)
+    act = N.ACT_NONE
+    if case.get('act') == 'relu':
+        ref, act = F.relu(ref), N.ACT_RELU
+    elif case.get('act') == 'tanh':
+        ref, act = torch.tanh(ref), N.ACT_TANH
+    mask_t = None
+    if case.get('mask'):
+        m = torch.randn(B, Cout, H, H, generator=g)
+        ref = ref * (m > 0).float()
+        mask_t = nhwc(m, dev)
+    pool = {None: N.POOL_NONE, 'max': N.POOL_MAX, 'sum': N.POOL_SUM}[case.get('pool')]
+    n_store = case.get('n_store')
+    kc = 16 if taps == 9 else 32
+    assert Cin % kc == 0
+    wp = O.pack_conv_weight(w.to(dev), taps, Cout, Cin)
+    y, yp = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, taps,
+                   bias=bias.to(dev) if bias is not None else None, pro=pro, pro_s=ps, pro_t=pt,
+                   pro_bstride=Cin if ps is not None else 0, ups=ups,
+                   alpha=case.get('alpha', 1.0), act=act, pool=pool, res=res_t,
+                   res_ups=case.get('res') == 'ups', mask=mask_t, n_store=n_store,
+                   want_y=case.get('want_y', True), splitk=case.get('splitk'))
+    torch.cuda.synchronize()
+    tol = 2e-5
+    if y is not None:
+        got = nchw(y)
+        exp = ref if n_store is None else ref[:, :n_store]
+        assert relerr(got, exp) < tol, 'y'
+    if pool:
+        got = nchw(yp)
+        exp = F.max_pool2d(ref, 2, 2) if case['pool'] == 'max' else F.avg_pool2d(ref, 2, 2) * 4
+        assert relerr(got, exp) < tol, 'pooled'
+
+
+@pytest.mark.parametrize('taps,Cin,Cout,H', [(9, 64, 128, 16), (1, 128, 64, 16), (9, 3, 64, 32), (9, 128, 3, 32)])
+def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
+    """the transpose_flip packing turns the same kernel into the input-gradient."""
+    g = torch.Generator().manual_seed(2)
+    k = 3 if taps == 9 else 1
+    B = 2
+    x = torch.randn(B, Cin, H, H, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    F.conv2d(x, w, None, padding=k // 2).backward(dy)
+    kc = 16 if taps == 9 else 32
+    K_pad = (Cout + kc - 1) // kc * kc
+    N_pad = (Cin + 31) // 32 * 32
+    wt = O.pack_conv_weight(w.to(dev), taps, N_pad, K_pad, flip=True)
+    dyp = torch.zeros(B, K_pad, H, H)
+    dyp[:, :Cout] = dy
+    dx, _ = O.conv(nhwc(dyp, dev), wt, B, H, H, K_pad, N_pad, taps)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx)[:, :Cin], x.grad) < 2e-5
+
+
+@pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(dev, O, akm, bkm):
+    g = torch.Generator().manual_seed(3)
+    batch, M, Nn, K = 2, 256, 96, 80
+    A = torch.randn(batch, M, K, generator=g)
+    Bm = torch.randn(batch, Nn, K, generator=g)
+    ref = torch.bmm(A, Bm.transpose(1, 2)) * 0.7
+    Ad = (A.transpose(1, 2) if akm else A).contiguous().to(dev)
+    Bd = (Bm.transpose(1, 2) if bkm else Bm).contiguous().to(dev)
+    Cm = O.gemm(Ad, Bd, batch, M, Nn, K, a_kmajor=akm, b_kmajor=bkm, alpha=0.7)
+    torch.cuda.synchronize()
+    assert relerr(Cm.cpu(), ref) < 2e-5
+    C2 = O.gemm(Ad, Bd, batch, M, Nn, K, a_kmajor=akm, b_kmajor=bkm, alpha=0.7, Cacc=Cm.clone())
+    torch.cuda.synchronize()
+    assert relerr(C2.cpu(), 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize('Bn', [1, 9, 18])
+def test_linear_fwd_bwd(dev, O, Bn):
+    g = torch.Generator().manual_seed(4)
+    K, Nn = 256, 1000
+    x = torch.randn(Bn, K, generator=g)
+    W = torch.randn(K, Nn, generator=g) / 16
+    b = torch.randn(Nn, generator=g)
+    y = O.linear_fwd(x.to(dev), W.to(dev), b.to(dev))
+    assert relerr(y.cpu(), x @ W + b) < 1e-5
+    dy = torch.randn(Bn, Nn, generator=g)
+    dx = O.linear_bwd(dy.to(dev), W.to(dev))
+    assert relerr(dx.cpu(), dy @ W.t()) < 1e-5
+    dx2 = O.linear_bwd(dy.to(dev), W.to(dev), dx=dx.clone())
+    assert relerr(dx2.cpu(), 2 * (dy @ W.t())) < 1e-5
+
+
+@pytest.mark.parametrize('skip', [None, 'same', 'ups'])
+def test_affine_relu_bwd(dev, O, skip):
+    g = torch.Generator().manual_seed(5)
+    B, C, H = 3, 128, 16
+    x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    s = (0.5 + torch.rand(B, C, generator=g)).requires_grad_(True)
+    t = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    da = torch.randn(B, C, H, H, generator=g)
+    a = F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1))
+    a.backward(da)
+    exp_dx = x.grad.clone()
+    sk_t, skip_C = None, 0
+    if skip == 'same':
+        sk = torch.randn(B, C, H, H, generator=g)
+        exp_dx = exp_dx + sk
+        sk_t, skip_C = nhwc(sk, dev), C
+    elif skip == 'ups':
+        sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
+        add = F.avg_pool2d(sk, 2, 2) * 4
+        exp_dx[:, :C // 2] += add
+        sk_t, skip_C = nhwc(sk, dev), C // 2
+    dx, ds, dt = O.affine_relu_bwd(nhwc(da, dev), nhwc(x.detach(), dev), s.detach().to(dev),
+                                   t.detach().to(dev), C, skip=sk_t, skip_C=skip_C,
+                                   skip_ups=(skip == 'ups'))
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), exp_dx) < 1e-5
+    assert relerr(ds.cpu(), s.grad) < 2e-5
+    assert relerr(dt.cpu(), t.grad) < 2e-5
+
+
+def test_softmax_fwd_bwd(dev, O):
+    g = torch.Generator().manual_seed(6)
+    S = (torch.randn(2, 64, 1024, generator=g) * 5).requires_grad_(True)
+    P = torch.softmax(S, -1)
+    dP = torch.randn(2, 64, 1024, generator=g)
+    P.backward(dP)
+    Pd = O.softmax_fwd(S.detach().to(dev))
+    assert relerr(Pd.cpu(), P.detach()) < 1e-5
+    dS = O.softmax_bwd(Pd, dP.to(dev))
+    assert relerr(dS.cpu(), S.grad) < 1e-4
+
+
+def test_maxpool2_bwd(dev, O):
+    g = torch.Generator().manual_seed(7)
+    B, C, H = 2, 64, 16
+    pre = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    y = F.relu(pre)
+    yp = F.max_pool2d(y, 2, 2)
+    dyp = torch.randn_like(yp)
+    add = torch.randn(B, C, H, H, generator=g)
+    (yp * dyp).sum().backward(retain_graph=True)
+    g_pool = pre.grad.clone()          # pool backward through relu mask
+    pre.grad = None
+    (y * add).sum().backward()
+    exp = g_pool + pre.grad
+    got = O.maxpool2_bwd(nhwc(y.detach(), dev), nhwc(dyp, dev), add=nhwc(add, dev), relu_mask=True)
+    assert relerr(nchw(got), exp) < 1e-6
+
+
+def test_adam_matches_torch(dev, O):
+    g = torch.Generator().manual_seed(8)
+    p0 = torch.randn(18 * 128, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=0.05)
+    p = p0.clone().to(dev)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for step in range(1, 6):
+        grad = torch.randn(18 * 128, generator=g) * (10.0 ** (-step))
+        p_ref.grad = grad.clone()
+        opt.step()
+        O.adam_step(p, grad.to(dev), m, v, 0.05, step)
+    assert (p.cpu() - p_ref.detach()).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('h', [256, 128, 64, 32, 16])
+def test_bilinear_adjoint(dev, O, h):
+    g = torch.Generator().manual_seed(9)
+    B, H = 2, 256
+    wsrc = torch.rand(B, H, H, generator=g)
+    m = torch.randn(B, 1, h, h, generator=g, requires_grad=True)
+    up = F.interpolate(m, size=(H, H), mode='bilinear', align_corners=False)
+    (up[:, 0] * wsrc).sum().backward()
+    wt = O.bilinear_adjoint(wsrc.to(dev), h, h)
+    assert relerr(wt.cpu(), m.grad[:, 0]) < 1e-5
+
+
+@pytest.mark.parametrize('C', [64, 128, 256, 512])
+def test_lpips_tap(dev, O, C):
+    g = torch.Generator().manual_seed(10)
+    B, h = 2, 16
+    f = F.relu(torch.randn(B, C, h, h, generator=g)).requires_grad_(True)
+    ft = F.relu(torch.randn(B, C, h, h, generator=g))
+    lin = torch.rand(C, generator=g) / C
+    wt = torch.rand(B, h, h, generator=g)
+    wsum = torch.tensor([3.0, 5.0])
+
+    def norm(a):
+        return a / (torch.sqrt((a ** 2).sum(1, keepdim=True)) + 1e-10)
+    d = ((norm(f) - norm(ft)) ** 2 * lin.view(1, C, 1, 1)).sum(1)
+    loss = (d * wt).sum((1, 2)) / wsum
+    gl = torch.tensor([0.7, -1.3])
+    (loss * gl).sum().backward()
+    nft = O.lpips_normalize(nhwc(ft, dev))
+    assert relerr(nchw(nft), norm(ft)) < 1e-5
+    got = O.lpips_tap_fwd(nhwc(f.detach(), dev), nft, lin.to(dev), wt.to(dev), wsum.to(dev))
+    assert relerr(got.cpu(), loss.detach()) < 1e-5
+    df = O.lpips_tap_bwd(nhwc(f.detach(), dev), nft, lin.to(dev), wt.to(dev), (gl / wsum).to(dev))
+    assert relerr(nchw(df), f.grad) < 1e-4
