@@ -381,9 +381,18 @@ int choose_tile(const P2LConv* d, ConvK& k) {
 template <int TAPS, int BN, int KC, int A_ITERS>
 int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles, k.splitk), block(256);
-#define P2L_LAUNCH(PRO, UPS)                                                   \
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS>), grid, \
-                     block, lds, st, k)
+#define P2L_LAUNCH(PRO, UPS)                                                     \
+  do {                                                                           \
+    auto kfn = conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS>;                \
+    static bool attr_set = false;                                                \
+    if (!attr_set) {                                                             \
+      (void)hipFuncSetAttribute((const void*)kfn,                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                160 * 1024);                                     \
+      attr_set = true;                                                           \
+    }                                                                            \
+    hipLaunchKernelGGL(kfn, grid, block, lds, st, k);                            \
+  } while (0)
   if (ups) {
     if (pro == P2L_PRO_NONE) P2L_LAUNCH(P2L_PRO_NONE, true);
     else if (pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH(P2L_PRO_AFFINE_RELU, true);

@@ -1,0 +1,195 @@
+"""_BaseOptimizer: shared step / transform / tracking / logging logic.
+
+Mirror of reference pix2latent/optimizer/base_optimizer.py:9-141 (constructor
+arguments, register_transform :44-59, apply_transform :62-78, step :81-97,
+track :100-107, log_result :123-141) with three MI355X-first changes:
+  * the population can be sharded across ranks (parallel.PopulationShard): each
+    rank evaluates a contiguous block of candidates, losses are all-gathered;
+  * `track()` keeps device clones and only copies to the host when `tracked` is
+    read (the reference forces a D2H sync every step, :105-106);
+  * `apply_transform` writes into the contiguous variable buffers in place, which
+    also invalidates the loss' cached target features.
+"""
+import numpy as np
+import torch
+
+from .closure import step, LazyLosses
+from ..parallel import PopulationShard
+from ..utils.image import to_image, to_grid, binarize, resize_area
+from ..variable_manager import slice_vars
+
+
+class _BaseOptimizer():
+    """ Base template for gradient optimization """
+
+    def __init__(self, model, var_manager, loss_fn, max_batch_size=9,
+                 log=False, track_variables=True, **kwargs):
+        """
+        Args
+            model (nn.Module): a model to invert
+            var_manager (VariableManager): instance of the variable manager
+            loss_fn (callable): loss function to compute gradients with
+            max_batch_size (int): maximum batch size; larger populations are
+                processed in chunks of this size
+        """
+        self.max_batch_size = max_batch_size
+        self.model = model.eval() if hasattr(model, 'eval') else model
+        self.var_manager = var_manager
+        self.loss_fn = loss_fn
+        self.transform_fns = {}
+
+        self.log = log
+        self.log_iter = 5
+        self.show_iter = 50
+        self.log_resize_factor = None
+        self.track_variables = track_variables
+        self._tracked = {}
+        self.shard = PopulationShard()
+        return
+
+    # -- tracking ------------------------------------------------------------
+    @property
+    def tracked(self):
+        """{variable name: [per-step CPU tensors [N,*shape]]} like the reference"""
+        return {k: [t.cpu() for t in v] for k, v in self._tracked.items()}
+
+    def track(self, variables):
+        for v_name, v_data in variables.input.items():
+            if v_name not in self._tracked.keys():
+                self._tracked[v_name] = []
+            self._tracked[v_name] += [torch.stack(list(v_data.data)).detach().clone()]
+        return
+
+    def register_benchmark(self, benchmark):
+        self.bm = benchmark
+        return
+
+    # -- transforms ----------------------------------------------------------
+    def register_transform(self, transform_fn, tranform_var_name, target_var_name):
+        """
+        Applies transformation function using the transform_var on the target
+        variables before optimizing.
+        """
+        self.transform_fns[target_var_name] = {
+            'fn': transform_fn,
+            'transform_param': tranform_var_name,
+            'target_var': target_var_name
+        }
+        return
+
+    @torch.no_grad()
+    def apply_transform(self, variables, transform_dict):
+        t_fn = transform_dict['fn']
+        src_name = transform_dict['transform_param']
+        dst_name = transform_dict['target_var']
+
+        src_type = self.var_manager.variable_info[src_name]['var_type']
+        dst_type = self.var_manager.variable_info[dst_name]['var_type']
+
+        src_data = torch.stack(list(variables[src_type][src_name].data))
+        dst_data = torch.stack(list(variables[dst_type][dst_name].data))
+
+        new_dst_data = t_fn(dst_data, src_data)
+        for i in range(len(new_dst_data)):
+            variables[dst_type][dst_name].data[i].copy_(new_dst_data[i])
+        return
+
+    # -- the step --------------------------------------------------------------
+    def _grad_scale(self, n, lo, hi, device):
+        """1 / (size of the REFERENCE chunk each candidate would sit in)"""
+        mbs = self.max_batch_size
+        sizes = [min(mbs, n - (i // mbs) * mbs) for i in range(lo, hi)]
+        return torch.tensor([1.0 / s for s in sizes], dtype=torch.float32, device=device)
+
+    def step(self, variables, optimize=True, transform=False):
+        if len(self.transform_fns) > 0 and transform:
+            for _, transform_dict in self.transform_fns.items():
+                self.apply_transform(variables, transform_dict)
+
+        if self.track_variables:
+            self.track(variables)
+
+        if not self.shard.enabled:
+            self.out, self.loss, self.other = step(
+                self.model, variables,
+                loss_fn=self.loss_fn,
+                optimize=optimize,
+                max_batch_size=self.max_batch_size
+            )
+            return self.out, self.loss, self.other
+
+        n = variables.num_samples
+        lo, hi = self.shard.bounds(n)
+        first = next(iter(variables.input.values())).data[0]
+        if hi > lo:
+            local = slice_vars(variables, lo, hi)
+            gs = self._grad_scale(n, lo, hi, first.device)
+            out, loss, self.other = step(self.model, local, loss_fn=self.loss_fn,
+                                         optimize=optimize,
+                                         max_batch_size=self.max_batch_size, grad_scale=gs)
+            loss_t = loss.tensor() if isinstance(loss, LazyLosses) else \
+                torch.tensor(np.asarray(loss), dtype=torch.float32, device=first.device)
+        else:
+            out, self.other = None, {}
+            loss_t = torch.zeros(0, dtype=torch.float32, device=first.device)
+        self.out_local = out
+        self.loss = LazyLosses(self.shard.all_gather_losses(loss_t, n))
+        self.out = out
+        return self.out, self.loss, self.other
+
+    def gather_population(self, variables):
+        """after sharded optimisation: make every rank's `variables` and
+        `self.out` hold the whole population again (final return value)."""
+        if not self.shard.enabled:
+            return
+        n = variables.num_samples
+        lo, hi = self.shard.bounds(n)
+        with torch.no_grad():
+            for _, v in variables.input.items():
+                full = self.shard.all_gather_rows(torch.stack(list(v.data[lo:hi])) if hi > lo
+                                                  else v.data[0].new_zeros((0,) + tuple(v.data[0].shape)), n)
+                for i in range(n):
+                    v.data[i].copy_(full[i])
+            if self.out_local is not None:
+                proto = self.out_local
+            else:
+                proto = None
+            shape = self.shard_out_shape(proto)
+            local = proto if proto is not None else torch.zeros((0,) + shape, device=v.data[0].device)
+            self.out = self.shard.all_gather_rows(local, n)
+
+    def shard_out_shape(self, proto):
+        if proto is not None:
+            self._out_shape = tuple(proto.shape[1:])
+        return getattr(self, '_out_shape', (3, 256, 256))
+
+    def optimize(self):
+        raise NotImplementedError
+
+    def benchmark(self, variables, out):
+        """quality metrics through a registered benchmark object (the reference
+        version, base_optimizer.py:114-120, raises NameError)."""
+        t_var = variables.get('transform', {}).get('t', None) if hasattr(variables, 'get') else None
+        if t_var is not None and 'target' in self.transform_fns:
+            out = self.transform_fns['target']['fn'](out, torch.stack(list(t_var.data)), invert=True)
+        target = variables.output.target.data[0].unsqueeze(0)
+        weight = binarize(variables.output.weight.data[0].clone()).unsqueeze(0)
+        return self.bm.evaluate(out, target, weight)
+
+    def log_result(self, variables, step_iter):
+        if hasattr(self, 'bm'):
+            res = self.benchmark(variables, self.out)
+        else:
+            res = {'loss': np.array(self.loss)}
+        self.losses.append([step_iter, res])
+
+        collage = to_image(to_grid(self.out.cpu()), cv2_format=False)
+
+        if self.log_resize_factor is not None:
+            collage = resize_area(np.array(collage, dtype=np.uint8), self.log_resize_factor)
+
+        self.outs.append(collage)
+        return
+
+    def _final_grid(self):
+        return to_grid(torch.stack(list(self.out.cpu().detach())))

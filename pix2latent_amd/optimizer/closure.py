@@ -1,0 +1,193 @@
+"""The inner-loop body: chunk -> hooks -> forward -> loss -> backward -> Adam.
+
+Mirror of the reference pix2latent/optimizer/closure.py:6-79 (`step`), with the
+semantics listed in SURVEY.md §3.2 kept:
+  * contiguous chunks of `max_batch_size` samples, one optimizer shared by all;
+  * per closure call: targets gathered, grads cleared, hooks mutate the latents
+    IN PLACE before the forward -- also when `optimize=False` -- then the model
+    is called with keyword arguments named after the input variables and the
+    loss with keyword arguments named after the output variables;
+  * per-sample loss = loss_fn(...).view(b, -1).mean(1); the back-propagated
+    scalar is the MEAN over the chunk (gradient factor 1/b_chunk);
+  * returns (out [N,3,H,W] detached, per-sample losses, {}).
+
+Two execution paths:
+  * fused (default on the ROCm device, `vars.opt` is a FusedAdam): chunk slices of
+    the contiguous variable buffers are fed straight to the generator, hooks are
+    one kernel per chunk, the gradient comes back as one [b, dim] tensor and
+    Adam is one HIP launch per variable; losses stay on the device until someone
+    reads them (no per-chunk host sync, reference closure.py:60);
+  * generic (any torch optimizer / CPU tensors): the reference's own sequence
+    -- stack the per-sample leaves, `opt.step(closure)` -- used by the golden
+    trace tests and for user-supplied optimizers.
+"""
+import numpy as np
+import torch
+
+from ..variable_manager import split_vars, FusedAdam
+
+
+class LazyLosses(object):
+    """per-sample losses that stay on the device until they are looked at;
+    behaves like the reference's list of np.float32."""
+
+    def __init__(self, t):
+        self._t = t
+        self._np = None
+
+    def tensor(self):
+        return self._t
+
+    def _get(self):
+        if self._np is None:
+            self._np = self._t.detach().float().cpu().numpy()
+        return self._np
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._get()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __len__(self):
+        return int(self._t.numel())
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __repr__(self):
+        return 'LazyLosses(%r)' % (self._get(),)
+
+
+def _in_sync(var):
+    """True when every per-sample tensor still aliases its slot of the
+    contiguous buffer (user code may rebind `.data` like the reference does)."""
+    buf = var.get('buf', None)
+    if buf is None or len(var.data) != buf.size(0):
+        return False
+    stride = buf.stride(0) * buf.element_size() if buf.size(0) > 1 else 0
+    base = buf.data_ptr()
+    for i, t in enumerate(var.data):
+        if t.data_ptr() != base + i * stride or t.shape != buf.shape[1:]:
+            return False
+    return True
+
+
+def _gather(var):
+    """[b, *shape] tensor of a variable chunk: zero-copy when possible."""
+    if _in_sync(var):
+        return var.buf
+    return torch.stack(list(var.data))
+
+
+def _run_hook(var):
+    if var.hook_fn is None:
+        return
+    if hasattr(var.hook_fn, 'apply_batched') and _in_sync(var):
+        with torch.no_grad():
+            var.hook_fn.apply_batched(var.buf)
+    else:
+        var.hook_fn(var.data)
+
+
+def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
+    outs, losses = [], []
+    for ci, _vars in enumerate(split_vars(vars, size=max_batch_size)):
+        b_sz = _vars.num_samples
+        gs = None if grad_scale is None else \
+            grad_scale[ci * max_batch_size: ci * max_batch_size + b_sz]
+        target_args = {k: _gather(v) for k, v in _vars.output.items()}
+        for _, var in _vars.input.items():
+            _run_hook(var)
+        leaves, input_args = {}, {}
+        for k, var in _vars.input.items():
+            x = _gather(var)
+            if optimize and var.get('requires_grad', False):
+                x = x.detach().requires_grad_(True)
+                leaves[k] = (x, var)
+            input_args[k] = x
+        with torch.set_grad_enabled(bool(optimize)):
+            out = model(**input_args)
+            loss = loss_fn(out, **target_args).view(b_sz, -1).mean(1)
+            if optimize:
+                if gs is None:
+                    loss.mean().backward()
+                else:
+                    (loss * gs).sum().backward()
+        if optimize:
+            for k, (x, var) in leaves.items():
+                if x.grad is None:
+                    continue
+                if not _in_sync(var):
+                    raise RuntimeError('variable `%s` was rebound outside its buffer; '
+                                       'fused Adam cannot update it' % k)
+                off = var.get('offset', 0)
+                _vars.opt.update(k, off, off + b_sz, x.grad)
+        outs.append(out.detach())
+        losses.append(loss.detach())
+    return torch.cat(outs), LazyLosses(torch.cat(losses)), {}
+
+
+def _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
+    outs, indiv_losses = [], []
+    for ci, _vars in enumerate(split_vars(vars, size=max_batch_size)):
+        box = {}
+        gs = None if grad_scale is None else \
+            grad_scale[ci * max_batch_size: ci * max_batch_size + _vars.num_samples]
+
+        def closure():
+            b_sz = _vars.num_samples
+            target_args = {k: torch.stack(list(v.data)) for k, v in _vars.output.items()}
+            if optimize:
+                _vars.opt.zero_grad()
+            # (1) hooks mutate the leaves in place
+            for _, var in _vars.input.items():
+                if var.hook_fn is not None:
+                    var.hook_fn(var.data)
+            # (2) forward
+            input_args = {k: torch.stack(list(v.data)) for k, v in _vars.input.items()}
+            out = model(**input_args)
+            # (3) loss
+            loss = loss_fn(out, **target_args).view(b_sz, -1).mean(1)
+            if optimize:
+                if gs is None:
+                    loss.mean().backward()
+                else:
+                    (loss * gs).sum().backward()
+            box['out'] = out
+            box['loss'] = loss.detach().cpu().numpy()
+
+        # (4) optimize
+        if optimize:
+            _vars.opt.step(closure)
+            _vars.opt.zero_grad()
+        else:
+            with torch.no_grad():
+                closure()
+        outs.extend(box['out'].detach())
+        indiv_losses.extend(box['loss'])
+    return torch.stack(outs), indiv_losses, {}
+
+
+def step(model, vars, loss_fn, optimize=True, max_batch_size=9, grad_scale=None):
+    """
+    The step function for model evaluation.
+
+    Args:
+        vars: variable object generated from variable_manager.
+        loss_fn: loss function; called as loss_fn(out, **{output variables}).
+        optimize: if False, does not compute gradients nor update anything
+            (hooks still run, as in the reference).
+        max_batch_size: chunk size.
+        grad_scale: optional per-sample gradient weight replacing the implicit
+            1/b_chunk of `loss.mean()`; population sharding passes the
+            REFERENCE chunk size here so that trajectories do not depend on the
+            number of GPUs.
+
+    Returns:
+        outs, indiv_losses (list-like of np.float32), misc_return ({})
+    """
+    if isinstance(vars.opt, FusedAdam):
+        return _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale)
+    return _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale)
