@@ -76,6 +76,9 @@ typedef struct P2LConv {
   int32_t res_ups;  /* 1: residual is [B,H/2,W/2,*] read with nearest x2      */
   int32_t mask_ld;  /* mask pixel pitch (mask > 0 keeps the value)            */
   int32_t splitk;   /* >=1; >1 needs workspace of splitk*B*H*W*Cout floats    */
+  double algo_flops; /* algorithmic FLOPs of this launch for the profiler;    */
+                     /* 0 = 2*B*H*W*Cin*Cout*taps (set it when Cin/Cout are   */
+                     /* zero-padded, e.g. the 3-channel image convs)          */
 } P2LConv;
 
 /* Weight layout expected in `w`: [taps][Cin/KC][Cout][KC] fp32 with KC = 16 for
@@ -88,6 +91,12 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                  const float* bias, const float* pro_s, const float* pro_t,
                  const float* res, const float* mask, float* y, float* yp,
                  void* workspace, size_t ws_bytes, void* stream);
+
+/* Per-launch timing of the conv kernel with HIP events recorded on the launch
+ * stream (bench.py roofline leg).  begin() pre-creates the event pool; end()
+ * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */
+int p2l_prof_begin(int max_launches);
+int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
 
 /* w_oihw is [O][I][kh][kw].  transpose_flip=0 packs the conv I->O (K_pad >= I,
  * N_pad >= O, zero padded); transpose_flip=1 packs the conv that maps dY[O] to

@@ -22,7 +22,7 @@ class P2LConv(C.Structure):
                 ('pro_bstride', C.c_int32), ('alpha', C.c_float), ('act', C.c_int32),
                 ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
                 ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
-                ('mask_ld', C.c_int32), ('splitk', C.c_int32)]
+                ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('algo_flops', C.c_double)]
 
 
 class P2LGemm(C.Structure):
@@ -82,7 +82,7 @@ EXPORTS = [
     'p2l_clamp', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end',
 ]
 
 _lib = None

@@ -34,7 +34,20 @@
 //     be reproducible).
 #include "p2l_common.h"
 
+#include <vector>
+
 namespace {
+
+// Optional per-launch timing of the conv kernel (bench.py's roofline leg):
+// hipEvents from a pre-created pool are recorded on the launch stream around
+// every conv (incl. its split-K finish); nothing is allocated while enabled.
+struct ConvProf {
+  bool on = false;
+  int n = 0;
+  std::vector<hipEvent_t> ev;
+  std::vector<double> flops;
+  std::vector<int> kind;
+} g_prof;
 
 struct ConvK {
   const float* x;
@@ -65,24 +78,39 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // Epilogue for one quad (4 sub-pixels) of one output channel.
-__device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4],
+// pix0 = linear index of the quad's top-left pixel ((b*H + oy0)*W + ox0); all
+// element offsets fit in 32 bits (B*H*W*ld < 2^31 is checked on the host).
+// SIMPLE = no residual / mask / pool / second output: the common conv->conv case.
+template <bool SIMPLE>
+__device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], int pix0,
                                               int b, int oy0, int ox0, int n,
                                               float bias_n) {
+  const int W = k.W;
+  const int sub[4] = {0, 1, W, W + 1};
+  if (SIMPLE) {
+    float* yp = k.y + (size_t)((unsigned)pix0 * (unsigned)k.y_ld + (unsigned)n);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float t = apply_act(k.alpha * a[s] + bias_n, k.act);
+      yp[(unsigned)sub[s] * (unsigned)k.y_ld] = t;
+    }
+    return;
+  }
   float v[4];
+  int rp0 = pix0;
+  if (k.res && k.res_ups)
+    rp0 = (b * (k.H >> 1) + (oy0 >> 1)) * (W >> 1) + (ox0 >> 1);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int oy = oy0 + (s >> 1), ox = ox0 + (s & 1);
-    const size_t pix = ((size_t)b * k.H + oy) * k.W + ox;
+    const unsigned pix = (unsigned)(pix0 + sub[s]);
     float t = k.alpha * a[s] + bias_n;
     if (k.res) {
-      const size_t rp =
-          k.res_ups ? ((size_t)b * (k.H >> 1) + (oy >> 1)) * (k.W >> 1) + (ox >> 1)
-                    : pix;
-      t += k.res[rp * k.res_ld + n];
+      const unsigned rp = k.res_ups ? (unsigned)rp0 : pix;
+      t += k.res[(size_t)(rp * (unsigned)k.res_ld + (unsigned)n)];
     }
     t = apply_act(t, k.act);
-    if (k.mask) t = (k.mask[pix * k.mask_ld + n] > 0.f) ? t : 0.f;
-    if (k.y) k.y[pix * k.y_ld + n] = t;
+    if (k.mask) t = (k.mask[(size_t)(pix * (unsigned)k.mask_ld + (unsigned)n)] > 0.f) ? t : 0.f;
+    if (k.y) k.y[(size_t)(pix * (unsigned)k.y_ld + (unsigned)n)] = t;
     v[s] = t;
   }
   if (k.pool) {
@@ -91,9 +119,8 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4],
       p = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
     else
       p = (v[0] + v[1]) + (v[2] + v[3]);
-    const size_t pp =
-        ((size_t)b * (k.H >> 1) + (oy0 >> 1)) * (k.W >> 1) + (ox0 >> 1);
-    k.yp[pp * k.yp_ld + n] = p;
+    const unsigned pp = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (W >> 1) + (ox0 >> 1));
+    k.yp[(size_t)(pp * (unsigned)k.yp_ld + (unsigned)n)] = p;
   }
 }
 
@@ -284,30 +311,50 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
 
   // ---- epilogue -----------------------------------------------------------
+  // lane owns column n of 4 quads (g): Q = wave*8 + 2g + lhi, 4 sub-pixels each
+  int q_pix0[4], q_b[4], q_oy[4], q_ox[4];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + j * 32 + l31;
-    const float bias_n = (k.bias && k.splitk == 1) ? k.bias[n] : 0.f;
+  for (int g = 0; g < 4; ++g) {
+    const int Q = wave * 8 + 2 * g + lhi;
+    const int qx = Q & ((TW >> 1) - 1);
+    const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
+    const int tb = Q >> (k.tw_log + k.th_log - 2);
+    q_b[g] = b0 + tb;
+    q_oy[g] = y0 + 2 * qy;
+    q_ox[g] = x0 + 2 * qx;
+    q_pix0[g] = (q_b[g] * k.H + q_oy[g]) * k.W + q_ox[g];
+  }
+  const bool simple = (k.splitk == 1) && !k.res && !k.mask && !k.pool && k.y;
+  if (k.splitk > 1) {
+    const size_t mtot = (size_t)k.B * k.H * k.W;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int Q = wave * 8 + 2 * g + lhi;
-      const int qx = Q & ((TW >> 1) - 1);
-      const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
-      const int tb = Q >> (k.tw_log + k.th_log - 2);
-      const int b = b0 + tb;
-      if (b >= k.B) continue;
-      const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
-      float a[4] = {acc[j][g * 4 + 0], acc[j][g * 4 + 1], acc[j][g * 4 + 2],
-                    acc[j][g * 4 + 3]};
-      if (k.splitk > 1) {
-        const size_t mtot = (size_t)k.B * k.H * k.W;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 32 + l31;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const size_t pix = ((size_t)b * k.H + oy0 + (s >> 1)) * k.W + ox0 + (s & 1);
-          k.ws[((size_t)z * mtot + pix) * k.Cout + n] = a[s];
-        }
-      } else if (n < k.n_store) {
-        epilogue_quad(k, a, b, oy0, ox0, n, bias_n);
+      for (int g = 0; g < 4; ++g) {
+        if (q_b[g] >= k.B) continue;
+        float* wp = k.ws + ((size_t)z * mtot + (size_t)q_pix0[g]) * k.Cout + n;
+        wp[0] = acc[j][g * 4 + 0];
+        wp[k.Cout] = acc[j][g * 4 + 1];
+        wp[(size_t)k.W * k.Cout] = acc[j][g * 4 + 2];
+        wp[(size_t)(k.W + 1) * k.Cout] = acc[j][g * 4 + 3];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 32 + l31;
+      if (n >= k.n_store) continue;
+      const float bias_n = k.bias ? k.bias[n] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (q_b[g] >= k.B) continue;
+        const float a[4] = {acc[j][g * 4 + 0], acc[j][g * 4 + 1], acc[j][g * 4 + 2],
+                            acc[j][g * 4 + 3]};
+        if (simple)
+          epilogue_quad<true>(k, a, q_pix0[g], q_b[g], q_oy[g], q_ox[g], n, bias_n);
+        else
+          epilogue_quad<false>(k, a, q_pix0[g], q_b[g], q_oy[g], q_ox[g], n, bias_n);
       }
     }
   }
@@ -335,7 +382,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
       acc += k.ws[((size_t)zz * mtot + pix) * k.Cout + n];
     a[s] = acc;
   }
-  epilogue_quad(k, a, b, 2 * qy, 2 * qx, n, k.bias ? k.bias[n] : 0.f);
+  epilogue_quad<false>(k, a, (b * k.H + 2 * qy) * k.W + 2 * qx, b, 2 * qy, 2 * qx, n,
+                       k.bias ? k.bias[n] : 0.f);
 }
 
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
@@ -378,6 +426,18 @@ int choose_tile(const P2LConv* d, ConvK& k) {
   return P2L_OK;
 }
 
+// Output-channel tile: 64 unless the grid then leaves CUs idle in its last
+// round.  All blocks of a launch do the same MFMA work and co-resident blocks
+// share a CU's matrix pipes, so time ~ ceil(blocks / 256 CUs) * work-per-block.
+int choose_bn(const P2LConv* d, int n_mtiles) {
+  if (d->Cout % 64) return 32;
+  const int n64 = n_mtiles * (d->Cout / 64), n32 = n_mtiles * (d->Cout / 32);
+  if (n64 < 256) return 64;               // split-K regime: keep the fatter tile
+  const double t64 = (double)cdiv(n64, 256) * 64.0;
+  const double t32 = (double)cdiv(n32, 256) * 32.0 * 1.06;   // thinner tile: less reuse
+  return (t32 < 0.93 * t64) ? 32 : 64;
+}
+
 template <int TAPS, int BN, int KC, int A_ITERS>
 int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles, k.splitk), block(256);
@@ -411,7 +471,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (choose_tile(d, k) != P2L_OK) return 1;
-  const int bn = (d->Cout % 64 == 0) ? 64 : 32;
+  const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : 32;
   const int nblk = k.n_mtiles * (d->Cout / bn);
   const int nchunks = d->Cin / kc;
@@ -445,6 +505,15 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
   if (d->n_store < 1 || d->n_store > d->Cout) return P2L_EINVAL;
+  {
+    // element offsets are computed in 32 bits inside the kernel
+    const int64_t px = (int64_t)d->B * d->H * d->W;
+    int64_t ldmax = d->x_ld;
+    if (d->y_ld > ldmax) ldmax = d->y_ld;
+    if (d->res_ld > ldmax) ldmax = d->res_ld;
+    if (d->mask_ld > ldmax) ldmax = d->mask_ld;
+    if (px * ldmax >= ((int64_t)1 << 31)) return P2L_EUNSUP;
+  }
 
   ConvK k{};
   k.x = x; k.w = w; k.bias = bias; k.pro_s = pro_s; k.pro_t = pro_t;
@@ -456,7 +525,7 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   k.ups = d->ups;
   int rc = choose_tile(d, k);
   if (rc) return rc;
-  const int bn = (d->Cout % 64 == 0) ? 64 : 32;
+  const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
   k.splitk = d->splitk < 1 ? 1 : d->splitk;
@@ -472,6 +541,15 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
   const size_t lds = (size_t)(a_rows + d->taps * bn) * (kc + 4) * sizeof(float);
 
+  int prof_slot = -1;
+  if (g_prof.on && g_prof.n < (int)g_prof.flops.size()) {
+    prof_slot = g_prof.n++;
+    g_prof.flops[prof_slot] = d->algo_flops > 0.0
+        ? d->algo_flops
+        : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
+    g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
+    (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
+  }
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256);
     if (bn == 64) rc = small ? launch_conv<9, 64, 16, 3>(k, d->pro, d->ups, lds, st)
@@ -489,7 +567,40 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                        st, k);
     rc = p2l_check_launch();
   }
+  if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
   return rc;
+}
+
+extern "C" int p2l_prof_begin(int max_launches) {
+  if (max_launches < 1) return P2L_EINVAL;
+  while ((int)g_prof.ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return P2L_ELAUNCH;
+    g_prof.ev.push_back(e);
+  }
+  g_prof.flops.assign(max_launches, 0.0);
+  g_prof.kind.assign(max_launches, 0);
+  g_prof.n = 0;
+  g_prof.on = true;
+  return P2L_OK;
+}
+
+extern "C" int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]) {
+  g_prof.on = false;
+  flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
+  count[0] = count[1] = 0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return P2L_ELAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      return P2L_ELAUNCH;
+    const int k = g_prof.kind[i];
+    flops[k] += g_prof.flops[i];
+    ms[k] += t;
+    count[k] += 1;
+  }
+  g_prof.n = 0;
+  return P2L_OK;
 }
 
 extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,

@@ -68,31 +68,50 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
   }
 }
 
-// linear bwd: dx[b][k] = sum_n dy[b][n] W[k][n]; one block per k
+// linear bwd: dx[b][k] = sum_n dy[b][n] W[k][n]; one 1024-thread block per k
+// (16 waves per CU keep enough loads in flight to stream W and the L2-resident
+// dy rows), float4 loads, fixed-order wave -> LDS reduction.
 template <int BG>
-__global__ __launch_bounds__(256) void linear_bwd_kernel(
+__global__ __launch_bounds__(1024) void linear_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ W,
     float* __restrict__ dx, int Bn, int b_begin, int K, int N, int accumulate) {
-  __shared__ float red[4];
+  __shared__ float red[BG][16];
   const int k = blockIdx.x, tid = threadIdx.x;
   const int nb = min(BG, Bn - b_begin);
   float acc[BG];
 #pragma unroll
   for (int b = 0; b < BG; ++b) acc[b] = 0.f;
   const float* wrow = W + (size_t)k * N;
-  for (int n = tid; n < N; n += 256) {
+  const int N4 = N >> 2;
+  for (int i = tid; i < N4; i += 1024) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + 4 * i);
+#pragma unroll
+    for (int b = 0; b < BG; ++b) {
+      if (b < nb) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (size_t)(b_begin + b) * N + 4 * i);
+        acc[b] += (d.x * w.x + d.y * w.y) + (d.z * w.z + d.w * w.w);
+      }
+    }
+  }
+  for (int n = 4 * N4 + tid; n < N; n += 1024) {   // tail when N % 4 != 0
     const float w = wrow[n];
 #pragma unroll
     for (int b = 0; b < BG; ++b)
       if (b < nb) acc[b] = fmaf(dy[(size_t)(b_begin + b) * N + n], w, acc[b]);
   }
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int b = 0; b < BG; ++b) {
-    const float s = block_sum_256(acc[b], red);
-    if (tid == 0 && b < nb) {
-      float* p = dx + (size_t)(b_begin + b) * K + k;
-      *p = accumulate ? (*p + s) : s;
-    }
+    const float v = wave_sum(acc[b]);
+    if (lane == 0) red[b][wave] = v;
+  }
+  __syncthreads();
+  if (tid < nb) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[tid][w];
+    float* p = dx + (size_t)(b_begin + tid) * K + k;
+    *p = accumulate ? (*p + s) : s;
   }
 }
 
@@ -665,10 +684,10 @@ extern "C" int p2l_linear_fwd(const float* x, const float* W, const float* bias,
 
 extern "C" int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn,
                               int K, int N, int accumulate, void* stream) {
-  if (!dy || !W || !dx || Bn < 1) return P2L_EINVAL;
+  if (!dy || !W || !dx || Bn < 1 || (N % 4)) return P2L_EINVAL;
   constexpr int BG = 16;
   for (int b0 = 0; b0 < Bn; b0 += BG)
-    hipLaunchKernelGGL(linear_bwd_kernel<BG>, dim3(K), dim3(256), 0, ST(stream), dy,
+    hipLaunchKernelGGL(linear_bwd_kernel<BG>, dim3(K), dim3(1024), 0, ST(stream), dy,
                        W, dx, Bn, b0, K, N, accumulate);
   return p2l_check_launch();
 }

@@ -68,7 +68,7 @@ ConvCall mk_conv(int B, int H, int W, int Cin, int Cout, int taps) {
   c.d.ups = 0; c.d.x_ld = Cin; c.d.pro = P2L_PRO_NONE; c.d.pro_bstride = 0;
   c.d.alpha = 1.f; c.d.act = P2L_ACT_NONE; c.d.pool = P2L_POOL_NONE;
   c.d.y_ld = Cout; c.d.yp_ld = Cout; c.d.n_store = Cout; c.d.res_ld = 0;
-  c.d.res_ups = 0; c.d.mask_ld = 0; c.d.splitk = 1;
+  c.d.res_ups = 0; c.d.mask_ld = 0; c.d.splitk = 1; c.d.algo_flops = 0.0;
   return c;
 }
 size_t conv_ws_floats(ConvCall& c) {
@@ -339,6 +339,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
   rc.x = x; rc.w = m->rgb_w; rc.bias = m->rgb_b; rc.y = img16;
   rc.d.pro = P2L_PRO_AFFINE_RELU; rc.d.pro_bstride = 0; rc.ps = m->tail_s; rc.pt = m->tail_t;
   rc.d.act = P2L_ACT_TANH; rc.d.y_ld = 16; rc.d.n_store = 16;
+  rc.d.algo_flops = 2.0 * B * L.out_res * L.out_res * (double)m->ch * 3 * 9;
   RET_IF(run_conv(rc, skws, L.skws_floats, st));
   return P2L_OK;
 }
@@ -364,6 +365,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     // conv_to_rgb input-gradient, then the unconditional BN+ReLU backward.
     ConvCall c = mk_conv(B, R, R, 16, m->ch, 9);
     c.x = dimg16; c.w = m->rgb_wt; c.y = gb;
+    c.d.algo_flops = 2.0 * B * R * R * (double)m->ch * 3 * 9;
     RET_IF(run_conv(c, skws, L.skws_floats, st));
     const float* xlast = W + L.blk[m->n_blocks - 1].y;
     // ds/dt of the tail BN feed nothing (no conditioning): park them in `draw`.
@@ -567,6 +569,7 @@ int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, f
     c.d.act = P2L_ACT_RELU;
     if (i == 0) {
       c.d.pro = P2L_PRO_AFFINE; c.d.pro_bstride = 0; c.ps = v->in_s; c.pt = v->in_t;
+      c.d.algo_flops = 2.0 * B * h * w * 3.0 * kVggCout[0] * 9;
     }
     if (vgg_pool_after(i)) {
       c.d.pool = P2L_POOL_MAX; c.yp = Wk + L.yp[pi];
@@ -715,6 +718,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
   {
     ConvCall c = mk_conv(B, H, W, 64, 32, 9);
     c.x = ga; c.w = v->wt[0]; c.y = dimg16; c.d.y_ld = 16; c.d.n_store = 16;
+    c.d.algo_flops = 2.0 * B * H * W * 3.0 * 64 * 9;
     RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
   }
   RET_IF(p2l_l1_loss_bwd(img16, target, weight, loss_mask, cache->wsum, gloss, dimg16, B, H,

@@ -136,17 +136,42 @@ class _VggLpipsParams(object):
         return dst.data_ptr()
 
 
+class _CacheSlot(object):
+    """target-dependent state of one (target, weight, loss_mask) chunk."""
+
+    def __init__(self, lib, B, H, W, dev):
+        nft_off = (C.c_size_t * 5)()
+        wt_off = (C.c_size_t * 5)()
+        wsum_off = C.c_size_t(0)
+        n = lib.p2l_loss_cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
+        self.buf = torch.empty(n, device=dev, dtype=torch.float32)
+        self.desc = N.P2LLossCache()
+        base = self.buf.data_ptr()
+        for k in range(5):
+            self.desc.nft[k] = base + 4 * nft_off[k]
+            self.desc.wt[k] = base + 4 * wt_off[k]
+        self.desc.wsum = base + 4 * wsum_off.value
+        self.held = None
+
+
 class _LossEngine(object):
-    """workspace + target cache for p2l_projloss_*; one per loss object."""
+    """workspace + target caches for p2l_projloss_*; one per loss object.
+
+    The cache is keyed on the identity (data_ptr, version, shape) of the target /
+    weight / loss_mask tensors.  A population is evaluated in several chunks per
+    step, each with its own slice of the per-sample targets, so several slots
+    are kept (LRU): the VGG pass over the targets runs once per chunk and
+    generation, not once per step as in the reference (loss_functions.py:142).
+    """
+    MAX_SLOTS = 8
 
     def __init__(self, vgg_params):
         self.lib = N.lib()
         self.vgg = vgg_params
-        self.key = None
         self.shape = None
         self.ws = None
-        self.cache_buf = None
-        self.cache = N.P2LLossCache()
+        self.slots = {}          # key -> _CacheSlot (insertion order = LRU order)
+        self.cache = None        # P2LLossCache of the slot bound by the last prepare()
         self._memo = {}
         self._fwd_ticket = 0
 
@@ -158,20 +183,10 @@ class _LossEngine(object):
             raise N.NativeError('p2l_projloss_ws_bytes rejected shape %s' % ((B, H, W),))
         self.ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         self.ws_bytes = nbytes
-        nft_off = (C.c_size_t * 5)()
-        wt_off = (C.c_size_t * 5)()
-        wsum_off = C.c_size_t(0)
-        n = self.lib.p2l_loss_cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
-        self.cache_buf = torch.empty(n, device=dev, dtype=torch.float32)
-        base = self.cache_buf.data_ptr()
-        for k in range(5):
-            self.cache.nft[k] = base + 4 * nft_off[k]
-            self.cache.wt[k] = base + 4 * wt_off[k]
-        self.cache.wsum = base + 4 * wsum_off.value
         self.img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
         self.dimg16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
         self.shape = (B, H, W)
-        self.key = None
+        self.slots = {}
 
     @staticmethod
     def _ident(t):
@@ -191,6 +206,8 @@ class _LossEngine(object):
                 self._memo[name] = (key, torch.ones(B, 3, like.size(2), like.size(3),
                                                     device=like.device))
             return self._memo[name][1]
+        if t.dim() == 4 and t.size(0) == B and t.is_contiguous() and t.dtype == torch.float32:
+            return t
         key = (self._ident(t), B)
         if self._memo.get(name, (None, None))[0] != key:
             e = t
@@ -206,16 +223,23 @@ class _LossEngine(object):
         B, _, H, W = out.shape
         self._alloc(B, H, W, out.device)
         key = (self._ident(target), self._ident(weight), self._ident(loss_mask), use_lpips)
-        if key == self.key:
-            return
-        vref = C.byref(self.vgg.desc) if use_lpips else None
-        N.check(self.lib.p2l_projloss_prepare(vref, N.ptr(target), N.ptr(weight),
-                                              N.ptr(loss_mask), B, H, W, C.byref(self.cache),
-                                              N.ptr(self.ws), C.c_size_t(self.ws_bytes),
-                                              N.stream()), 'p2l_projloss_prepare')
-        self.key = key
-        # keep the tensors alive so that data_ptr identity stays meaningful
-        self._held = (target, weight, loss_mask)
+        slot = self.slots.pop(key, None)
+        if slot is None:
+            if len(self.slots) >= self.MAX_SLOTS:
+                slot = self.slots.pop(next(iter(self.slots)))     # recycle the LRU slot
+            else:
+                slot = _CacheSlot(self.lib, B, H, W, out.device)
+            vref = C.byref(self.vgg.desc) if use_lpips else None
+            N.check(self.lib.p2l_projloss_prepare(vref, N.ptr(target), N.ptr(weight),
+                                                  N.ptr(loss_mask), B, H, W,
+                                                  C.byref(slot.desc), N.ptr(self.ws),
+                                                  C.c_size_t(self.ws_bytes), N.stream()),
+                    'p2l_projloss_prepare')
+            # keep the tensors alive so that data_ptr identity stays meaningful
+            slot.held = (target, weight, loss_mask)
+        self.slots[key] = slot      # most recently used last
+        self.cache = slot.desc
+        return slot
 
 
 def _apply(eng, output, target, weight, loss_mask, beta, mode):
@@ -233,7 +257,8 @@ class _ProjLossFn(torch.autograd.Function):
         B, _, H, W = output.shape
         out_c = output.contiguous().float()
         use_lpips = 0 if mode == 1 else 1
-        eng.prepare(out_c, target, weight, loss_mask, use_lpips)
+        slot = eng.prepare(out_c, target, weight, loss_mask, use_lpips)
+        ctx.slot = slot
         N.check(lib.p2l_nchw3_to_nhwc16(N.ptr(out_c), N.ptr(eng.img16), B, H, W, N.stream()),
                 'p2l_nchw3_to_nhwc16')
         loss = torch.empty(B, device=output.device, dtype=torch.float32)
@@ -241,7 +266,7 @@ class _ProjLossFn(torch.autograd.Function):
         lp = torch.empty_like(loss)
         vref = C.byref(eng.vgg.desc) if use_lpips else None
         N.check(lib.p2l_projloss_fwd(vref, N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
-                                     N.ptr(loss_mask), C.byref(eng.cache), N.f32(beta),
+                                     N.ptr(loss_mask), C.byref(slot.desc), N.f32(beta),
                                      use_lpips, B, H, W, N.ptr(eng.ws),
                                      C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
                                      N.ptr(lp), N.stream()), 'p2l_projloss_fwd')
@@ -275,7 +300,7 @@ class _ProjLossFn(torch.autograd.Function):
                                 'ProjectionLoss in this build')
         N.check(lib.p2l_projloss_bwd(C.byref(eng.vgg.desc) if use_lpips else None,
                                      N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
-                                     N.ptr(loss_mask), C.byref(eng.cache), N.f32(ctx.beta),
+                                     N.ptr(loss_mask), C.byref(ctx.slot.desc), N.f32(ctx.beta),
                                      use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
                                      C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
                 'p2l_projloss_bwd')

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the GPU box has 256 host cores; torch-CPU (the oracle) is slowest when it
+    # oversubscribes them
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 

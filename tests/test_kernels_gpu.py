@@ -170,7 +170,7 @@ def test_gemm_layouts(dev, O, akm, bkm):
 @pytest.mark.parametrize('Bn', [1, 9, 18])
 def test_linear_fwd_bwd(dev, O, Bn):
     g = torch.Generator().manual_seed(4)
-    K, Nn = 256, 1000
+    K, Nn = 256, 1000  # Nn % 4 == 0
     x = torch.randn(Bn, K, generator=g)
     W = torch.randn(K, Nn, generator=g) / 16
     b = torch.randn(Nn, generator=g)

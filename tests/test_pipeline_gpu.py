@@ -1,0 +1,128 @@
+"""The fused closure path (contiguous buffers, batched hooks, p2l_adam_step,
+lazy losses) and whole optimisation loops on the MI355X against (a) the golden
+traces of the imported reference and (b) the same loop driven on the CPU
+oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toy import ToyGenerator, toy_target, toy_weight  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def make_vm(device):
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import function_hooks as hook
+    vm = VariableManager(device=device)
+    vm.register('z', (6,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook.Clamp(1.5), grad_free=True)
+    vm.register('c', (4,), 'input', default=torch.linspace(-0.2, 0.2, 4), learning_rate=0.01)
+    vm.register('target', (3, 4, 4), 'output', requires_grad=False, default=toy_target())
+    vm.register('weight', (3, 4, 4), 'output', requires_grad=False, default=toy_weight())
+    return vm
+
+
+def toy_loss(out, target, weight):
+    loss = torch.abs(target - out)
+    return torch.sum(loss * weight, [1, 2, 3]) / torch.sum(weight, [1, 2, 3])
+
+
+def test_fused_closure_matches_reference_trace(dev):
+    """FusedAdam + batched Clamp + chunk slices reproduce the reference's
+    GradientOptimizer trajectory (golden from the imported reference)."""
+    from pix2latent_amd.optimizer import GradientOptimizer
+    from pix2latent_amd.variable_manager import FusedAdam
+    g = np.load(os.path.join(GOLD, 'gradient_optimizer.npz'))
+    model = ToyGenerator().to(dev)
+    torch.manual_seed(42)
+    opt = GradientOptimizer(model, make_vm(dev), toy_loss, max_batch_size=2)
+    vars2 = opt.var_manager.initialize(num_samples=5)
+    assert isinstance(vars2.opt, FusedAdam)
+    for i in range(3):
+        _, l, _ = opt.step(vars2, optimize=True, transform=(i == 0))
+        assert np.allclose(np.array(l), g['step_losses'][i], atol=2e-6)
+        assert np.allclose(vars2.input.z.buf.cpu().numpy(), g['step_z'][i], atol=2e-6)
+    _, l_ns, _ = opt.step(vars2, optimize=False)
+    assert np.allclose(np.array(l_ns), g['rescore_loss'], atol=2e-6)
+    assert [c[0] for c in model.calls] == [2, 2, 1] * 4
+
+
+class OracleBigGAN(nn.Module):
+    def __init__(self, W):
+        super().__init__()
+        self.W = W
+
+    def forward(self, z=None, c=None):
+        from oracle import biggan_ref as R
+        return R.biggan_forward(self.W, z, c)
+
+
+def test_gradient_optimizer_biggan_vs_cpu_oracle(dev):
+    """BASELINE config 2 shape, reduced to 2 candidates x 3 Adam steps: the
+    native engine and the CPU oracle driven by the SAME optimizer code."""
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import synthetic as S, function_hooks as hook
+    from pix2latent_amd.model.biggan import BigGAN
+    from pix2latent_amd.optimizer import GradientOptimizer
+    import pix2latent_amd.loss_functions as LF
+    from oracle import lpips_ref as L
+    W, Wv = S.biggan_weights(0), S.lpips_vgg_weights(1)
+    gen = torch.Generator().manual_seed(2)
+    c_default = 0.05 * torch.randn(128, generator=gen)
+    target, weight = S.synthetic_target(256, 1), S.synthetic_weight_mask(256)
+
+    def run(device, model, loss_fn):
+        vm = VariableManager(device=device)
+        vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                    learning_rate=0.05, hook_fn=hook.Clamp(2.0))
+        vm.register('c', (128,), 'input', default=c_default, learning_rate=0.01)
+        vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=target)
+        vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
+        torch.manual_seed(5)
+        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9)
+        variables = vm.initialize(num_samples=2)
+        losses = []
+        for i in range(3):
+            _, l, _ = opt.step(variables, optimize=True, transform=(i == 0))
+            losses.append(np.array(l, dtype=np.float64))
+        z = torch.stack(list(variables.input.z.data)).detach().cpu().numpy()
+        return np.stack(losses), z
+
+    l_gpu, z_gpu = run(dev, BigGAN(weights=W, device=dev),
+                       LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev))
+    l_cpu, z_cpu = run('cpu', OracleBigGAN(W),
+                       lambda out, target, weight: L.projection_loss(Wv, out, target, weight))
+    assert np.abs(l_gpu - l_cpu).max() < 1e-3, (l_gpu, l_cpu)
+    assert np.all(np.diff(l_gpu.mean(1)) < 0), 'loss must go down'
+    # Adam's first update is lr*sign(g): latents agree unless a gradient SIGN flips,
+    # which fp32 noise (relL2 ~3e-3 in the oracle itself) only does for |g| ~ 0.
+    dz = np.abs(z_gpu - z_cpu)
+    assert np.median(dz) < 1e-3, np.median(dz)
+    assert np.mean(dz < 0.02) > 0.97, np.mean(dz < 0.02)
+
+
+def test_basincma_generation_on_biggan(dev):
+    """one BasinCMA generation (pop 18, chunks 9+9) end to end: finite, improving,
+    ranking stable across a repeated re-score (deterministic reductions)."""
+    import bench
+    opt, vm, _ = bench.build_problem(dev)
+    opt.setup_cma(vm)
+    variables = opt.cma_init(vm)
+    _, l0, _ = opt.step(variables, optimize=False)
+    l0 = np.array(l0)
+    for j in range(2):
+        opt.step(variables, optimize=True, transform=(j == 0))
+    _, l1, _ = opt.step(variables, optimize=False)
+    _, l2, _ = opt.step(variables, optimize=False)
+    l1, l2 = np.array(l1), np.array(l2)
+    assert l0.shape == (18,) and np.isfinite(l1).all()
+    assert l1.mean() < l0.mean()
+    assert np.array_equal(l1, l2), 're-score must be bit-reproducible'
+    opt.cma_update(variables, loss=l1)

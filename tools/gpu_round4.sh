@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -15 > gpurun_out/tests.log
+timeout 300 python tools/bench_kernels.py > gpurun_out/bench_kernels.log 2>&1
+python bench.py --steps 10 --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err
+echo "=== tests"; cat gpurun_out/tests.log
+echo "=== kernels"; cat gpurun_out/bench_kernels.log
+echo "=== bench"; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
