@@ -1,0 +1,100 @@
+"""C-ABI checks that need no GPU: the shared library loads, exports every symbol
+include/p2l.h declares, pure-host entry points behave, ctypes structs match the
+C layout, and the product path refuses to run without the HIP device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    so = os.path.join(ROOT, 'pix2latent_amd', 'libp2l_hip.so')
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    from pix2latent_amd import _native as N
+    return N.lib()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'p2l.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(p2l_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from pix2latent_amd import _native as N
+    syms = header_symbols()
+    assert len(syms) >= 45
+    for s in syms:
+        assert hasattr(lib, s), 'libp2l_hip.so does not export %s' % s
+    assert sorted(N.EXPORTS) == syms, set(N.EXPORTS) ^ set(syms)
+
+
+def test_version_and_errors(lib):
+    assert lib.p2l_version() >= 100
+    assert lib.p2l_strerror(0) == b'ok'
+    assert b'workspace' in lib.p2l_strerror(-3)
+    assert lib.p2l_affine_relu_bwd_nblk(65536) == 256
+    assert lib.p2l_l1_loss_nblk(256, 256) == 256
+
+
+def test_struct_layouts_match_c(lib):
+    """sizes implied by include/p2l.h on LP64"""
+    from pix2latent_amd import _native as N
+    assert C.sizeof(N.P2LConv) == 20 * 4 + 8
+    assert C.sizeof(N.P2LGemm) == 7 * 4 + 4 + 3 * 8 + 4 * 4
+    assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 12 * 8
+    assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8
+    assert C.sizeof(N.P2LLossCache) == 11 * 8
+
+
+def test_host_side_planning_calls(lib):
+    """shape validation / workspace sizing run on the host only"""
+    from pix2latent_amd import _native as N
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps = 9, 4, 4, 512, 512, 9
+    d.splitk = 1
+    s = lib.p2l_conv_suggest_splitk(C.byref(d))
+    assert 1 < s <= 32                       # 4x4 layers must split K to fill the chip
+    d.splitk = s
+    assert lib.p2l_conv_workspace_bytes(C.byref(d)) == s * 9 * 16 * 512 * 4
+    d.H = d.W = 256
+    d.Cin = d.Cout = 64
+    assert lib.p2l_conv_suggest_splitk(C.byref(d)) == 1
+    assert lib.p2l_projloss_ws_bytes(2, 256, 256) > 0
+    assert lib.p2l_projloss_ws_bytes(2, 100, 100) == 0          # not a power of two
+    # invalid arguments are rejected before any launch
+    assert lib.p2l_conv_fwd(None, None, None, None, None, None, None, None, None, None,
+                            None, C.c_size_t(0), None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from pix2latent_amd import _native as N
+    from pix2latent_amd.model.biggan import BigGAN
+    from pix2latent_amd.utils import synthetic as S
+    with pytest.raises(N.NativeError, match='no CPU fallback'):
+        BigGAN(weights={'embeddings.weight': torch.zeros(128, 1000),
+                        'generator.gen_z.weight': torch.zeros(8, 256),
+                        'generator.gen_z.bias': torch.zeros(8)}, device='cpu')
+    import pix2latent_amd.loss_functions as LF
+    with pytest.raises(NotImplementedError):
+        LF.ProjectionLoss(lpips_net='alex')
+
+
+def test_oracle_not_imported_by_product():
+    """the oracle is test infrastructure: nothing under pix2latent_amd/ or the
+    drop-in alias may import it."""
+    for base in ('pix2latent_amd', 'pix2latent'):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith('.py'):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f

@@ -1,0 +1,93 @@
+"""Population sharding (pix2latent_amd/parallel.py) with world_size 2 over gloo
+on CPU: partition, loss all-gather, CMA ask broadcast, and the invariant that a
+sharded BasinCMA run reproduces the single-process trajectory (gradient scale
+= reference chunk size)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def test_partition_blocks():
+    from pix2latent_amd.parallel import partition
+    assert [hi - lo for lo, hi in partition(18, 8)] == [3, 3, 2, 2, 2, 2, 2, 2]
+    assert [hi - lo for lo, hi in partition(18, 4)] == [5, 5, 4, 4]
+    assert partition(18, 2) == [(0, 9), (9, 18)]
+    assert [hi - lo for lo, hi in partition(22, 8)] == [3, 3, 3, 3, 3, 3, 2, 2]
+    assert [hi - lo for lo, hi in partition(3, 8)] == [1, 1, 1, 0, 0, 0, 0, 0]
+
+
+def _run_basincma(shard_expected):
+    from _toy import ToyGenerator, toy_target, toy_weight, FakeCMAES
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import BasinCMAOptimizer
+    import pix2latent_amd.optimizer.base_cma_optimizer as B
+    B.CMAEvolutionStrategy = FakeCMAES
+    FakeCMAES.log = []
+
+    def toy_loss(out, target, weight):
+        loss = torch.abs(target - out)
+        return torch.sum(loss * weight, [1, 2, 3]) / torch.sum(weight, [1, 2, 3])
+    vm = VariableManager(device='cpu')
+    vm.register('z', (6,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook.Clamp(1.5), grad_free=True)
+    vm.register('c', (4,), 'input', default=torch.linspace(-0.2, 0.2, 4), learning_rate=0.01)
+    vm.register('target', (3, 4, 4), 'output', requires_grad=False, default=toy_target())
+    vm.register('weight', (3, 4, 4), 'output', requires_grad=False, default=toy_weight())
+    torch.manual_seed(43)
+    opt = BasinCMAOptimizer(ToyGenerator(), vm, toy_loss, max_batch_size=3)
+    assert opt.shard.enabled == shard_expected
+    variables, _, losses = opt.optimize(meta_steps=2, grad_steps=2, last_grad_steps=3)
+    return (torch.stack(list(variables.input.z.data)).detach().numpy(),
+            np.array(losses[-1][1]['loss']), [t[1] for t in FakeCMAES.log], opt.out.shape)
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pix2latent_amd.parallel import PopulationShard
+        sh = PopulationShard()
+        lo, hi = sh.bounds(9)
+        local = torch.arange(lo, hi, dtype=torch.float32) * 10
+        full = sh.all_gather_losses(local, 9)
+        asked = sh.broadcast_numpy(np.full((9, 6), float(rank + 7)), src=0)
+        z, loss, told, out_shape = _run_basincma(True)
+        q.put((rank, full.numpy(), asked, z, loss, told, tuple(out_shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_basincma_matches_single_process():
+    g = np.load(os.path.join(HERE, 'golden', 'basincma.npz'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, full, asked, z, loss, told, out_shape in res:
+        assert np.array_equal(full, np.arange(9) * 10.0)
+        assert np.all(asked == 7.0)                      # rank 0's ask() reached everyone
+        assert out_shape == (9, 3, 4, 4)
+        # same numbers as the reference's single-process golden trace
+        assert np.allclose(told[0], g['tell_y0'], atol=1e-6)
+        assert np.allclose(told[1], g['tell_y1'], atol=1e-6)
+        assert np.allclose(z, g['final_z'], atol=1e-5)
+        assert np.allclose(loss, g['final_loss'], atol=1e-6)
+    assert np.array_equal(res[0][3], res[1][3])           # replicas agree bit for bit
