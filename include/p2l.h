@@ -92,6 +92,31 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                  const float* res, const float* mask, float* y, float* yp,
                  void* workspace, size_t ws_bytes, void* stream);
 
+/* Input-gradient conv fused with the backward of a = max(x*s+t,0) of its consumer
+ * (replaces p2l_conv_fwd + p2l_affine_relu_bwd for the GenBlock convs):
+ *   da = conv(dy, w)  [2x2-summed when d->pool == P2L_POOL_SUM: nearest-x2 backward]
+ *   g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ; ds[b,c] = sum g*x ; dt[b,c] = sum g
+ * Usable when p2l_conv_arb_fusable(d) (one image per tile, no split-K); `partial`
+ * needs 2*B*p2l_conv_arb_nblk(d)*Cout floats. */
+typedef struct P2LArb {
+  const float* x; int32_t x_ld;              /* pre-activation input of the forward conv */
+  const float* s; const float* t; int32_t st_bstride;
+  const float* skip; int32_t skip_ld, skip_C, skip_ups;   /* GenBlock shortcut gradient   */
+  float* ds; float* dt; int32_t dsdt_bstride;
+  float* partial;
+} P2LArb;
+int p2l_conv_arb_fusable(const P2LConv* d);
+int p2l_conv_arb_nblk(const P2LConv* d);
+int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
+                       const float* w, float* dx, void* stream);
+int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk, int C,
+                   int out_bstride, void* stream);
+
+/* Select the 3x3 kernel for eligible layers: -1 = v1 (default); 0 / 1 = the
+ * persistent LDS-double-buffered v2 with 256- / 128-pixel tiles (experimental,
+ * see csrc/p2l_conv2.hip).  $P2L_CONV_FORCE overrides the argument. */
+int p2l_set_conv_variant(int variant);
+
 /* Per-launch timing of the conv kernel with HIP events recorded on the launch
  * stream (bench.py roofline leg).  begin() pre-creates the event pool; end()
  * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */

@@ -25,6 +25,13 @@ class P2LConv(C.Structure):
                 ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('algo_flops', C.c_double)]
 
 
+class P2LArb(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('x_ld', C.c_int32), ('s', C.c_void_p), ('t', C.c_void_p),
+                ('st_bstride', C.c_int32), ('skip', C.c_void_p), ('skip_ld', C.c_int32),
+                ('skip_C', C.c_int32), ('skip_ups', C.c_int32), ('ds', C.c_void_p),
+                ('dt', C.c_void_p), ('dsdt_bstride', C.c_int32), ('partial', C.c_void_p)]
+
+
 class P2LGemm(C.Structure):
     _fields_ = [('batch', C.c_int32), ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
                 ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32),
@@ -82,7 +89,8 @@ EXPORTS = [
     'p2l_clamp', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
+    'p2l_conv_dgrad_arb', 'p2l_arb_finish',
 ]
 
 _lib = None

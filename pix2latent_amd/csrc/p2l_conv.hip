@@ -32,11 +32,18 @@
 //   * Small-M layers (4x4..16x16) split K over blockIdx.y and finish with a
 //     deterministic reduce+epilogue kernel (no float atomics: CMA ranking must
 //     be reproducible).
-#include "p2l_common.h"
+#include "p2l_conv_k.h"
 
+#include <cstdlib>
 #include <vector>
 
+using namespace p2lconv;
+
 namespace {
+
+// which 3x3 kernel p2l_conv_fwd uses for eligible layers: -1 = v1 (default),
+// 0 / 1 = persistent double-buffered v2 with 256- / 128-pixel tiles.
+int g_conv_variant = -1;
 
 // Optional per-launch timing of the conv kernel (bench.py's roofline leg):
 // hipEvents from a pre-created pool are recorded on the launch stream around
@@ -49,78 +56,161 @@ struct ConvProf {
   std::vector<int> kind;
 } g_prof;
 
-struct ConvK {
-  const float* x;
-  const float* w;
-  const float* bias;
-  const float* pro_s;
-  const float* pro_t;
-  const float* res;
-  const float* mask;
-  float* y;
-  float* yp;
-  float* ws;
-  int B, H, W, Cin, Cout;
-  int x_ld, y_ld, yp_ld, res_ld, mask_ld, n_store;
-  int pro_bstride;
-  float alpha;
-  int act, pool, res_ups, ups;
-  int nchunks, chunks_per_split, splitk;
-  int tw_log, th_log, tb_log;
-  int tiles_x_log, tiles_y_log;
-  int n_mtiles, n_ntiles;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == P2L_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == P2L_ACT_TANH) return tanhf(v);
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+  if (act == P2L_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (act == P2L_ACT_TANH) {
+    v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+  }
   return v;
 }
+__device__ __forceinline__ f32x4 ld4(const float* p, unsigned off) {
+  return *reinterpret_cast<const f32x4*>(p + (size_t)off);
+}
+__device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p + (size_t)off) = v;
+}
 
-// Epilogue for one quad (4 sub-pixels) of one output channel.
-// pix0 = linear index of the quad's top-left pixel ((b*H + oy0)*W + ox0); all
-// element offsets fit in 32 bits (B*H*W*ld < 2^31 is checked on the host).
-// SIMPLE = no residual / mask / pool / second output: the common conv->conv case.
-template <bool SIMPLE>
-__device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], int pix0,
-                                              int b, int oy0, int ox0, int n,
-                                              float bias_n) {
-  const int W = k.W;
-  const int sub[4] = {0, 1, W, W + 1};
-  if (SIMPLE) {
-    float* yp = k.y + (size_t)((unsigned)pix0 * (unsigned)k.y_ld + (unsigned)n);
+// Vectorised epilogue.  The MFMA C layout gives a lane one channel of 16 pixels:
+// storing that directly is 4-byte accesses, 128 B per pixel and instruction.  Instead
+// every wave dumps its 32 x (NT*32) accumulator tile into LDS (free after the K loop)
+// and re-reads it so that a lane owns ONE 2x2 pixel quad x FOUR consecutive channels:
+// all global accesses are 16 B per lane and NT*128 B contiguous per pixel, 2x2 pooling
+// stays lane-local, and the per-channel sums of the fused activation backward reduce
+// with 2-3 shuffles.  Handles every epilogue mode of the conv:
+//   v = alpha*acc + bias + residual ; act ; mask ; store ; 2x2 max/sum pool, or
+//   ARB (input-gradient convs): g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ;
+//   partial sums of g*x and g per (tile, channel)  [da 2x2-summed first if pool==SUM].
+template <int NT>
+__device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)[NT],
+                                             float* smem, int wave, int lane, int b0, int y0,
+                                             int x0, int n0, int tile_in_image) {
+  constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* tb = smem + wave * 32 * EP;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float t = apply_act(k.alpha * a[s] + bias_n, k.act);
-      yp[(unsigned)sub[s] * (unsigned)k.y_ld] = t;
-    }
-    return;
-  }
-  float v[4];
-  int rp0 = pix0;
-  if (k.res && k.res_ups)
-    rp0 = (b * (k.H >> 1) + (oy0 >> 1)) * (W >> 1) + (ox0 >> 1);
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const unsigned pix = (unsigned)(pix0 + sub[s]);
-    float t = k.alpha * a[s] + bias_n;
-    if (k.res) {
-      const unsigned rp = k.res_ups ? (unsigned)rp0 : pix;
-      t += k.res[(size_t)(rp * (unsigned)k.res_ld + (unsigned)n)];
+    for (int r = 0; r < 16; ++r)
+      tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[j][r];
+  __syncthreads();
+
+  const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
+  const bool arb = k.arb_x != nullptr;
+  const bool pool_sum = k.pool == P2L_POOL_SUM;
+  f32x4 sgx = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+#pragma unroll
+  for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+    const int it = it0 + lane;
+    const int q = it / C4, c4 = it - q * C4;
+    const int n = n0 + c4 * 4;
+    const int Q = wave * 8 + q;
+    const int qx = Q & (TWh - 1), qy = (Q >> (k.tw_log - 1)) & (THh - 1);
+    const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
+    if (b >= k.B || n >= k.n_store) continue;
+    const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
+    const unsigned pix0 = (unsigned)((b * k.H + oy0) * k.W + ox0);
+    const unsigned sub[4] = {0u, 1u, (unsigned)k.W, (unsigned)k.W + 1u};
+    f32x4 v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * EP + c4 * 4) * k.alpha;
+    const unsigned ppix = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (k.W >> 1) + (ox0 >> 1));
+
+    if (!arb) {
+      f32x4 bias4 = {0, 0, 0, 0};
+      if (k.bias) bias4 = ld4(k.bias, (unsigned)n);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned pix = pix0 + sub[s];
+        f32x4 t = v[s] + bias4;
+        if (k.res) t += ld4(k.res, (k.res_ups ? ppix : pix) * (unsigned)k.res_ld + (unsigned)n);
+        t = act4(t, k.act);
+        if (k.mask) {
+          const f32x4 m = ld4(k.mask, pix * (unsigned)k.mask_ld + (unsigned)n);
+          t.x = m.x > 0.f ? t.x : 0.f; t.y = m.y > 0.f ? t.y : 0.f;
+          t.z = m.z > 0.f ? t.z : 0.f; t.w = m.w > 0.f ? t.w : 0.f;
+        }
+        if (k.y) st4(k.y, pix * (unsigned)k.y_ld + (unsigned)n, t);
+        v[s] = t;
+      }
+      if (k.pool) {
+        f32x4 p;
+        if (k.pool == P2L_POOL_MAX) {
+          p.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
+          p.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
+          p.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
+          p.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
+        } else {
+          p = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        st4(k.yp, ppix * (unsigned)k.yp_ld + (unsigned)n, p);
+      }
+    } else {
+      const f32x4 s4 = ld4(k.arb_s, (unsigned)(b * k.arb_bstride + n));
+      const f32x4 t4 = ld4(k.arb_t, (unsigned)(b * k.arb_bstride + n));
+      const bool has_skip = k.arb_skip && n < k.arb_skip_C;
+      const int nv = pool_sum ? 1 : 4;
+      if (pool_sum) v[0] = (v[0] + v[1]) + (v[2] + v[3]);
+      float* dst = pool_sum ? k.yp : k.y;
+      const unsigned dld = (unsigned)(pool_sum ? k.yp_ld : k.y_ld);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < nv) {
+          const unsigned pix = pool_sum ? ppix : pix0 + sub[s];
+          const f32x4 xv = ld4(k.arb_x, pix * (unsigned)k.arb_x_ld + (unsigned)n);
+          const f32x4 pre = xv * s4 + t4;
+          f32x4 g = v[s];
+          g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
+          g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+          f32x4 o = g * s4;
+          if (has_skip) {
+            const unsigned ld = (unsigned)k.arb_skip_ld;
+            if (k.arb_skip_ups) {
+              // this output pixel's 2x2 children in the [B,2Ho,2Wo,*] gradient
+              const int Wo = pool_sum ? (k.W >> 1) : k.W, Ho = pool_sum ? (k.H >> 1) : k.H;
+              const int yy = pool_sum ? (oy0 >> 1) : oy0 + (s >> 1);
+              const int xx = pool_sum ? (ox0 >> 1) : ox0 + (s & 1);
+              const unsigned W2 = 2u * (unsigned)Wo;
+              const unsigned cq = ((unsigned)(b * 2 * Ho + 2 * yy)) * W2 + 2u * (unsigned)xx;
+              o += (ld4(k.arb_skip, cq * ld + n) + ld4(k.arb_skip, (cq + 1) * ld + n)) +
+                   (ld4(k.arb_skip, (cq + W2) * ld + n) + ld4(k.arb_skip, (cq + W2 + 1) * ld + n));
+            } else {
+              o += ld4(k.arb_skip, pix * ld + (unsigned)n);
+            }
+          }
+          st4(dst, pix * dld + (unsigned)n, o);
+          sgx += g * xv;
+          sg += g;
+        }
+      }
     }
-    t = apply_act(t, k.act);
-    if (k.mask) t = (k.mask[(size_t)(pix * (unsigned)k.mask_ld + (unsigned)n)] > 0.f) ? t : 0.f;
-    if (k.y) k.y[(size_t)(pix * (unsigned)k.y_ld + (unsigned)n)] = t;
-    v[s] = t;
   }
-  if (k.pool) {
-    float p;
-    if (k.pool == P2L_POOL_MAX)
-      p = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    else
-      p = (v[0] + v[1]) + (v[2] + v[3]);
-    const unsigned pp = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (W >> 1) + (ox0 >> 1));
-    k.yp[(size_t)(pp * (unsigned)k.yp_ld + (unsigned)n)] = p;
+  if (arb) {
+    // lanes with equal (lane % C4) hold the same 4 channels for different quads
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1) {
+      sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
+      sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
+      sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
+      sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+    }
+    __syncthreads();                      // everyone is done reading the tile dumps
+    float* red = smem;                    // [2][4 waves][COLS]
+    if (lane < C4) {
+      *reinterpret_cast<f32x4*>(red + wave * COLS + lane * 4) = sgx;
+      *reinterpret_cast<f32x4*>(red + (4 + wave) * COLS + lane * 4) = sg;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < COLS && n0 + tid < k.n_store) {
+      const float a = (red[tid] + red[COLS + tid]) + (red[2 * COLS + tid] + red[3 * COLS + tid]);
+      const float t = (red[4 * COLS + tid] + red[5 * COLS + tid]) +
+                      (red[6 * COLS + tid] + red[7 * COLS + tid]);
+      const size_t o = ((size_t)b0 * k.arb_nblk + tile_in_image) * k.Cout + n0 + tid;
+      k.arb_partial[o] = a;
+      k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = t;
+    }
   }
 }
 
@@ -324,7 +414,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     q_ox[g] = x0 + 2 * qx;
     q_pix0[g] = (q_b[g] * k.H + q_oy[g]) * k.W + q_ox[g];
   }
-  const bool simple = (k.splitk == 1) && !k.res && !k.mask && !k.pool && k.y;
   if (k.splitk > 1) {
     const size_t mtot = (size_t)k.B * k.H * k.W;
 #pragma unroll
@@ -341,22 +430,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       }
     }
   } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 32 + l31;
-      if (n >= k.n_store) continue;
-      const float bias_n = k.bias ? k.bias[n] : 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (q_b[g] >= k.B) continue;
-        const float a[4] = {acc[j][g * 4 + 0], acc[j][g * 4 + 1], acc[j][g * 4 + 2],
-                            acc[j][g * 4 + 3]};
-        if (simple)
-          epilogue_quad<true>(k, a, q_pix0[g], q_b[g], q_oy[g], q_ox[g], n, bias_n);
-        else
-          epilogue_quad<false>(k, a, q_pix0[g], q_b[g], q_oy[g], q_ox[g], n, bias_n);
-      }
-    }
+    epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0,
+                     mt & ((1 << (k.tiles_x_log + k.tiles_y_log)) - 1));
   }
 }
 
@@ -490,7 +565,7 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
   return (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
 }
 
-extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
+static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x, const float* w,
                             const float* bias, const float* pro_s,
                             const float* pro_t, const float* res,
                             const float* mask, float* y, float* yp,
@@ -504,7 +579,10 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   if (d->pool != P2L_POOL_NONE && !yp) return P2L_EINVAL;
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
-  if (d->n_store < 1 || d->n_store > d->Cout) return P2L_EINVAL;
+  if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
+  if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
+      (mask && d->mask_ld % 4))
+    return P2L_EINVAL;
   {
     // element offsets are computed in 32 bits inside the kernel
     const int64_t px = (int64_t)d->B * d->H * d->W;
@@ -525,6 +603,15 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   k.ups = d->ups;
   int rc = choose_tile(d, k);
   if (rc) return rc;
+  if (arb) {
+    if (k.tb_log != 0 || d->splitk > 1 || res || mask || d->act != P2L_ACT_NONE ||
+        d->pool == P2L_POOL_MAX || !arb->x || !arb->s || !arb->t || !arb->partial)
+      return P2L_EUNSUP;
+    k.arb_x = arb->x; k.arb_s = arb->s; k.arb_t = arb->t; k.arb_skip = arb->skip;
+    k.arb_partial = arb->partial; k.arb_x_ld = arb->x_ld; k.arb_bstride = arb->st_bstride;
+    k.arb_skip_ld = arb->skip_ld; k.arb_skip_C = arb->skip_C; k.arb_skip_ups = arb->skip_ups;
+    k.arb_nblk = k.n_mtiles / d->B;
+  }
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
@@ -537,9 +624,6 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
     if (!workspace || ws_bytes < need) return P2L_EWS;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
-  const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
-  const size_t lds = (size_t)(a_rows + d->taps * bn) * (kc + 4) * sizeof(float);
 
   int prof_slot = -1;
   if (g_prof.on && g_prof.n < (int)g_prof.flops.size()) {
@@ -550,6 +634,33 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
     (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
   }
+  // ---- optional v2 kernel (see p2l_conv2.hip; measured equal-or-slower than v1, so
+  //      only used when selected through p2l_set_conv_variant) ----------------------
+  if (!arb && g_conv_variant >= 0 && d->taps == 9 && d->Cout % 64 == 0 && d->W >= 16 &&
+      d->H >= (g_conv_variant == 0 ? 16 : 8) && k.splitk == 1) {
+    ConvK k2 = k;
+    const int th = g_conv_variant == 0 ? 16 : 8;
+    k2.tw_log = 4; k2.th_log = ilog2(th); k2.tb_log = 0;
+    k2.tiles_x_log = ilog2(d->W / 16);
+    k2.tiles_y_log = ilog2(d->H / th);
+    k2.n_mtiles = d->B * (d->W / 16) * (d->H / th);
+    k2.n_ntiles = d->Cout / 64;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("P2L_ABL"); abl = e ? atoi(e) : 0; }
+    k2.abl = abl;
+    rc = p2l_launch_conv2(k2, d->pro, d->ups, g_conv_variant, st);
+    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    return rc;
+  }
+  const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
+  const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
+  size_t lds = (size_t)(a_rows + d->taps * bn) * (kc + 4) * sizeof(float);
+  {
+    // the vectorised epilogue re-uses the staging LDS for 4 wave tiles of 32 x (bn+4)
+    const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
+    if (lds_epi > lds) lds = lds_epi;
+  }
+
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256);
     if (bn == 64) rc = small ? launch_conv<9, 64, 16, 3>(k, d->pro, d->ups, lds, st)
@@ -569,6 +680,48 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
   }
   if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
   return rc;
+}
+
+extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
+                            const float* bias, const float* pro_s,
+                            const float* pro_t, const float* res,
+                            const float* mask, float* y, float* yp,
+                            void* workspace, size_t ws_bytes, void* stream) {
+  return conv_launch_impl(d, nullptr, x, w, bias, pro_s, pro_t, res, mask, y, yp, workspace,
+                          ws_bytes, stream);
+}
+
+extern "C" int p2l_conv_arb_fusable(const P2LConv* d) {
+  ConvK k{};
+  if (!d || choose_tile(d, k) != P2L_OK) return 0;
+  return k.tb_log == 0;     // one image per tile; the caller decides about split-K
+}
+
+extern "C" int p2l_conv_arb_nblk(const P2LConv* d) {
+  ConvK k{};
+  if (!d || choose_tile(d, k) != P2L_OK) return 0;
+  return k.n_mtiles / d->B;
+}
+
+extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
+                                  const float* w, float* dx, void* stream) {
+  if (!d || !arb || !dx) return P2L_EINVAL;
+  P2LConv dd = *d;
+  dd.splitk = 1;
+  const bool pooled = dd.pool == P2L_POOL_SUM;
+  int rc = conv_launch_impl(&dd, arb, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            pooled ? nullptr : dx, pooled ? dx : nullptr, nullptr, 0, stream);
+  if (rc) return rc;
+  const int nblk = p2l_conv_arb_nblk(&dd);
+  return p2l_arb_finish(arb->partial, arb->ds, arb->dt, dd.B, nblk, dd.Cout,
+                        arb->dsdt_bstride, stream);
+}
+
+extern "C" int p2l_set_conv_variant(int variant) {
+  if (variant < -1 || variant > 1) return P2L_EINVAL;
+  const char* e = getenv("P2L_CONV_FORCE");
+  g_conv_variant = e ? atoi(e) : variant;
+  return P2L_OK;
 }
 
 extern "C" int p2l_prof_begin(int max_launches) {

@@ -732,6 +732,13 @@ extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
   return p2l_check_launch();
 }
 
+extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk,
+                              int C, int out_bstride, void* stream) {
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0, ST(stream),
+                     partial, ds, dt, Bn, nblk, C, out_bstride);
+  return p2l_check_launch();
+}
+
 extern "C" int p2l_softmax_fwd(const float* S, float* P, int64_t rows, int cols,
                                void* stream) {
   const dim3 grid(cdiv(rows, 4)), block(256);

@@ -81,6 +81,32 @@ int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
                       skws_floats * sizeof(float), st);
 }
 
+// input-gradient conv + backward of the consumer's affine+ReLU; fused in the conv
+// epilogue when the layer allows it, otherwise conv -> tmp -> p2l_affine_relu_bwd.
+struct ArbArgs {
+  const float* x; int x_ld; const float* s; const float* t; int st_bstride;
+  const float* skip; int skip_ld, skip_C, skip_ups;
+  float* ds; float* dt; int dsdt_bstride;
+};
+int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* part,
+                  float* skws, size_t skws_floats, void* st) {
+  c.d.splitk = p2l_conv_suggest_splitk(&c.d);
+  const bool pooled = c.d.pool == P2L_POOL_SUM;
+  const int Ho = pooled ? c.d.H / 2 : c.d.H, Wo = pooled ? c.d.W / 2 : c.d.W;
+  if (c.d.splitk == 1 && p2l_conv_arb_fusable(&c.d)) {
+    P2LArb arb{};
+    arb.x = a.x; arb.x_ld = a.x_ld; arb.s = a.s; arb.t = a.t; arb.st_bstride = a.st_bstride;
+    arb.skip = a.skip; arb.skip_ld = a.skip_ld; arb.skip_C = a.skip_C; arb.skip_ups = a.skip_ups;
+    arb.ds = a.ds; arb.dt = a.dt; arb.dsdt_bstride = a.dsdt_bstride; arb.partial = part;
+    return p2l_conv_dgrad_arb(&c.d, &arb, c.x, c.w, dx, st);
+  }
+  if (pooled) { c.yp = tmp; c.y = nullptr; } else { c.y = tmp; c.yp = nullptr; }
+  RET_IF(run_conv(c, skws, skws_floats, st));
+  return p2l_affine_relu_bwd(tmp, c.d.Cout, a.x, a.x_ld, a.s, a.t, a.st_bstride, a.skip,
+                             a.skip_ld, a.skip_C, a.skip_ups, dx, c.d.Cout, a.ds, a.dt,
+                             a.dsdt_bstride, part, c.d.B, Ho, Wo, c.d.Cout, st);
+}
+
 // ---------------------------------------------------------------------------
 // BigGAN workspace layout
 // ---------------------------------------------------------------------------
@@ -96,7 +122,7 @@ struct BGLayout {
   size_t att_theta, att_phi, att_phi_p, att_g, att_g_p, att_P, att_ag, att_y;
   int att_H;
   // backward temporaries
-  size_t g_a, g_b, g_c;     // ping-pong gradient buffers (max activation size)
+  size_t g_a, g_b, g_c, g_d;  // gradient scratch buffers (max activation size)
   size_t arb_partial;
   size_t d_theta, d_phi_p, d_phi, d_g_p, d_g, d_ag;
   size_t skws; size_t skws_floats;
@@ -158,7 +184,7 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
     const size_t acts[] = {(size_t)B * H * H * g.cin, (size_t)B * Ho * Ho * mid,
                            (size_t)B * Ho * Ho * g.cout};
     for (size_t v : acts) if (v > max_act) max_act = v;
-    const int nblk = p2l_affine_relu_bwd_nblk(Ho * Ho);
+    const int nblk = cdiv(Ho * Ho, 128);   // fused epilogue: one partial per 128-pixel tile
     const size_t cmax = (size_t)(g.cin > mid ? g.cin : mid);
     const size_t pf = 2 * (size_t)B * nblk * cmax;
     if (pf > max_partial) max_partial = pf;
@@ -169,7 +195,7 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   }
   L.out_res = H;
   {
-    const int nblk = p2l_affine_relu_bwd_nblk(H * H);
+    const int nblk = cdiv(H * H, 128);
     const size_t pf = 2 * (size_t)B * nblk * m->ch;
     if (pf > max_partial) max_partial = pf;
     if ((size_t)B * H * H * m->ch > max_act) max_act = (size_t)B * H * H * m->ch;
@@ -177,6 +203,7 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   L.g_a = a.take(max_act);
   L.g_b = a.take(max_act);
   L.g_c = a.take(max_act);
+  L.g_d = a.take(max_act);
   L.arb_partial = a.take(max_partial);
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
@@ -358,21 +385,20 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
   float* ga = W + L.g_a;   // gradient w.r.t. the current layer's output
   float* gb = W + L.g_b;   // scratch
   float* gc = W + L.g_c;   // scratch
+  float* gd = W + L.g_d;   // scratch
 
   const int R = L.out_res;
   RET_IF(p2l_tanh_bwd16(img16, dimg16, (int64_t)B * R * R, st));
   {
-    // conv_to_rgb input-gradient, then the unconditional BN+ReLU backward.
+    // conv_to_rgb input-gradient fused with the unconditional BN+ReLU backward.
     ConvCall c = mk_conv(B, R, R, 16, m->ch, 9);
-    c.x = dimg16; c.w = m->rgb_wt; c.y = gb;
+    c.x = dimg16; c.w = m->rgb_wt;
     c.d.algo_flops = 2.0 * B * R * R * (double)m->ch * 3 * 9;
-    RET_IF(run_conv(c, skws, L.skws_floats, st));
     const float* xlast = W + L.blk[m->n_blocks - 1].y;
     // ds/dt of the tail BN feed nothing (no conditioning): park them in `draw`.
-    RET_IF(p2l_affine_relu_bwd(gb, m->ch, xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr,
-                               0, 0, 0, ga, m->ch, W + L.draw,
-                               W + L.draw + (size_t)B * m->ch, m->ch, part, B, R, R, m->ch,
-                               st));
+    ArbArgs a{xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr, 0, 0, 0, W + L.draw,
+              W + L.draw + (size_t)B * m->ch, m->ch};
+    RET_IF(run_dgrad_arb(c, a, ga, gd, part, skws, L.skws_floats, st));
   }
   for (int i = m->n_blocks - 1; i >= 0; --i) {
     const P2LGenBlock& g = m->blocks[i];
@@ -383,41 +409,33 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     else if (i == 0) xin = W + L.x0;
     else xin = W + L.blk[i - 1].y;
 
-    // conv_3 input-gradient: dy[cout] -> [mid]; then relu(cbn_3) backward
+    // ga = dy (kept for the shortcut), gb / gc alternate, gd = temp of the unfused path
+    // conv_3 input-gradient: dy[cout] -> [mid], + relu(cbn_3) backward
     ConvCall d3 = mk_conv(B, o.Ho, o.Ho, g.cout, mid, 1);
-    d3.x = ga; d3.w = g.wt[3]; d3.y = gb;
-    RET_IF(run_conv(d3, skws, L.skws_floats, st));
-    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h3, mid, W + L.s + g.cbn_off[3],
-                               W + L.t + g.cbn_off[3], CT, nullptr, 0, 0, 0, gc, mid,
-                               W + L.ds + g.cbn_off[3], W + L.dt + g.cbn_off[3], CT, part,
-                               B, o.Ho, o.Ho, mid, st));
+    d3.x = ga; d3.w = g.wt[3];
+    ArbArgs a3{W + o.h3, mid, W + L.s + g.cbn_off[3], W + L.t + g.cbn_off[3], CT, nullptr, 0,
+               0, 0, W + L.ds + g.cbn_off[3], W + L.dt + g.cbn_off[3], CT};
+    RET_IF(run_dgrad_arb(d3, a3, gb, gd, part, skws, L.skws_floats, st));
     // conv_2
     ConvCall d2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
-    d2.x = gc; d2.w = g.wt[2]; d2.y = gb;
-    RET_IF(run_conv(d2, skws, L.skws_floats, st));
-    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h2, mid, W + L.s + g.cbn_off[2],
-                               W + L.t + g.cbn_off[2], CT, nullptr, 0, 0, 0, gc, mid,
-                               W + L.ds + g.cbn_off[2], W + L.dt + g.cbn_off[2], CT, part,
-                               B, o.Ho, o.Ho, mid, st));
+    d2.x = gb; d2.w = g.wt[2];
+    ArbArgs a2{W + o.h2, mid, W + L.s + g.cbn_off[2], W + L.t + g.cbn_off[2], CT, nullptr, 0,
+               0, 0, W + L.ds + g.cbn_off[2], W + L.dt + g.cbn_off[2], CT};
+    RET_IF(run_dgrad_arb(d2, a2, gc, gd, part, skws, L.skws_floats, st));
     // conv_1 (+ nearest-x2 backward = 2x2 sum pool fused in the epilogue)
     ConvCall d1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     d1.x = gc; d1.w = g.wt[1];
-    if (g.up) { d1.d.pool = P2L_POOL_SUM; d1.yp = gb; d1.y = nullptr; }
-    else d1.y = gb;
-    RET_IF(run_conv(d1, skws, L.skws_floats, st));
-    RET_IF(p2l_affine_relu_bwd(gb, mid, W + o.h1, mid, W + L.s + g.cbn_off[1],
-                               W + L.t + g.cbn_off[1], CT, nullptr, 0, 0, 0, gc, mid,
-                               W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT, part,
-                               B, o.H, o.H, mid, st));
-    // conv_0, then relu(cbn_0) backward + shortcut gradient from dy (= ga)
+    if (g.up) d1.d.pool = P2L_POOL_SUM;
+    ArbArgs a1{W + o.h1, mid, W + L.s + g.cbn_off[1], W + L.t + g.cbn_off[1], CT, nullptr, 0,
+               0, 0, W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT};
+    RET_IF(run_dgrad_arb(d1, a1, gb, gd, part, skws, L.skws_floats, st));
+    // conv_0, + relu(cbn_0) backward + shortcut gradient from dy (= ga)
     ConvCall d0 = mk_conv(B, o.H, o.H, mid, g.cin, 1);
-    d0.x = gc; d0.w = g.wt[0]; d0.y = gb;
-    RET_IF(run_conv(d0, skws, L.skws_floats, st));
+    d0.x = gb; d0.w = g.wt[0];
     const int skipC = (g.cin != g.cout) ? g.cin / 2 : g.cin;
-    RET_IF(p2l_affine_relu_bwd(gb, g.cin, xin, g.cin, W + L.s + g.cbn_off[0],
-                               W + L.t + g.cbn_off[0], CT, ga, g.cout, skipC, g.up, gc,
-                               g.cin, W + L.ds + g.cbn_off[0], W + L.dt + g.cbn_off[0], CT,
-                               part, B, o.H, o.H, g.cin, st));
+    ArbArgs a0{xin, g.cin, W + L.s + g.cbn_off[0], W + L.t + g.cbn_off[0], CT, ga, g.cout,
+               skipC, g.up, W + L.ds + g.cbn_off[0], W + L.dt + g.cbn_off[0], CT};
+    RET_IF(run_dgrad_arb(d0, a0, gc, gd, part, skws, L.skws_floats, st));
     { float* tmp = ga; ga = gc; gc = tmp; }
 
     if (i == m->attn_before) {

@@ -178,3 +178,33 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
                                      N.i64(P), N.ptr(gscale), N.ptr(df), Bn, P, Cc, N.stream()),
             'lpips_tap_bwd')
     return df
+
+
+def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
+                   skip=None, skip_C=0, skip_ups=False):
+    """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
+    H, W = resolution of dy; Cin = channels of dy, Cout = channels of x."""
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
+    d.x_ld = Cin
+    d.alpha = 1.0
+    d.pool = N.POOL_SUM if pool_sum else N.POOL_NONE
+    d.y_ld = d.yp_ld = d.n_store = Cout
+    d.splitk = 1
+    assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1
+    nblk = _lib().p2l_conv_arb_nblk(C.byref(d))
+    part = torch.empty(2 * B * nblk * Cout, device=dy.device)
+    Ho, Wo = (H // 2, W // 2) if pool_sum else (H, W)
+    dx = torch.empty(B, Ho, Wo, Cout, device=dy.device)
+    ds = torch.empty(B, Cout, device=dy.device)
+    dt = torch.empty(B, Cout, device=dy.device)
+    a = N.P2LArb()
+    a.x, a.x_ld = x.data_ptr(), x.shape[-1]
+    a.s, a.t, a.st_bstride = s.data_ptr(), t.data_ptr(), st_bstride
+    if skip is not None:
+        a.skip, a.skip_ld, a.skip_C, a.skip_ups = skip.data_ptr(), skip.shape[-1], skip_C, int(skip_ups)
+    a.ds, a.dt, a.dsdt_bstride = ds.data_ptr(), dt.data_ptr(), Cout
+    a.partial = part.data_ptr()
+    N.check(_lib().p2l_conv_dgrad_arb(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
+                                      N.ptr(dx), N.stream()), 'conv_dgrad_arb')
+    return dx, ds, dt

@@ -129,6 +129,20 @@ def test_conv_fwd(dev, O, case):
         assert relerr(got, exp) < tol, 'pooled'
 
 
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c['taps'] == 9 and c['Cout'] % 64 == 0
+                                  and c['H'] >= 16 and not c.get('splitk')],
+                         ids=lambda c: '-'.join('%s%s' % (k, v) for k, v in c.items()) if isinstance(c, dict) else str(c))
+def test_conv_fwd_v2_variants(dev, O, case, variant):
+    """the persistent double-buffered 3x3 kernel (csrc/p2l_conv2.hip) on the same cases"""
+    from pix2latent_amd import _native as N
+    N.check(N.lib().p2l_set_conv_variant(variant))
+    try:
+        test_conv_fwd(dev, O, case)
+    finally:
+        N.check(N.lib().p2l_set_conv_variant(-1))
+
+
 @pytest.mark.parametrize('taps,Cin,Cout,H', [(9, 64, 128, 16), (1, 128, 64, 16), (9, 3, 64, 32), (9, 128, 3, 32)])
 def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
     """the transpose_flip packing turns the same kernel into the input-gradient."""
@@ -148,6 +162,44 @@ def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
     dx, _ = O.conv(nhwc(dyp, dev), wt, B, H, H, K_pad, N_pad, taps)
     torch.cuda.synchronize()
     assert relerr(nchw(dx)[:, :Cin], x.grad) < 2e-5
+
+
+@pytest.mark.parametrize('taps,ups,skip', [(9, False, None), (9, True, None), (1, False, 'same'),
+                                           (1, False, 'ups')])
+def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip):
+    """dgrad conv with the consumer's CBN+ReLU backward (and GenBlock shortcut gradient)
+    fused into its epilogue, vs autograd through relu(x*s+t) -> (nearest x2) -> conv."""
+    g = torch.Generator().manual_seed(12)
+    B, C, Co, H = 3, 64, 128, 16           # x: [B,C,H,H] ; y: [B,Co,Ho,Ho]
+    k = 3 if taps == 9 else 1
+    Ho = 2 * H if ups else H
+    x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    s = (0.5 + torch.rand(B, C, generator=g)).requires_grad_(True)
+    t = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(Co, C, k, k, generator=g) / math.sqrt(C * k * k)
+    dy = torch.randn(B, Co, Ho, Ho, generator=g)
+    a = F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1))
+    if ups:
+        a = F.interpolate(a, scale_factor=2, mode='nearest')
+    F.conv2d(a, w, None, padding=k // 2).backward(dy)
+    exp_dx = x.grad.clone()
+    sk_t, skip_C = None, 0
+    if skip == 'same':
+        sk = torch.randn(B, C, H, H, generator=g)
+        exp_dx = exp_dx + sk
+        sk_t, skip_C = nhwc(sk, dev), C
+    elif skip == 'ups':
+        sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
+        exp_dx[:, :C // 2] += F.avg_pool2d(sk, 2, 2) * 4
+        sk_t, skip_C = nhwc(sk, dev), C // 2
+    wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True)
+    dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, Ho, Ho, Co, C, taps, nhwc(x.detach(), dev),
+                                  s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups,
+                                  skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'))
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), exp_dx) < 2e-5
+    assert relerr(ds.cpu(), s.grad) < 5e-5
+    assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
 @pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, False), (True, True)])

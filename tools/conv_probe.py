@@ -1,0 +1,15 @@
+"""launch a few conv shapes several times (for rocprofv3 --pmc runs)"""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pix2latent_amd import ops, _native as N
+dev = torch.device('cuda'); B = 9
+SH = [(256, 64, 64, 9), (128, 128, 128, 9), (64, 256, 256, 9), (32, 512, 512, 9), (256, 64, 128, 1), (64, 256, 512, 1)]
+for H, Cin, Cout, taps in SH:
+    k = 3 if taps == 9 else 1
+    x = torch.randn(B, H, H, Cin, device=dev)
+    wp = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k), taps, Cout, Cin)
+    bias = torch.randn(Cout, device=dev)
+    for _ in range(4):
+        ops.conv(x, wp, B, H, H, Cin, Cout, taps, bias=bias)
+torch.cuda.synchronize()
