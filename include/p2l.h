@@ -60,6 +60,11 @@ typedef struct P2LConv {
   int32_t Cout;     /* multiple of 32                                         */
   int32_t taps;     /* 1 (1x1) or 9 (3x3, zero pad 1)                         */
   int32_t ups;      /* 1: x is [B,H/2,W/2,*]; nearest x2 applied on the fly   */
+                    /* 2: same conv in SUB-PIXEL form (4 phase 2x2 convs on   */
+                    /*    the low-res input, weights from                     */
+                    /*    p2l_pack_conv_weight_subpix; 2.25x fewer FLOPs)     */
+                    /* 3: input-gradient of such a conv: x is the high-res    */
+                    /*    dY [B,H,W,Cin], result is low-res [B,H/2,W/2,Cout]  */
   int32_t x_ld;     /* floats per input pixel (>= Cin)                        */
   /* prologue on the input operand (applied before zero padding):             */
   /*   AFFINE_RELU: a = max(x*s[b,c] + t[b,c], 0)   (CBN+ReLU, BN+ReLU)       */
@@ -129,6 +134,13 @@ int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
 int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps, int N_pad,
                          int K_pad, int transpose_flip, float* w_packed,
                          void* stream);
+
+/* Sub-pixel weight packing for 3x3 convs that read a nearest-x2 upsampled input
+ * (P2LConv.ups = 2 forward, 3 input-gradient with transpose_flip=1):
+ * [16 slabs = phase*4 + tap][K_pad/16][N_pad][16]. */
+int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
+                                int K_pad, int transpose_flip, float* w_packed,
+                                void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Batched GEMM fp32 (attention bmm's and their gradients).                  */
@@ -297,6 +309,8 @@ typedef struct P2LGenBlock {
   const float* w[4];              /* packed forward weights conv_0..conv_3   */
   const float* b[4];              /* biases                                  */
   const float* wt[4];             /* packed input-gradient weights           */
+  const float* w1_sp;             /* up blocks: conv_1 in sub-pixel form (or NULL) */
+  const float* wt1_sp;            /* and its input-gradient form (or NULL)   */
 } P2LGenBlock;
 
 typedef struct P2LBigGAN {

@@ -46,7 +46,8 @@ P2L_MAX_BLOCKS = 16
 class P2LGenBlock(C.Structure):
     _fields_ = [('cin', C.c_int32), ('cout', C.c_int32), ('up', C.c_int32),
                 ('cbn_off', C.c_int32 * 4),
-                ('w', C.c_void_p * 4), ('b', C.c_void_p * 4), ('wt', C.c_void_p * 4)]
+                ('w', C.c_void_p * 4), ('b', C.c_void_p * 4), ('wt', C.c_void_p * 4),
+                ('w1_sp', C.c_void_p), ('wt1_sp', C.c_void_p)]
 
 
 class P2LBigGAN(C.Structure):
@@ -79,7 +80,7 @@ PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd',
-    'p2l_pack_conv_weight', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
+    'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',

@@ -84,7 +84,8 @@ __device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
 template <int NT>
 __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)[NT],
                                              float* smem, int wave, int lane, int b0, int y0,
-                                             int x0, int n0, int tile_in_image) {
+                                             int x0, int n0, int tile_in_image, int osh,
+                                             int ph_y, int ph_x) {
   constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
   const int l31 = lane & 31, lhi = lane >> 5;
   float* tb = smem + wave * 32 * EP;
@@ -109,8 +110,11 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
     const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
     if (b >= k.B || n >= k.n_store) continue;
     const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
-    const unsigned pix0 = (unsigned)((b * k.H + oy0) * k.W + ox0);
-    const unsigned sub[4] = {0u, 1u, (unsigned)k.W, (unsigned)k.W + 1u};
+    // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of [B,2H,2W,*]
+    const unsigned OW = (unsigned)k.W << osh;
+    const unsigned pix0 = ((unsigned)(b * k.H + oy0) << osh) * OW + ((unsigned)ph_y * OW) +
+                          ((unsigned)ox0 << osh) + (unsigned)ph_x;
+    const unsigned sub[4] = {0u, 1u << osh, OW << osh, (OW << osh) + (1u << osh)};
     f32x4 v[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
 
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int HW_ = TW + 2, HH_ = TH + 2;
-  const int a_rows = (TAPS == 9) ? TB * HH_ * HW_ : 128;
+  const int a_rows = (TAPS != 1) ? TB * HH_ * HW_ : 128;
   float* As = smem;
   float* Bs = smem + a_rows * PITCH;
 
@@ -243,7 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   const int n0 = nt * BN;
   const int y0 = ty << k.th_log, x0 = tx << k.tw_log, b0 = bt << k.tb_log;
 
-  const int z = blockIdx.y;
+  // blockIdx.y: split-K slice, or (sub-pixel forward) the output phase
+  const bool sp_fwd = (TAPS == 4) && k.sp_mode == 1;
+  const bool sp_bwd = (TAPS == 4) && k.sp_mode == 2;
+  const int z = sp_fwd ? 0 : blockIdx.y;
+  const int ph_y = sp_fwd ? (int)(blockIdx.y >> 1) : 0, ph_x = sp_fwd ? (int)(blockIdx.y & 1) : 0;
   const int c_begin = z * k.chunks_per_split;
   const int c_end = min(k.nchunks, c_begin + k.chunks_per_split);
 
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     a_loff[it] = (p < a_rows) ? p * PITCH + v * 4 : -1;
     if (p < a_rows) {
       int tb, iy, ix;
-      if (TAPS == 9) {
+      if (TAPS != 1) {
         tb = p / (HH_ * HW_);
         const int rem = p - tb * (HH_ * HW_);
         const int hy = rem / HW_, hx = rem - hy * HW_;
@@ -283,6 +291,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         int pix;
         if (UPS)
           pix = (b * (k.H >> 1) + (iy >> 1)) * (k.W >> 1) + (ix >> 1);
+        else if (sp_bwd)      // phase plane (0,0) of the [B,2H,2W,*] gradient
+          pix = (b * 2 * k.H + 2 * iy) * 2 * k.W + 2 * ix;
         else
           pix = (b * k.H + iy) * k.W + ix;
         a_goff[it] = pix * k.x_ld + v * 4;
@@ -294,13 +304,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
 
   f32x4 xr[A_ITERS], sr[A_ITERS], tr[A_ITERS], wr[B_ITERS];
 
+  // sub-pixel input-gradient: chunk c = (phase plane cls, channel chunk cc)
   auto load_regs = [&](int c) {
+    int cc = c, wslab = 0, a_extra = 0;
+    if (TAPS == 4) {
+      if (sp_bwd) {
+        const int cls = c / k.sp_ncc;
+        cc = c - cls * k.sp_ncc;
+        wslab = cls * 4;
+        a_extra = ((cls >> 1) * 2 * k.W + (cls & 1)) * k.x_ld;
+      } else {
+        wslab = (ph_y * 2 + ph_x) * 4;
+      }
+    }
+    const int ncc = (TAPS == 4 && sp_bwd) ? k.sp_ncc : k.nchunks;
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + c * KC);
+      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)(a_goff[it] + a_extra) + cc * KC);
       if (PRO != P2L_PRO_NONE) {
-        sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + a_soff[it] + c * KC);
-        tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + a_soff[it] + c * KC);
+        sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + a_soff[it] + cc * KC);
+        tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + a_soff[it] + cc * KC);
       }
     }
 #pragma unroll
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         const int tap = j / (BN * VPR);
         const int rem = j - tap * (BN * VPR);  // row*VPR + v
         const size_t off =
-            (((size_t)tap * k.nchunks + c) * k.Cout + n0) * KC + rem * 4;
+            (((size_t)(wslab + tap) * ncc + cc) * k.Cout + n0) * KC + rem * 4;
         wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
       }
     }
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   int a_row0;
   {
     const int i = wave * 32 + l31;
-    if (TAPS == 9) {
+    if (TAPS != 1) {
       const int Q = i >> 2, s = i & 3;
       const int qx = Q & ((TW >> 1) - 1);
       const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
@@ -377,10 +400,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     const bool more = (c + 1 < c_end);
     if (more) load_regs(c + 1);
 
+    // window origin inside the halo: 3x3 -> (0,0); sub-pixel forward -> the output
+    // phase; sub-pixel input-gradient -> (1 - plane parity)
+    int win0 = 0;
+    if (TAPS == 4) {
+      int oy = ph_y, ox = ph_x;
+      if (sp_bwd) {
+        const int cls = c / k.sp_ncc;
+        oy = 1 - (cls >> 1);
+        ox = 1 - (cls & 1);
+      }
+      win0 = (oy * HW_ + ox) * PITCH;
+    }
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const float* ap = a_frag + ((TAPS == 9) ? (dy * HW_ + dx) * PITCH : 0);
+      const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
+      const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
+      const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
 #pragma unroll
       for (int kk = 0; kk < KC / 8; ++kk) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
@@ -431,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     }
   } else {
     epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0,
-                     mt & ((1 << (k.tiles_x_log + k.tiles_y_log)) - 1));
+                     mt & ((1 << (k.tiles_x_log + k.tiles_y_log)) - 1), sp_fwd ? 1 : 0, ph_y,
+                     ph_x);
   }
 }
 
@@ -486,18 +523,64 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
   dst[idx] = v;
 }
 
+// The GEMM M grid: output pixels, except in the sub-pixel modes (ups 2 / 3) where it is
+// the LOW-RES pixel grid (d->H, d->W are always the high-res dims there).
+// Sub-pixel weights of a 3x3 conv applied to a nearest-x2 upsampled input.
+// Forward (flip=0): slab = phase(py,px)*4 + tap(i,j); value = sum of the original taps
+//   dy in S(py,i), dx in S(px,j) with S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}.
+// Input-gradient (flip=1): slab = plane(pu,pv)*4 + tap(i,j); the plane row offset is
+//   u = 2i - pu (pu=1: -1,+1 ; pu=0: 0,+2) with D(2)={0} D(0)={1,2} D(1)={0,1} D(-1)={2},
+//   channels swapped.  dst layout [16][K_pad/16][N_pad][16].
+__device__ __forceinline__ unsigned sp_tapset(int flip, int p, int i) {
+  // returns a 3-bit mask of the original taps (bit dy) that are summed
+  if (!flip) {
+    if (p == 0) return i == 0 ? 1u : 6u;
+    return i == 0 ? 3u : 4u;
+  }
+  const int u = 2 * i - p;      // p = plane parity
+  return u == 2 ? 1u : u == 0 ? 6u : u == 1 ? 3u : 4u;
+}
+__global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int O, int I,
+                                                          int N_pad, int K_pad, int flip) {
+  const size_t per = (size_t)K_pad * N_pad;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 16 * per) return;
+  const int slab = (int)(idx / per);
+  size_t r = idx - (size_t)slab * per;
+  const int kk = (int)(r % 16);
+  r /= 16;
+  const int n = (int)(r % N_pad);
+  const int q = (int)(r / N_pad);
+  const int c = q * 16 + kk;
+  const int ph = slab >> 2, tap = slab & 3;
+  const unsigned my = sp_tapset(flip, ph >> 1, tap >> 1), mx = sp_tapset(flip, ph & 1, tap & 1);
+  float v = 0.f;
+  const bool ok = flip ? (n < I && c < O) : (n < O && c < I);
+  if (ok) {
+    for (int dy = 0; dy < 3; ++dy)
+      for (int dx = 0; dx < 3; ++dx)
+        if (((my >> dy) & 1u) && ((mx >> dx) & 1u))
+          v += flip ? src[((size_t)c * I + n) * 9 + dy * 3 + dx]
+                    : src[((size_t)n * I + c) * 9 + dy * 3 + dx];
+  }
+  dst[idx] = v;
+}
+
 int choose_tile(const P2LConv* d, ConvK& k) {
-  if (!is_pow2(d->H) || !is_pow2(d->W) || d->H < 4 || d->W < 4) return P2L_EINVAL;
-  int TW = d->W < 16 ? d->W : 16;
+  const int sh = (d->ups >= 2) ? 1 : 0;
+  const int H = d->H >> sh, W = d->W >> sh;
+  if (!is_pow2(d->H) || !is_pow2(d->W) || H < 4 || W < 4) return P2L_EINVAL;
+  int TW = W < 16 ? W : 16;
   int TH = 128 / TW;
-  if (TH > d->H) TH = d->H;
+  if (TH > H) TH = H;
   int TB = 128 / (TW * TH);
   k.tw_log = ilog2(TW);
   k.th_log = ilog2(TH);
   k.tb_log = ilog2(TB);
-  k.tiles_x_log = ilog2(d->W / TW);
-  k.tiles_y_log = ilog2(d->H / TH);
-  k.n_mtiles = (d->W / TW) * (d->H / TH) * cdiv(d->B, TB);
+  k.tiles_x_log = ilog2(W / TW);
+  k.tiles_y_log = ilog2(H / TH);
+  k.n_mtiles = (W / TW) * (H / TH) * cdiv(d->B, TB);
   return P2L_OK;
 }
 
@@ -506,7 +589,8 @@ int choose_tile(const P2LConv* d, ConvK& k) {
 // share a CU's matrix pipes, so time ~ ceil(blocks / 256 CUs) * work-per-block.
 int choose_bn(const P2LConv* d, int n_mtiles) {
   if (d->Cout % 64) return 32;
-  const int n64 = n_mtiles * (d->Cout / 64), n32 = n_mtiles * (d->Cout / 32);
+  const int ph = (d->ups == 2) ? 4 : 1;      // sub-pixel forward: 4 phases per tile
+  const int n64 = n_mtiles * (d->Cout / 64) * ph, n32 = n_mtiles * (d->Cout / 32) * ph;
   if (n64 < 256) return 64;               // split-K regime: keep the fatter tile
   const double t64 = (double)cdiv(n64, 256) * 64.0;
   const double t32 = (double)cdiv(n32, 256) * 32.0 * 1.06;   // thinner tile: less reuse
@@ -545,6 +629,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
+  if (d->ups >= 2) return 1;             // sub-pixel modes never split K
   if (choose_tile(d, k) != P2L_OK) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : 32;
@@ -579,6 +664,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x,
   if (d->pool != P2L_POOL_NONE && !yp) return P2L_EINVAL;
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
+  if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
   if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
   if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
       (mask && d->mask_ld % 4))
@@ -633,6 +719,47 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x,
         : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
     (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
+  }
+  // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
+  if (d->ups >= 2) {
+    if (d->taps != 9 || k.tb_log != 0 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
+        (d->ups == 2 && (res || mask)))
+      return P2L_EUNSUP;
+    k.H = d->H >> 1; k.W = d->W >> 1;        // the kernel tiles the low-res grid
+    k.sp_mode = d->ups - 1;
+    k.sp_ncc = d->Cin / 16;
+    k.nchunks = (d->ups == 3) ? 4 * k.sp_ncc : k.sp_ncc;
+    k.chunks_per_split = k.nchunks;
+    k.ups = 0;
+    const int a_rows_sp = ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
+    size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * 20 * sizeof(float);
+    const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
+    if (lds_epi > lds_sp) lds_sp = lds_epi;
+    dim3 grid(k.n_mtiles * k.n_ntiles, d->ups == 2 ? 4 : 1), block(256);
+#define P2L_LAUNCH_SP(BNV, PROV)                                                          \
+    do {                                                                                  \
+      auto kfn = conv_mfma_kernel<4, BNV, 16, 3, PROV, false>;                            \
+      static bool attr_set = false;                                                       \
+      if (!attr_set) {                                                                    \
+        (void)hipFuncSetAttribute((const void*)kfn,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr_set = true;                                                                  \
+      }                                                                                   \
+      hipLaunchKernelGGL(kfn, grid, block, lds_sp, st, k);                                \
+    } while (0)
+    if (bn == 64) {
+      if (d->pro == P2L_PRO_NONE) P2L_LAUNCH_SP(64, P2L_PRO_NONE);
+      else if (d->pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH_SP(64, P2L_PRO_AFFINE_RELU);
+      else P2L_LAUNCH_SP(64, P2L_PRO_AFFINE);
+    } else {
+      if (d->pro == P2L_PRO_NONE) P2L_LAUNCH_SP(32, P2L_PRO_NONE);
+      else if (d->pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH_SP(32, P2L_PRO_AFFINE_RELU);
+      else P2L_LAUNCH_SP(32, P2L_PRO_AFFINE);
+    }
+#undef P2L_LAUNCH_SP
+    rc = p2l_check_launch();
+    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    return rc;
   }
   // ---- optional v2 kernel (see p2l_conv2.hip; measured equal-or-slower than v1, so
   //      only used when selected through p2l_set_conv_variant) ----------------------
@@ -708,6 +835,7 @@ extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const flo
   if (!d || !arb || !dx) return P2L_EINVAL;
   P2LConv dd = *d;
   dd.splitk = 1;
+  if (dd.ups == 3) dd.pool = P2L_POOL_NONE;
   const bool pooled = dd.pool == P2L_POOL_SUM;
   int rc = conv_launch_impl(&dd, arb, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
                             pooled ? nullptr : dx, pooled ? dx : nullptr, nullptr, 0, stream);
@@ -715,6 +843,18 @@ extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const flo
   const int nblk = p2l_conv_arb_nblk(&dd);
   return p2l_arb_finish(arb->partial, arb->ds, arb->dt, dd.B, nblk, dd.Cout,
                         arb->dsdt_bstride, stream);
+}
+
+extern "C" int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
+                                           int K_pad, int transpose_flip, float* w_packed,
+                                           void* stream) {
+  if (!w_oihw || !w_packed) return P2L_EINVAL;
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  if (K_pad % 16 || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
+  const size_t total = (size_t)16 * K_pad * N_pad;
+  hipLaunchKernelGGL(pack_subpix_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, w_packed, O, I, N_pad, K_pad, transpose_flip);
+  return p2l_check_launch();
 }
 
 extern "C" int p2l_set_conv_variant(int variant) {

@@ -29,6 +29,10 @@ struct ConvK {
   const float* arb_x; const float* arb_s; const float* arb_t; const float* arb_skip;
   float* arb_partial;
   int arb_x_ld, arb_bstride, arb_skip_ld, arb_skip_C, arb_skip_ups, arb_nblk;
+  // sub-pixel mode of the TAPS=4 kernel (nearest-x2 upsample folded into the weights):
+  //   1 = forward: low-res input, 4 output phases (blockIdx.y), output stride 2
+  //   2 = input-gradient: the 4 phase planes of the high-res dY are 4 K-slices
+  int sp_mode, sp_ncc;   // sp_ncc = channel chunks per phase plane (mode 2)
   int abl;  // ablation bits (diagnostics only, P2L_ABL env): see p2l_conv2.hip
 };
 

@@ -204,20 +204,34 @@ __global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
   }
 }
 
-__global__ void arb_finish_kernel(const float* partial, float* ds, float* dt,
-                                  int Bn, int nblk, int C, int out_bstride) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Bn * C) return;
-  const int b = i / C, c = i - b * C;
-  float a = 0.f, t = 0.f;
+// second stage of the per-(sample, channel) sums: partial[2][B][nblk][C] -> ds, dt.
+// grid (C/64, B); 16 segments x 16 channel-float4 lanes per block, each thread adds its
+// segment's tiles in order, then the 16 segments are combined in a fixed order.
+__global__ __launch_bounds__(256) void arb_finish_kernel(const float* partial, float* ds,
+                                                         float* dt, int Bn, int nblk, int C,
+                                                         int out_bstride) {
+  __shared__ f32x4 red_s[256], red_t[256];
+  const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
+  const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
   const size_t half = (size_t)Bn * nblk * C;
-  for (int j = 0; j < nblk; ++j) {
+  f32x4 a = {0, 0, 0, 0}, t = {0, 0, 0, 0};
+  for (int j = seg; j < nblk; j += 16) {
     const size_t o = ((size_t)b * nblk + j) * C + c;
-    a += partial[o];
-    t += partial[half + o];
+    a += *reinterpret_cast<const f32x4*>(partial + o);
+    t += *reinterpret_cast<const f32x4*>(partial + half + o);
   }
-  ds[(size_t)b * out_bstride + c] = a;
-  dt[(size_t)b * out_bstride + c] = t;
+  red_s[tid] = a;
+  red_t[tid] = t;
+  __syncthreads();
+  if (seg == 0) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      a += red_s[j * 16 + cl];
+      t += red_t[j * 16 + cl];
+    }
+    *reinterpret_cast<f32x4*>(ds + (size_t)b * out_bstride + c) = a;
+    *reinterpret_cast<f32x4*>(dt + (size_t)b * out_bstride + c) = t;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -727,14 +741,15 @@ extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
   k.nblk = cdiv(k.P, ARB_SLAB);
   hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0,
                      ST(stream), k);
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0,
                      ST(stream), partial, ds, dt, Bn, k.nblk, C, dsdt_bstride);
   return p2l_check_launch();
 }
 
 extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk,
                               int C, int out_bstride, void* stream) {
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0, ST(stream),
+  if (C % 64 || out_bstride % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0, ST(stream),
                      partial, ds, dt, Bn, nblk, C, out_bstride);
   return p2l_check_launch();
 }

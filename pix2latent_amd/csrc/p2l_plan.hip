@@ -92,7 +92,8 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
                   float* skws, size_t skws_floats, void* st) {
   c.d.splitk = p2l_conv_suggest_splitk(&c.d);
   const bool pooled = c.d.pool == P2L_POOL_SUM;
-  const int Ho = pooled ? c.d.H / 2 : c.d.H, Wo = pooled ? c.d.W / 2 : c.d.W;
+  const bool half = pooled || c.d.ups == 3;          // result lives at half resolution
+  const int Ho = half ? c.d.H / 2 : c.d.H, Wo = half ? c.d.W / 2 : c.d.W;
   if (c.d.splitk == 1 && p2l_conv_arb_fusable(&c.d)) {
     P2LArb arb{};
     arb.x = a.x; arb.x_ld = a.x_ld; arb.s = a.s; arb.t = a.t; arb.st_bstride = a.st_bstride;
@@ -342,6 +343,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
     ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     c1.x = W + o.h1; c1.w = g.w[1]; c1.bias = g.b[1]; c1.y = W + o.h2; c1.d.ups = g.up;
+    if (g.up && g.w1_sp && o.H >= 16) { c1.d.ups = 2; c1.w = g.w1_sp; }   // sub-pixel form
     c1.d.pro = P2L_PRO_AFFINE_RELU; c1.d.pro_bstride = CT;
     c1.ps = W + L.s + g.cbn_off[1]; c1.pt = W + L.t + g.cbn_off[1];
     RET_IF(run_conv(c1, skws, L.skws_floats, st));
@@ -425,7 +427,8 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     // conv_1 (+ nearest-x2 backward = 2x2 sum pool fused in the epilogue)
     ConvCall d1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     d1.x = gc; d1.w = g.wt[1];
-    if (g.up) d1.d.pool = P2L_POOL_SUM;
+    if (g.up && g.wt1_sp && o.H >= 32) { d1.d.ups = 3; d1.w = g.wt1_sp; }   // sub-pixel form
+    else if (g.up) d1.d.pool = P2L_POOL_SUM;
     ArbArgs a1{W + o.h1, mid, W + L.s + g.cbn_off[1], W + L.t + g.cbn_off[1], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT};
     RET_IF(run_dgrad_arb(d1, a1, gb, gd, part, skws, L.skws_floats, st));

@@ -140,6 +140,17 @@ class BigGAN(nn.Module):
         self._keep.append(dst)
         return dst
 
+    def _pack_subpix(self, w, n_pad, k_pad, flip):
+        O, I = w.shape[0], w.shape[1]
+        src = w.detach().to(self._dev, torch.float32).contiguous()
+        dst = torch.empty(16 * n_pad * k_pad, device=self._dev, dtype=torch.float32)
+        N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+                                                      N.ptr(dst), N.stream()),
+                'p2l_pack_conv_weight_subpix')
+        torch.cuda.current_stream().synchronize()
+        self._keep.append(dst)
+        return dst
+
     def _pack(self, W):
         d = self._desc
         table = synthetic.layer_table()
@@ -176,6 +187,11 @@ class BigGAN(nn.Module):
                 g.w[k] = self._pack_conv(w, taps, o, i_, False).data_ptr()
                 g.wt[k] = self._pack_conv(w, taps, i_, o, True).data_ptr()
                 g.b[k] = self._dev_t(W['%s.conv_%d.bias' % (p, k)]).data_ptr()
+            if up:
+                # conv_1 reads a nearest-x2 upsampled input: sub-pixel forms (2.25x fewer FLOPs)
+                w1 = W['%s.conv_1.weight' % p]
+                g.w1_sp = self._pack_subpix(w1, mid, mid, False).data_ptr()
+                g.wt1_sp = self._pack_subpix(w1, mid, mid, True).data_ptr()
         d.cbn_total = off
         d.cbn_w = self._dev_t(torch.cat(scale_cols + offset_cols, dim=1)).data_ptr()
         # attention

@@ -31,6 +31,15 @@ def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False):
     return dst
 
 
+def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False):
+    O, I = w_oihw.shape[0], w_oihw.shape[1]
+    src = w_oihw.contiguous().float()
+    dst = torch.empty(16 * n_pad * k_pad, device=src.device)
+    N.check(_lib().p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+                                               N.ptr(dst), N.stream()), 'pack_subpix')
+    return dst
+
+
 def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
@@ -50,7 +59,10 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
     d.splitk = splitk if splitk is not None else _lib().p2l_conv_suggest_splitk(C.byref(d))
     wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
     ws = torch.empty(max(wsb // 4, 1), device=x.device)
-    y = torch.empty(B, H, W, d.y_ld, device=x.device) if want_y else None
+    if d.ups == 3:      # sub-pixel input-gradient: result at half resolution
+        y = torch.empty(B, H // 2, W // 2, d.y_ld, device=x.device)
+    else:
+        y = torch.empty(B, H, W, d.y_ld, device=x.device) if want_y else None
     yp = torch.empty(B, H // 2, W // 2, d.yp_ld, device=x.device) if pool else None
     N.check(_lib().p2l_conv_fwd(C.byref(d), N.ptr(x), N.ptr(w_packed), N.ptr(bias),
                                 N.ptr(pro_s), N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y),
@@ -181,20 +193,21 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
 
 
 def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
-                   skip=None, skip_C=0, skip_ups=False):
+                   skip=None, skip_C=0, skip_ups=False, subpix=False):
     """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
     H, W = resolution of dy; Cin = channels of dy, Cout = channels of x."""
     d = N.P2LConv()
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.x_ld = Cin
     d.alpha = 1.0
-    d.pool = N.POOL_SUM if pool_sum else N.POOL_NONE
+    d.pool = N.POOL_SUM if (pool_sum and not subpix) else N.POOL_NONE
+    d.ups = 3 if subpix else 0
     d.y_ld = d.yp_ld = d.n_store = Cout
     d.splitk = 1
     assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1
     nblk = _lib().p2l_conv_arb_nblk(C.byref(d))
     part = torch.empty(2 * B * nblk * Cout, device=dy.device)
-    Ho, Wo = (H // 2, W // 2) if pool_sum else (H, W)
+    Ho, Wo = (H // 2, W // 2) if (pool_sum or subpix) else (H, W)
     dx = torch.empty(B, Ho, Wo, Cout, device=dy.device)
     ds = torch.empty(B, Cout, device=dy.device)
     dt = torch.empty(B, Cout, device=dy.device)

@@ -129,6 +129,52 @@ def test_conv_fwd(dev, O, case):
         assert relerr(got, exp) < tol, 'pooled'
 
 
+@pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 96)])
+def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout):
+    """3x3 conv on a nearest-x2 upsampled input in sub-pixel form (ups=2) and its
+    input-gradient (ups=3) against F.interpolate + F.conv2d and autograd."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(13)
+    B, h = 2, 16
+    x = torch.randn(B, Cin, h, h, generator=g)
+    s = 0.5 + torch.rand(B, Cin, generator=g)
+    t = torch.randn(B, Cin, generator=g) * 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    a = F.relu(x * s.view(B, Cin, 1, 1) + t.view(B, Cin, 1, 1)).requires_grad_(True)
+    y_ref = F.conv2d(F.interpolate(a, scale_factor=2, mode='nearest'), w, bias, padding=1)
+    dy = torch.randn(B, Cout, 2 * h, 2 * h, generator=g)
+    y_ref.backward(dy)
+    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin)
+    y, _ = O.conv(nhwc(x, dev), wsp, B, 2 * h, 2 * h, Cin, Cout, 9, bias=bias.to(dev),
+                  pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin, ups=2)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), y_ref.detach()) < 2e-5
+    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True)
+    da, _ = O.conv(nhwc(dy, dev), wtsp, B, 2 * h, 2 * h, Cout, Cin, 9, ups=3)
+    torch.cuda.synchronize()
+    assert relerr(nchw(da), a.grad) < 2e-5
+
+
+def test_conv_subpixel_dgrad_fused_arb(dev, O):
+    g = torch.Generator().manual_seed(14)
+    B, C, Co, h = 2, 64, 64, 16
+    x = torch.randn(B, C, h, h, generator=g, requires_grad=True)
+    s = (0.5 + torch.rand(B, C, generator=g)).requires_grad_(True)
+    t = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    dy = torch.randn(B, Co, 2 * h, 2 * h, generator=g)
+    a = F.interpolate(F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1)), scale_factor=2, mode='nearest')
+    F.conv2d(a, w, None, padding=1).backward(dy)
+    wt = O.pack_conv_weight_subpix(w.to(dev), C, Co, flip=True)
+    dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, 2 * h, 2 * h, Co, C, 9, nhwc(x.detach(), dev),
+                                  s.detach().to(dev), t.detach().to(dev), C, subpix=True)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), x.grad) < 2e-5
+    assert relerr(ds.cpu(), s.grad) < 5e-5
+    assert relerr(dt.cpu(), t.grad) < 5e-5
+
+
 @pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c['taps'] == 9 and c['Cout'] % 64 == 0
                                   and c['H'] >= 16 and not c.get('splitk')],
