@@ -34,7 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 GFLOP_PER_EVAL = 197.8              # BASELINE.md §2 (conv_to_rgb sliced to 3 channels)
 
 
-def build_problem(dev, seed=0):
+def build_problem(dev, seed=0, exec_batch_size=None):
     from pix2latent_amd import VariableManager, distribution
     from pix2latent_amd.utils import synthetic as S, function_hooks as hook
     from pix2latent_amd.model.biggan import BigGAN
@@ -56,7 +56,8 @@ def build_problem(dev, seed=0):
     vm.register('c', (128,), 'input', default=c_default, learning_rate=0.01)
     vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=target)
     vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
-    opt = BasinCMAOptimizer(model, vm, loss_fn, max_batch_size=MAX_BATCH)
+    opt = BasinCMAOptimizer(model, vm, loss_fn, max_batch_size=MAX_BATCH,
+                            exec_batch_size=exec_batch_size)
     opt.cma_seed = seed
     return opt, vm, (W, Wv, c_default, target, weight)
 
@@ -122,6 +123,10 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--exec-batch', type=int, default=POP,
+                    help='candidates pushed through the device per pass (semantic chunk '
+                         'size stays max_batch_size=9); 9 = execute chunk by chunk like '
+                         'the reference')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -139,7 +144,7 @@ def main():
 
     from pix2latent_amd import _native as N
     torch.manual_seed(0)
-    opt, vm, problem = build_problem(dev)
+    opt, vm, problem = build_problem(dev, exec_batch_size=args.exec_batch)
     opt.setup_cma(vm)
     assert opt.num_samples == POP
     variables = opt.cma_init(vm)
@@ -195,6 +200,7 @@ def main():
                             'bwd to (z,c) -> Adam; 256x256 synthetic target',
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
+                'exec_batch_size': args.exec_batch,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'gflop_per_eval_basis': GFLOP_PER_EVAL,
                 'end_to_end_tflops': round(GFLOP_PER_EVAL * evals / elapsed / 1e3, 2),

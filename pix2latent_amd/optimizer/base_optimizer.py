@@ -23,7 +23,7 @@ class _BaseOptimizer():
     """ Base template for gradient optimization """
 
     def __init__(self, model, var_manager, loss_fn, max_batch_size=9,
-                 log=False, track_variables=True, **kwargs):
+                 log=False, track_variables=True, exec_batch_size=None, **kwargs):
         """
         Args
             model (nn.Module): a model to invert
@@ -31,8 +31,16 @@ class _BaseOptimizer():
             loss_fn (callable): loss function to compute gradients with
             max_batch_size (int): maximum batch size; larger populations are
                 processed in chunks of this size
+            exec_batch_size (int): (extension) how many candidates are pushed
+                through the device at once.  The reference chunks by
+                `max_batch_size` only because of GPU memory; with 288 GB of HBM the
+                whole population fits, so the chunk size that DEFINES the
+                semantics (gradient factor 1/b_chunk, reference closure.py:58) is
+                kept while the execution batch may be larger.  None = the
+                reference behaviour (execute chunk by chunk).
         """
         self.max_batch_size = max_batch_size
+        self.exec_batch_size = exec_batch_size
         self.model = model.eval() if hasattr(model, 'eval') else model
         self.var_manager = var_manager
         self.loss_fn = loss_fn
@@ -110,12 +118,21 @@ class _BaseOptimizer():
             self.track(variables)
 
         if not self.shard.enabled:
-            self.out, self.loss, self.other = step(
-                self.model, variables,
-                loss_fn=self.loss_fn,
-                optimize=optimize,
-                max_batch_size=self.max_batch_size
-            )
+            ebs = self.exec_batch_size
+            if ebs is not None and ebs > self.max_batch_size and \
+                    variables.num_samples > self.max_batch_size:
+                n = variables.num_samples
+                first = next(iter(variables.input.values())).data[0]
+                self.out, self.loss, self.other = step(
+                    self.model, variables, loss_fn=self.loss_fn, optimize=optimize,
+                    max_batch_size=ebs, grad_scale=self._grad_scale(n, 0, n, first.device))
+            else:
+                self.out, self.loss, self.other = step(
+                    self.model, variables,
+                    loss_fn=self.loss_fn,
+                    optimize=optimize,
+                    max_batch_size=self.max_batch_size
+                )
             return self.out, self.loss, self.other
 
         n = variables.num_samples

@@ -175,6 +175,21 @@ def test_gradient_optimizer_trajectory_golden():
     assert [c[0] for c in model2.calls[-3:]] == [int(c[0]) for c in g['rescore_model_calls']]
 
 
+def test_exec_batch_size_keeps_reference_trajectory():
+    """executing the whole population in one pass (exec_batch_size) with the
+    reference chunk's gradient scale reproduces the chunked golden trajectory."""
+    from pix2latent_amd.optimizer import GradientOptimizer
+    g = gold('gradient_optimizer')
+    model = ToyGenerator()
+    torch.manual_seed(42)
+    opt = GradientOptimizer(model, make_vm(), toy_loss, max_batch_size=2, exec_batch_size=5)
+    variables, outs, losses = opt.optimize(num_samples=5, grad_steps=3)
+    assert [c[0] for c in model.calls] == [5, 5, 5]
+    assert np.allclose(np.array(losses[-1][1]['loss']), g['final_loss'], atol=1e-6)
+    assert np.allclose(torch.stack(list(variables.input.z.data)).detach().numpy(), g['final_z'], atol=1e-6)
+    assert np.allclose(torch.stack(list(variables.input.c.data)).detach().numpy(), g['final_c'], atol=1e-6)
+
+
 def _patch_cma(monkeypatch):
     import pix2latent_amd.optimizer.base_cma_optimizer as B
     FakeCMAES.log = []

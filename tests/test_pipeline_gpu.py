@@ -126,3 +126,23 @@ def test_basincma_generation_on_biggan(dev):
     assert l1.mean() < l0.mean()
     assert np.array_equal(l1, l2), 're-score must be bit-reproducible'
     opt.cma_update(variables, loss=l1)
+
+
+def test_exec_batch_matches_chunked_on_biggan(dev):
+    """whole population in one device pass (exec_batch_size=18) vs the reference's
+    chunks of 9: same losses / latents up to fp32 summation order."""
+    import bench
+    res = []
+    for ebs in (None, 18):
+        torch.manual_seed(0)
+        opt, vm, _ = bench.build_problem(dev, exec_batch_size=ebs)
+        opt.setup_cma(vm)
+        variables = opt.cma_init(vm)
+        for j in range(3):
+            _, l, _ = opt.step(variables, optimize=True, transform=(j == 0))
+        res.append((np.array(l, dtype=np.float64), variables.input.z.buf.cpu().numpy().copy()))
+    (l9, z9), (l18, z18) = res
+    assert np.abs(l9 - l18).max() < 2e-4, np.abs(l9 - l18).max()
+    assert np.array_equal(np.argsort(l9), np.argsort(l18))
+    dz = np.abs(z9 - z18)
+    assert np.median(dz) < 1e-4 and np.mean(dz < 0.02) > 0.97
