@@ -123,6 +123,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) or "
+                    "'gloo' (test only: lets several ranks share one GPU)")
     ap.add_argument('--exec-batch', type=int, default=POP,
                     help='candidates pushed through the device per pass (semantic chunk '
                          'size stays max_batch_size=9); 9 = execute chunk by chunk like '
@@ -135,11 +137,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (ROCm device); none visible')
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from pix2latent_amd import _native as N
@@ -205,6 +211,7 @@ def main():
                 'gflop_per_eval_basis': GFLOP_PER_EVAL,
                 'end_to_end_tflops': round(GFLOP_PER_EVAL * evals / elapsed / 1e3, 2),
                 'last_losses_min_max': [round(min(last_loss), 5), round(max(last_loss), 5)],
+                'last_losses': [round(x, 6) for x in last_loss],
             },
             'roofline': {
                 'kernel': 'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)',

@@ -389,6 +389,13 @@ int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
                      int H, int W, void* ws, size_t ws_bytes, float* dimg16,
                      void* stream);
 
+/* Fused F.affine_grid + F.grid_sample (bilinear, zeros, align_corners=False) on NCHW
+ * images; theta is [B][6] row-major 2x3.  Replaces the warps of
+ * pix2latent/transform/spatial_transform.py:69-104 (SpatialTransform.transform /
+ * invert_transform). */
+int p2l_affine_grid_sample(const float* src, const float* theta, float* dst, int Bn,
+                           int C, int H, int W, void* stream);
+
 /* MFMA layout self-test: C[32x32] = A[32xK] * B[Kx32] via one wave. */
 int p2l_mfma_probe(const float* A, const float* B, float* C, int K,
                    void* stream);

@@ -19,7 +19,9 @@ for _name in ('distribution', 'variable_manager', 'loss_functions', 'optimizer',
               'optimizer.gradient_optimizer', 'optimizer.basincma_optimizer',
               'optimizer.cma_optimizer', 'optimizer.base_cma_optimizer',
               'optimizer.ng_optimizer', 'optimizer.hybrid_ng_optimizer',
-              'optimizer.base_ng_optimizer', 'model.biggan'):
+              'optimizer.base_ng_optimizer', 'model.biggan', 'transform',
+              'transform.spatial_transform', 'transform.transform_optimizer',
+              'transform.transform_utils', 'transform.base_transform'):
     try:
         sys.modules['pix2latent.' + _name] = importlib.import_module('pix2latent_amd.' + _name)
     except Exception:  # pragma: no cover  (e.g. native library missing: raised on use)

@@ -641,6 +641,37 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* partial,
   }
 }
 
+// fused F.affine_grid + F.grid_sample (bilinear, zero padding, align_corners=False) for
+// NCHW images; theta[b] = [a00 a01 a02 a10 a11 a12] (reference
+// pix2latent/transform/spatial_transform.py:69-104)
+__global__ void affine_grid_sample_kernel(const float* src, const float* theta, float* dst,
+                                          int Bn, int C, int H, int W) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * H * W) return;
+  const int x = (int)(idx % W);
+  const int y = (int)((idx / W) % H);
+  const int b = (int)(idx / ((size_t)W * H));
+  const float* th = theta + b * 6;
+  const float gx0 = (2.f * x + 1.f) / W - 1.f, gy0 = (2.f * y + 1.f) / H - 1.f;
+  const float gx = th[0] * gx0 + th[1] * gy0 + th[2];
+  const float gy = th[3] * gx0 + th[4] * gy0 + th[5];
+  const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+  for (int c = 0; c < C; ++c) {
+    const float* s = src + ((size_t)b * C + c) * H * W;
+    float v = 0.f;
+    if (vy0 && vx0) v += s[(size_t)y0 * W + x0] * (wy0 * wx0);
+    if (vy0 && vx1) v += s[(size_t)y0 * W + x1] * (wy0 * wx1);
+    if (vy1 && vx0) v += s[(size_t)y1 * W + x0] * (wy1 * wx0);
+    if (vy1 && vx1) v += s[(size_t)y1 * W + x1] * (wy1 * wx1);
+    dst[((size_t)b * C + c) * H * W + (size_t)y * W + x] = v;
+  }
+}
+
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n,
                             float step_size, float beta1, float beta2, float eps,
                             float bc2_sqrt) {
@@ -917,6 +948,14 @@ extern "C" int p2l_reduce_rows(const float* partial, float* out, int Bn, int n,
                                void* stream) {
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(Bn), dim3(256), 0, ST(stream), partial,
                      out, n, scale, div, accumulate);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_affine_grid_sample(const float* src, const float* theta, float* dst, int Bn,
+                                      int C, int H, int W, void* stream) {
+  if (!src || !theta || !dst || Bn < 1) return P2L_EINVAL;
+  hipLaunchKernelGGL(affine_grid_sample_kernel, dim3(cdiv((size_t)Bn * H * W, 256)), dim3(256),
+                     0, ST(stream), src, theta, dst, Bn, C, H, W);
   return p2l_check_launch();
 }
 

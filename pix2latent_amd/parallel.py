@@ -62,7 +62,7 @@ class PopulationShard(object):
         if not self.enabled:
             return arr
         dev = torch.device('cuda', torch.cuda.current_device()) \
-            if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+            if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')   # gloo: host buffer
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
         dist.broadcast(t, src=src, group=self.group)
         return t.cpu().numpy()

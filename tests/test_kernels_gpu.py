@@ -390,3 +390,16 @@ def test_lpips_tap(dev, O, C):
     assert relerr(got.cpu(), loss.detach()) < 1e-5
     df = O.lpips_tap_bwd(nhwc(f.detach(), dev), nft, lin.to(dev), wt.to(dev), (gl / wsum).to(dev))
     assert relerr(nchw(df), f.grad) < 1e-4
+
+
+def test_affine_grid_sample_kernel(dev):
+    """fused affine-grid + bilinear grid-sample vs the two torch ops the reference calls"""
+    from pix2latent_amd.transform import SpatialTransform
+    g = torch.Generator().manual_seed(15)
+    ims = torch.rand(4, 3, 64, 64, generator=g) * 2 - 1
+    t = torch.tensor([[1.0, 0.0, 0.0], [0.8, 0.1, -0.2], [1.3, -0.25, 0.15], [0.6, 0.4, 0.4]])
+    st = SpatialTransform()
+    ref_f, ref_i = st.transform(ims, t), st.invert_transform(ims, t)
+    got_f, got_i = st.transform(ims.to(dev), t.to(dev)), st.invert_transform(ims.to(dev), t.to(dev))
+    assert (got_f.cpu() - ref_f).abs().max().item() < 1e-5
+    assert (got_i.cpu() - ref_i).abs().max().item() < 1e-5

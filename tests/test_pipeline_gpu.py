@@ -147,3 +147,43 @@ def test_exec_batch_matches_chunked_on_biggan(dev):
     dz = np.abs(z9 - z18)
     # gradients carry ~3e-3 relative fp32 noise; Adam turns that into ~1e-4 steps
     assert np.median(dz) < 1e-3 and np.mean(dz < 0.02) > 0.97
+
+
+def test_transform_basincma_on_biggan(dev):
+    """examples/invert_biggan_with_transform.py flow, shortened: CMA over the 3-d
+    transform parameter (pop 7), targets/weights warped by p2l_affine_grid_sample, the
+    inverted-loss tell, variable propagation on z."""
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import synthetic as S, function_hooks as hook
+    from pix2latent_amd.model.biggan import BigGAN
+    from pix2latent_amd.transform import SpatialTransform, TransformBasinCMAOptimizer
+    import pix2latent_amd.loss_functions as LF
+    model = BigGAN(weights=S.biggan_weights(0), device=dev)
+    loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=S.lpips_vgg_weights(1), device=dev)
+    target, weight = S.synthetic_target(256, 1), S.synthetic_weight_mask(256)
+    mask = (weight > 0.5).float() * 2 - 1
+    vm = VariableManager(device=dev)
+    vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook.Clamp(2.0))
+    vm.register('c', (128,), 'input', default=torch.zeros(128), learning_rate=0.01)
+    vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=target)
+    vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
+    tf_t, tf_w = SpatialTransform(pre_align=mask), SpatialTransform(pre_align=mask)
+    vm.register('t', tuple(tf_t.get_default_param().size()), 'transform', requires_grad=False,
+                grad_free=True)
+    torch.manual_seed(3)
+    opt = TransformBasinCMAOptimizer(model, vm, loss_fn, max_batch_size=8)
+    opt.cma_seed = 1
+    opt.register_transform(tf_t, 't', 'target')
+    opt.register_transform(tf_w, 't', 'weight')
+    opt.set_variable_propagation('z')
+    variables, (t_out, t_target, t_cand), loss = opt.optimize(meta_steps=2, grad_steps=2)
+    assert opt.num_samples == 7
+    assert np.isfinite(np.asarray(loss)).all()
+    assert tuple(opt.get_candidate().shape) == (3,)
+    assert t_cand.shape == (3, 256, 256)
+    # warped targets differ per candidate (each has its own t)
+    tg = torch.stack(list(variables.output.target.data))
+    assert (tg[0] - tg[1]).abs().max().item() > 1e-3

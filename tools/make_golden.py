@@ -210,6 +210,60 @@ def main():
              final_z=torch.stack(cvars.input.z.data).detach().numpy(),
              final_loss=np.array(closses[-1][1]['loss']), total_steps=closses[-1][0],
              model_calls=np.array(model4.calls))
+    # (6) SpatialTransform / pre-alignment / TransformBasinCMAOptimizer
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent.transform import SpatialTransform, TransformBasinCMAOptimizer
+    from pix2latent.transform.transform_utils import (compute_pre_alignment, bbox_from_mask,
+                                                      compute_stat_from_mask, convert_to_t)
+    g = torch.Generator().manual_seed(61)
+    ims = torch.rand(3, 3, 16, 16, generator=g) * 2 - 1
+    tpar = torch.tensor([[1.0, 0.0, 0.0], [0.8, 0.1, -0.2], [1.3, -0.25, 0.15]])
+    st = SpatialTransform()
+    fwd = st.transform(ims, tpar)
+    inv = st.invert_transform(fwd, tpar)
+    st2 = SpatialTransform(t=[0.9, 0.05, -0.1], sensitivity=0.1)
+    delta = torch.tensor([[0.5, -1.0, 2.0]]).repeat(3, 1)
+    called = st2(ims, delta)
+    called_inv = st2(ims, delta, invert=True)
+    mask = torch.zeros(3, 32, 32)
+    mask[:, 6:20, 10:29] = 1.0
+    pre = compute_pre_alignment(mask.clone())
+    st3 = SpatialTransform(pre_align=mask.clone())
+    np.savez(os.path.join(OUT, 'spatial_transform.npz'), ims=ims.numpy(), t=tpar.numpy(),
+             fwd=fwd.numpy(), inv=inv.numpy(), delta=delta.numpy(), called=called.numpy(),
+             called_inv=called_inv.numpy(), mask=mask.numpy(), pre_align=np.asarray(pre),
+             bbox=np.array(bbox_from_mask(mask)),
+             stat=np.array(compute_stat_from_mask(mask)).reshape(-1),
+             convert=convert_to_t((0.4, 0.6), (0.5, 0.3), (0.5, 0.5), (0.8, 0.8)).numpy(),
+             default_param=st3.get_default_param().numpy())
+
+    def make_vm_t():
+        vm = VariableManager()
+        vm.register('z', (6,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                    learning_rate=0.05, hook_fn=hook.Clamp(1.5))
+        vm.register('c', (4,), 'input', default=torch.linspace(-0.2, 0.2, 4), learning_rate=0.01)
+        vm.register('target', (3, 4, 4), 'output', requires_grad=False, default=toy_target())
+        vm.register('weight', (3, 4, 4), 'output', requires_grad=False, default=toy_weight())
+        vm.register('t', (3,), 'transform', requires_grad=False, grad_free=True)
+        return vm
+    FakeCMAES.log = []
+    model5 = ToyGenerator()
+    torch.manual_seed(45)
+    topt = TransformBasinCMAOptimizer(model5, make_vm_t(), toy_loss, max_batch_size=4)
+    topt.register_transform(SpatialTransform(), 't', 'target')
+    topt.register_transform(SpatialTransform(), 't', 'weight')
+    topt.set_variable_propagation('z')
+    tvars, (tout, ttarget, tcand), tloss = topt.optimize(meta_steps=3, grad_steps=2)
+    told = FakeCMAES.log
+    np.savez(os.path.join(OUT, 'transform_basincma.npz'), popsize=topt.num_samples,
+             n_tell=len(told), tell_x0=told[0][0], tell_y0=told[0][1], tell_y1=told[1][1],
+             tracked=torch.stack(topt.transform_tracked).numpy(),
+             candidate=topt.get_candidate().numpy(), best_loss=float(topt._best_loss),
+             final_z=torch.stack(tvars.input.z.data).detach().numpy(),
+             final_target=torch.stack(tvars.output.target.data).detach().numpy(),
+             final_loss=np.array(tloss), cand_out=tcand.detach().numpy(),
+             vp_mean=topt.vp_means['z'].detach().numpy(), model_calls=np.array(model5.calls))
     print('golden fixtures written to', OUT)
     for f in sorted(os.listdir(OUT)):
         print('  ', f, os.path.getsize(os.path.join(OUT, f)))
