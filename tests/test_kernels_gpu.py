@@ -401,5 +401,6 @@ def test_affine_grid_sample_kernel(dev):
     st = SpatialTransform()
     ref_f, ref_i = st.transform(ims, t), st.invert_transform(ims, t)
     got_f, got_i = st.transform(ims.to(dev), t.to(dev)), st.invert_transform(ims.to(dev), t.to(dev))
-    assert (got_f.cpu() - ref_f).abs().max().item() < 1e-5
-    assert (got_i.cpu() - ref_i).abs().max().item() < 1e-5
+    # interpolation weights come from coordinates of magnitude ~W: fp32 rounding ~1e-5
+    assert (got_f.cpu() - ref_f).abs().max().item() < 5e-5
+    assert (got_i.cpu() - ref_i).abs().max().item() < 5e-5
