@@ -94,7 +94,8 @@ class BigGAN(nn.Module):
         if weights is None:
             path = os.environ.get('P2L_BIGGAN_WEIGHTS')
             if path:
-                weights = torch.load(path, map_location='cpu')
+                from ..utils.checkpoint import load_biggan_state_dict
+                weights = load_biggan_state_dict(torch.load(path, map_location='cpu'))
             else:
                 warnings.warn('BigGAN: no pretrained weights available (no network); '
                               'using seeded random-init biggan-deep-256 weights')
