@@ -49,7 +49,8 @@ int p2l_last_hip_error(void);
 /* SelfAttn 1x1s, VGG16 features) and its input-gradient.                    */
 /* ------------------------------------------------------------------------- */
 
-enum { P2L_ACT_NONE = 0, P2L_ACT_RELU = 1, P2L_ACT_TANH = 2 };
+enum { P2L_ACT_NONE = 0, P2L_ACT_RELU = 1, P2L_ACT_TANH = 2,
+       P2L_ACT_LRELU_SQRT2 = 3 /* leaky_relu(0.2) * sqrt(2), StyleGAN2 FusedLeakyReLU */ };
 enum { P2L_POOL_NONE = 0, P2L_POOL_MAX = 1, P2L_POOL_SUM = 2 };
 enum { P2L_PRO_NONE = 0, P2L_PRO_AFFINE_RELU = 1, P2L_PRO_AFFINE = 2 };
 
@@ -81,6 +82,10 @@ typedef struct P2LConv {
   int32_t res_ups;  /* 1: residual is [B,H/2,W/2,*] read with nearest x2      */
   int32_t mask_ld;  /* mask pixel pitch (mask > 0 keeps the value)            */
   int32_t splitk;   /* >=1; >1 needs workspace of splitk*B*H*W*Cout floats    */
+  int32_t ext;      /* ups 2/3 only: 1 = stride-2 TRANSPOSED conv geometry: the   */
+                    /* high-res buffer is [B,H+2,W+2,*] (rows/cols 0..H real,     */
+                    /* H+1 zero) and the low-res grid of ups=2 has H/2+1 points   */
+  int32_t reserved0;
   double algo_flops; /* algorithmic FLOPs of this launch for the profiler;    */
                      /* 0 = 2*B*H*W*Cin*Cout*taps (set it when Cin/Cout are   */
                      /* zero-padded, e.g. the 3-channel image convs)          */
@@ -128,6 +133,19 @@ int p2l_set_conv_variant(int variant);
 int p2l_prof_begin(int max_launches);
 int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
 
+/* Extra epilogue terms of the StyleGAN2 styled conv (p2l_conv_fwd_ex):
+ *   v = acc * oscale[b][n] + noise_w * noise[b][pixel] + bias[n] ; act            */
+typedef struct P2LConvExtra {
+  const float* oscale;      /* [B][oscale_bstride] demodulation factors, or NULL  */
+  int32_t oscale_bstride;
+  const float* noise;       /* [B][H*W] per-pixel noise, or NULL                  */
+  float noise_w;
+} P2LConvExtra;
+int p2l_conv_fwd_ex(const P2LConv* d, const P2LConvExtra* ex, const float* x,
+                    const float* w, const float* bias, const float* pro_s,
+                    const float* pro_t, const float* res, const float* mask, float* y,
+                    float* yp, void* workspace, size_t ws_bytes, void* stream);
+
 /* w_oihw is [O][I][kh][kw].  transpose_flip=0 packs the conv I->O (K_pad >= I,
  * N_pad >= O, zero padded); transpose_flip=1 packs the conv that maps dY[O] to
  * dX[I] (taps mirrored, channels swapped; K_pad >= O, N_pad >= I). */
@@ -135,12 +153,13 @@ int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps, int N_pad,
                          int K_pad, int transpose_flip, float* w_packed,
                          void* stream);
 
-/* Sub-pixel weight packing for 3x3 convs that read a nearest-x2 upsampled input
- * (P2LConv.ups = 2 forward, 3 input-gradient with transpose_flip=1):
- * [16 slabs = phase*4 + tap][K_pad/16][N_pad][16]. */
+/* Sub-pixel weight packing (P2LConv.ups = 2 forward, 3 input-gradient with
+ * transpose_flip=1): [16 slabs = phase*4 + tap][K_pad/16][N_pad][16].
+ *   mode 0: 3x3 conv reading a nearest-x2 upsampled input (BigGAN GenBlock conv_1)
+ *   mode 1: stride-2 transposed 3x3 conv (StyleGAN2 up-conv; use with P2LConv.ext=1) */
 int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
-                                int K_pad, int transpose_flip, float* w_packed,
-                                void* stream);
+                                int K_pad, int transpose_flip, int mode,
+                                float* w_packed, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Batched GEMM fp32 (attention bmm's and their gradients).                  */

@@ -22,7 +22,8 @@ class P2LConv(C.Structure):
                 ('pro_bstride', C.c_int32), ('alpha', C.c_float), ('act', C.c_int32),
                 ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
                 ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
-                ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('algo_flops', C.c_double)]
+                ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('ext', C.c_int32),
+                ('reserved0', C.c_int32), ('algo_flops', C.c_double)]
 
 
 class P2LArb(C.Structure):
@@ -30,6 +31,11 @@ class P2LArb(C.Structure):
                 ('st_bstride', C.c_int32), ('skip', C.c_void_p), ('skip_ld', C.c_int32),
                 ('skip_C', C.c_int32), ('skip_ups', C.c_int32), ('ds', C.c_void_p),
                 ('dt', C.c_void_p), ('dsdt_bstride', C.c_int32), ('partial', C.c_void_p)]
+
+
+class P2LConvExtra(C.Structure):
+    _fields_ = [('oscale', C.c_void_p), ('oscale_bstride', C.c_int32), ('noise', C.c_void_p),
+                ('noise_w', C.c_float)]
 
 
 class P2LGemm(C.Structure):
@@ -72,14 +78,14 @@ class P2LLossCache(C.Structure):
     _fields_ = [('nft', C.c_void_p * 5), ('wt', C.c_void_p * 5), ('wsum', C.c_void_p)]
 
 
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
 POOL_NONE, POOL_MAX, POOL_SUM = 0, 1, 2
 PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 
 # every symbol include/p2l.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
-    'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd',
+    'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',

@@ -61,6 +61,10 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   } else if (act == P2L_ACT_TANH) {
     v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+  } else if (act == P2L_ACT_LRELU_SQRT2) {   // FusedLeakyReLU: lrelu(0.2) * sqrt(2)
+    const float a = 1.41421356237f, c = 0.2f * 1.41421356237f;
+    v.x *= v.x > 0.f ? a : c; v.y *= v.y > 0.f ? a : c;
+    v.z *= v.z > 0.f ? a : c; v.w *= v.w > 0.f ? a : c;
   }
   return v;
 }
@@ -110,11 +114,18 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
     const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
     if (b >= k.B || n >= k.n_store) continue;
     const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
-    // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of [B,2H,2W,*]
-    const unsigned OW = (unsigned)k.W << osh;
-    const unsigned pix0 = ((unsigned)(b * k.H + oy0) << osh) * OW + ((unsigned)ph_y * OW) +
+    // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of the output buffer
+    const unsigned OW = (unsigned)k.obW;
+    const unsigned pix0 = ((unsigned)(b * k.obH) + ((unsigned)oy0 << osh) + (unsigned)ph_y) * OW +
                           ((unsigned)ox0 << osh) + (unsigned)ph_x;
     const unsigned sub[4] = {0u, 1u << osh, OW << osh, (OW << osh) + (1u << osh)};
+    // border quads of a grid that is not a multiple of the tile
+    bool ok[4] = {true, true, true, true};
+    if (k.partial) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ok[s] = (oy0 + (s >> 1) < k.H) && (ox0 + (s & 1) < k.W);
+      if (!ok[0]) continue;
+    }
     f32x4 v[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -124,10 +135,14 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
     if (!arb) {
       f32x4 bias4 = {0, 0, 0, 0};
       if (k.bias) bias4 = ld4(k.bias, (unsigned)n);
+      f32x4 osc = {1.f, 1.f, 1.f, 1.f};
+      if (k.oscale) osc = ld4(k.oscale, (unsigned)(b * k.oscale_bstride + n));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (!ok[s]) continue;
         const unsigned pix = pix0 + sub[s];
-        f32x4 t = v[s] + bias4;
+        f32x4 t = v[s] * osc + bias4;
+        if (k.noise) t += k.noise_w * k.noise[(size_t)pix];
         if (k.res) t += ld4(k.res, (k.res_ups ? ppix : pix) * (unsigned)k.res_ld + (unsigned)n);
         t = act4(t, k.act);
         if (k.mask) {
@@ -241,9 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   // ---- which tile -------------------------------------------------------
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
-  const int tx = mt & ((1 << k.tiles_x_log) - 1);
-  const int ty = (mt >> k.tiles_x_log) & ((1 << k.tiles_y_log) - 1);
-  const int bt = mt >> (k.tiles_x_log + k.tiles_y_log);
+  const int tiles_per_image = k.tiles_x * k.tiles_y;
+  const int bt = mt / tiles_per_image;
+  const int tile_in_image = mt - bt * tiles_per_image;
+  const int ty = tile_in_image / k.tiles_x, tx = tile_in_image - ty * k.tiles_x;
   const int n0 = nt * BN;
   const int y0 = ty << k.th_log, x0 = tx << k.tw_log, b0 = bt << k.tb_log;
 
@@ -287,14 +303,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         ix = x0 + 2 * qx + (s & 1);
       }
       const int b = b0 + tb;
-      if (b < k.B && iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
+      if (b < k.B && iy >= 0 && iy < k.iH && ix >= 0 && ix < k.iW) {
         int pix;
         if (UPS)
           pix = (b * (k.H >> 1) + (iy >> 1)) * (k.W >> 1) + (ix >> 1);
-        else if (sp_bwd)      // phase plane (0,0) of the [B,2H,2W,*] gradient
-          pix = (b * 2 * k.H + 2 * iy) * 2 * k.W + 2 * ix;
+        else if (sp_bwd)      // phase plane (0,0) of the high-res gradient buffer
+          pix = (b * k.ibH + 2 * iy) * k.ibW + 2 * ix;
         else
-          pix = (b * k.H + iy) * k.W + ix;
+          pix = (b * k.ibH + iy) * k.ibW + ix;
         a_goff[it] = pix * k.x_ld + v * 4;
         a_soff[it] = b * k.pro_bstride + v * 4;
         a_valid |= 1u << it;
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         const int cls = c / k.sp_ncc;
         cc = c - cls * k.sp_ncc;
         wslab = cls * 4;
-        a_extra = ((cls >> 1) * 2 * k.W + (cls & 1)) * k.x_ld;
+        a_extra = ((cls >> 1) * k.ibW + (cls & 1)) * k.x_ld;
       } else {
         wslab = (ph_y * 2 + ph_x) * 4;
       }
@@ -466,9 +482,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       }
     }
   } else {
-    epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0,
-                     mt & ((1 << (k.tiles_x_log + k.tiles_y_log)) - 1), sp_fwd ? 1 : 0, ph_y,
-                     ph_x);
+    epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image,
+                     sp_fwd ? 1 : 0, ph_y, ph_x);
   }
 }
 
@@ -523,26 +538,34 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
   dst[idx] = v;
 }
 
-// The GEMM M grid: output pixels, except in the sub-pixel modes (ups 2 / 3) where it is
-// the LOW-RES pixel grid (d->H, d->W are always the high-res dims there).
-// Sub-pixel weights of a 3x3 conv applied to a nearest-x2 upsampled input.
-// Forward (flip=0): slab = phase(py,px)*4 + tap(i,j); value = sum of the original taps
-//   dy in S(py,i), dx in S(px,j) with S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}.
-// Input-gradient (flip=1): slab = plane(pu,pv)*4 + tap(i,j); the plane row offset is
-//   u = 2i - pu (pu=1: -1,+1 ; pu=0: 0,+2) with D(2)={0} D(0)={1,2} D(1)={0,1} D(-1)={2},
-//   channels swapped.  dst layout [16][K_pad/16][N_pad][16].
-__device__ __forceinline__ unsigned sp_tapset(int flip, int p, int i) {
-  // returns a 3-bit mask of the original taps (bit dy) that are summed
-  if (!flip) {
-    if (p == 0) return i == 0 ? 1u : 6u;
-    return i == 0 ? 3u : 4u;
+// Sub-pixel weights.  dst layout [16 slabs = phase*4 + tap][K_pad/16][N_pad][16]; each
+// slab is a sum of original 3x3 taps selected by sp_tapset (a 3-bit mask over dy / dx).
+// mode 0: 3x3 conv on a nearest-x2 upsampled input
+//   forward: S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2};
+//   input-gradient (flip): plane row offset u = 2i - pu: D(2)={0} D(0)={1,2} D(1)={0,1} D(-1)={2}
+// mode 1: stride-2 transposed 3x3 conv (StyleGAN2 up-conv: out[2p+k] += x[p] W[k])
+//   forward: phase 0 window {p-1,p} <- taps {2},{0}; phase 1 window {p,p+1} <- {1},{}
+//   input-gradient: plane 0 window {p,p+1} <- {0},{2}; plane 1 window {p-1,p} <- {},{1}
+__device__ __forceinline__ unsigned sp_tapset(int mode, int flip, int p, int i) {
+  if (mode == 0) {
+    if (!flip) {
+      if (p == 0) return i == 0 ? 1u : 6u;
+      return i == 0 ? 3u : 4u;
+    }
+    const int u = 2 * i - p;      // p = plane parity
+    return u == 2 ? 1u : u == 0 ? 6u : u == 1 ? 3u : 4u;
   }
-  const int u = 2 * i - p;      // p = plane parity
-  return u == 2 ? 1u : u == 0 ? 6u : u == 1 ? 3u : 4u;
+  if (!flip) {
+    if (p == 0) return i == 0 ? 4u : 1u;
+    return i == 0 ? 2u : 0u;
+  }
+  if (p == 0) return i == 0 ? 1u : 4u;
+  return i == 0 ? 0u : 2u;
 }
 __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restrict__ src,
                                                           float* __restrict__ dst, int O, int I,
-                                                          int N_pad, int K_pad, int flip) {
+                                                          int N_pad, int K_pad, int flip,
+                                                          int mode) {
   const size_t per = (size_t)K_pad * N_pad;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 16 * per) return;
@@ -554,7 +577,8 @@ __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restric
   const int q = (int)(r / N_pad);
   const int c = q * 16 + kk;
   const int ph = slab >> 2, tap = slab & 3;
-  const unsigned my = sp_tapset(flip, ph >> 1, tap >> 1), mx = sp_tapset(flip, ph & 1, tap & 1);
+  const unsigned my = sp_tapset(mode, flip, ph >> 1, tap >> 1);
+  const unsigned mx = sp_tapset(mode, flip, ph & 1, tap & 1);
   float v = 0.f;
   const bool ok = flip ? (n < I && c < O) : (n < O && c < I);
   if (ok) {
@@ -567,20 +591,33 @@ __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restric
   dst[idx] = v;
 }
 
-int choose_tile(const P2LConv* d, ConvK& k) {
+// The GEMM M grid: output pixels, except in the sub-pixel modes (ups 2 / 3) where it is
+// the LOW-RES pixel grid (d->H, d->W are always the high-res dims there); ext = 1 adds
+// the extra row/column of a stride-2 transposed conv (ups 2: grid H/2+1).
+static inline int npow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+void grid_dims(const P2LConv* d, int& gH, int& gW) {
   const int sh = (d->ups >= 2) ? 1 : 0;
-  const int H = d->H >> sh, W = d->W >> sh;
-  if (!is_pow2(d->H) || !is_pow2(d->W) || H < 4 || W < 4) return P2L_EINVAL;
-  int TW = W < 16 ? W : 16;
+  gH = d->H >> sh; gW = d->W >> sh;
+  if (d->ups == 2 && d->ext) { gH += 1; gW += 1; }
+}
+int choose_tile(const P2LConv* d, ConvK& k) {
+  int gH, gW;
+  grid_dims(d, gH, gW);
+  if (d->H < 4 || d->W < 4 || gH < 2 || gW < 2) return P2L_EINVAL;
+  if (d->ups < 2 && ((d->H & 1) || (d->W & 1))) return P2L_EINVAL;   // quads need even dims
+  int TW = npow2(gW) < 16 ? npow2(gW) : 16;
   int TH = 128 / TW;
-  if (TH > H) TH = H;
+  if (TH > npow2(gH)) TH = npow2(gH);
   int TB = 128 / (TW * TH);
   k.tw_log = ilog2(TW);
   k.th_log = ilog2(TH);
   k.tb_log = ilog2(TB);
-  k.tiles_x_log = ilog2(W / TW);
-  k.tiles_y_log = ilog2(H / TH);
-  k.n_mtiles = (W / TW) * (H / TH) * cdiv(d->B, TB);
+  k.tiles_x = cdiv(gW, TW);
+  k.tiles_y = cdiv(gH, TH);
+  k.tiles_x_log = ilog2(k.tiles_x);      // only meaningful for power-of-two grids (v2 kernel)
+  k.tiles_y_log = ilog2(k.tiles_y);
+  k.n_mtiles = k.tiles_x * k.tiles_y * cdiv(d->B, TB);
+  k.partial = (gW % TW != 0) || (gH % TH != 0);
   return P2L_OK;
 }
 
@@ -650,7 +687,8 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
   return (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
 }
 
-static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x, const float* w,
+static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvExtra* ex,
+                            const float* x, const float* w,
                             const float* bias, const float* pro_s,
                             const float* pro_t, const float* res,
                             const float* mask, float* y, float* yp,
@@ -689,6 +727,13 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x,
   k.ups = d->ups;
   int rc = choose_tile(d, k);
   if (rc) return rc;
+  k.iH = d->H; k.iW = d->W; k.ibH = d->H; k.ibW = d->W; k.obH = d->H; k.obW = d->W;
+  if (ex) {
+    k.oscale = ex->oscale; k.oscale_bstride = ex->oscale_bstride;
+    k.noise = ex->noise; k.noise_w = ex->noise_w;
+    if (k.noise && d->y_ld != d->n_store && false) return P2L_EINVAL;
+  }
+  if (k.partial && (arb || d->pool != P2L_POOL_NONE || d->splitk > 1)) return P2L_EUNSUP;
   if (arb) {
     if (k.tb_log != 0 || d->splitk > 1 || res || mask || d->act != P2L_ACT_NONE ||
         d->pool == P2L_POOL_MAX || !arb->x || !arb->s || !arb->t || !arb->partial)
@@ -722,23 +767,37 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x,
   }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
   if (d->ups >= 2) {
-    if (d->taps != 9 || k.tb_log != 0 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
-        (d->ups == 2 && (res || mask)))
+    if (d->taps != 9 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
+        (arb && k.tb_log != 0) || (d->ups == 2 && (res || mask)))
       return P2L_EUNSUP;
-    k.H = d->H >> 1; k.W = d->W >> 1;        // the kernel tiles the low-res grid
+    {
+      int gH, gW;
+      grid_dims(d, gH, gW);
+      const int e = d->ext ? 1 : 0, e2 = d->ext ? 2 : 0;
+      k.H = gH; k.W = gW;                    // the kernel tiles the low-res grid
+      if (d->ups == 2) {                     // low-res input -> phases of the high-res buffer
+        k.iH = d->H >> 1; k.iW = d->W >> 1; k.ibH = k.iH; k.ibW = k.iW;
+        k.obH = d->H + e2; k.obW = d->W + e2;
+      } else {                               // phase planes of the high-res buffer -> low-res
+        k.iH = (d->H >> 1) + e; k.iW = (d->W >> 1) + e;
+        k.ibH = d->H + e2; k.ibW = d->W + e2;
+        k.obH = gH; k.obW = gW;
+      }
+    }
     k.sp_mode = d->ups - 1;
     k.sp_ncc = d->Cin / 16;
     k.nchunks = (d->ups == 3) ? 4 * k.sp_ncc : k.sp_ncc;
     k.chunks_per_split = k.nchunks;
     k.ups = 0;
-    const int a_rows_sp = ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
+    const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
+    const bool small_sp = (a_rows_sp * 4 <= 3 * 256);
     size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * 20 * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
     if (lds_epi > lds_sp) lds_sp = lds_epi;
     dim3 grid(k.n_mtiles * k.n_ntiles, d->ups == 2 ? 4 : 1), block(256);
-#define P2L_LAUNCH_SP(BNV, PROV)                                                          \
+#define P2L_LAUNCH_SP(BNV, AIT, PROV)                                                     \
     do {                                                                                  \
-      auto kfn = conv_mfma_kernel<4, BNV, 16, 3, PROV, false>;                            \
+      auto kfn = conv_mfma_kernel<4, BNV, 16, AIT, PROV, false>;                          \
       static bool attr_set = false;                                                       \
       if (!attr_set) {                                                                    \
         (void)hipFuncSetAttribute((const void*)kfn,                                       \
@@ -747,15 +806,18 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const float* x,
       }                                                                                   \
       hipLaunchKernelGGL(kfn, grid, block, lds_sp, st, k);                                \
     } while (0)
+#define P2L_LAUNCH_SP_PRO(BNV, AIT)                                                       \
+    do {                                                                                  \
+      if (d->pro == P2L_PRO_NONE) P2L_LAUNCH_SP(BNV, AIT, P2L_PRO_NONE);                  \
+      else if (d->pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH_SP(BNV, AIT, P2L_PRO_AFFINE_RELU); \
+      else P2L_LAUNCH_SP(BNV, AIT, P2L_PRO_AFFINE);                                       \
+    } while (0)
     if (bn == 64) {
-      if (d->pro == P2L_PRO_NONE) P2L_LAUNCH_SP(64, P2L_PRO_NONE);
-      else if (d->pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH_SP(64, P2L_PRO_AFFINE_RELU);
-      else P2L_LAUNCH_SP(64, P2L_PRO_AFFINE);
+      if (small_sp) P2L_LAUNCH_SP_PRO(64, 3); else P2L_LAUNCH_SP_PRO(64, 5);
     } else {
-      if (d->pro == P2L_PRO_NONE) P2L_LAUNCH_SP(32, P2L_PRO_NONE);
-      else if (d->pro == P2L_PRO_AFFINE_RELU) P2L_LAUNCH_SP(32, P2L_PRO_AFFINE_RELU);
-      else P2L_LAUNCH_SP(32, P2L_PRO_AFFINE);
+      if (small_sp) P2L_LAUNCH_SP_PRO(32, 3); else P2L_LAUNCH_SP_PRO(32, 5);
     }
+#undef P2L_LAUNCH_SP_PRO
 #undef P2L_LAUNCH_SP
     rc = p2l_check_launch();
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
@@ -814,7 +876,16 @@ extern "C" int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                             const float* pro_t, const float* res,
                             const float* mask, float* y, float* yp,
                             void* workspace, size_t ws_bytes, void* stream) {
-  return conv_launch_impl(d, nullptr, x, w, bias, pro_s, pro_t, res, mask, y, yp, workspace,
+  return conv_launch_impl(d, nullptr, nullptr, x, w, bias, pro_s, pro_t, res, mask, y, yp,
+                          workspace, ws_bytes, stream);
+}
+
+extern "C" int p2l_conv_fwd_ex(const P2LConv* d, const P2LConvExtra* ex, const float* x,
+                               const float* w, const float* bias, const float* pro_s,
+                               const float* pro_t, const float* res, const float* mask,
+                               float* y, float* yp, void* workspace, size_t ws_bytes,
+                               void* stream) {
+  return conv_launch_impl(d, nullptr, ex, x, w, bias, pro_s, pro_t, res, mask, y, yp, workspace,
                           ws_bytes, stream);
 }
 
@@ -837,7 +908,7 @@ extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const flo
   dd.splitk = 1;
   if (dd.ups == 3) dd.pool = P2L_POOL_NONE;
   const bool pooled = dd.pool == P2L_POOL_SUM;
-  int rc = conv_launch_impl(&dd, arb, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
+  int rc = conv_launch_impl(&dd, arb, nullptr, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
                             pooled ? nullptr : dx, pooled ? dx : nullptr, nullptr, 0, stream);
   if (rc) return rc;
   const int nblk = p2l_conv_arb_nblk(&dd);
@@ -846,14 +917,15 @@ extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const flo
 }
 
 extern "C" int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
-                                           int K_pad, int transpose_flip, float* w_packed,
-                                           void* stream) {
-  if (!w_oihw || !w_packed) return P2L_EINVAL;
+                                           int K_pad, int transpose_flip, int mode,
+                                           float* w_packed, void* stream) {
+  if (!w_oihw || !w_packed || mode < 0 || mode > 1) return P2L_EINVAL;
   const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
   if (K_pad % 16 || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
   const size_t total = (size_t)16 * K_pad * N_pad;
   hipLaunchKernelGGL(pack_subpix_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, w_packed, O, I, N_pad, K_pad, transpose_flip);
+                     (hipStream_t)stream, w_oihw, w_packed, O, I, N_pad, K_pad, transpose_flip,
+                     mode);
   return p2l_check_launch();
 }
 

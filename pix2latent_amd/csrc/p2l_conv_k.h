@@ -25,6 +25,13 @@ struct ConvK {
   int tw_log, th_log, tb_log;
   int tiles_x_log, tiles_y_log;
   int n_mtiles, n_ntiles;
+  // general (non power-of-two) M grid: k.H x k.W grid points, tiles_x x tiles_y tiles per
+  // image; input coordinates are valid in [0,iH) x [0,iW) and live in an ibH x ibW pixel
+  // buffer; outputs go to an obH x obW pixel buffer.  partial != 0 when the grid is not a
+  // multiple of the tile (border sub-pixels are skipped in the epilogue).
+  int tiles_x, tiles_y, iH, iW, ibH, ibW, obH, obW, partial;
+  // StyleGAN2 epilogue terms: v = acc * oscale[b][n] + noise_w * noise[b][pixel] + bias[n]
+  const float* oscale; const float* noise; float noise_w; int oscale_bstride;
   // fused backward of a = max(x*s+t, 0) applied to the conv result (dgrad epilogue)
   const float* arb_x; const float* arb_s; const float* arb_t; const float* arb_skip;
   float* arb_partial;

@@ -145,7 +145,7 @@ class BigGAN(nn.Module):
         O, I = w.shape[0], w.shape[1]
         src = w.detach().to(self._dev, torch.float32).contiguous()
         dst = torch.empty(16 * n_pad * k_pad, device=self._dev, dtype=torch.float32)
-        N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+        N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 0,
                                                       N.ptr(dst), N.stream()),
                 'p2l_pack_conv_weight_subpix')
         torch.cuda.current_stream().synchronize()

@@ -31,11 +31,11 @@ def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False):
     return dst
 
 
-def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False):
+def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0):
     O, I = w_oihw.shape[0], w_oihw.shape[1]
     src = w_oihw.contiguous().float()
     dst = torch.empty(16 * n_pad * k_pad, device=src.device)
-    N.check(_lib().p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+    N.check(_lib().p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), mode,
                                                N.ptr(dst), N.stream()), 'pack_subpix')
     return dst
 
@@ -43,7 +43,7 @@ def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False):
 def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
-         splitk=None, x_ld=None):
+         splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0):
     d = N.P2LConv()
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.ups = int(ups)
@@ -56,17 +56,25 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
     d.res_ld = res.shape[-1] if res is not None else 0
     d.res_ups = int(res_ups)
     d.mask_ld = mask.shape[-1] if mask is not None else 0
+    d.ext = int(ext)
     d.splitk = splitk if splitk is not None else _lib().p2l_conv_suggest_splitk(C.byref(d))
     wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
     ws = torch.empty(max(wsb // 4, 1), device=x.device)
     if d.ups == 3:      # sub-pixel input-gradient: result at half resolution
         y = torch.empty(B, H // 2, W // 2, d.y_ld, device=x.device)
+    elif d.ups == 2 and ext:   # transposed-conv geometry: [B,H+2,W+2,*] buffer
+        y = torch.empty(B, H + 2, W + 2, d.y_ld, device=x.device)
     else:
         y = torch.empty(B, H, W, d.y_ld, device=x.device) if want_y else None
     yp = torch.empty(B, H // 2, W // 2, d.yp_ld, device=x.device) if pool else None
-    N.check(_lib().p2l_conv_fwd(C.byref(d), N.ptr(x), N.ptr(w_packed), N.ptr(bias),
-                                N.ptr(pro_s), N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y),
-                                N.ptr(yp), N.ptr(ws), C.c_size_t(wsb), N.stream()), 'conv_fwd')
+    ex = N.P2LConvExtra()
+    if oscale is not None:
+        ex.oscale, ex.oscale_bstride = oscale.data_ptr(), oscale.shape[-1]
+    if noise is not None:
+        ex.noise, ex.noise_w = noise.data_ptr(), float(noise_w)
+    N.check(_lib().p2l_conv_fwd_ex(C.byref(d), C.byref(ex), N.ptr(x), N.ptr(w_packed), N.ptr(bias),
+                                   N.ptr(pro_s), N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y),
+                                   N.ptr(yp), N.ptr(ws), C.c_size_t(wsb), N.stream()), 'conv_fwd')
     return y, yp
 
 

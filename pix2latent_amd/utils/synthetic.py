@@ -124,3 +124,61 @@ def synthetic_weight_mask(size=256):
     m = ((xs / 0.7) ** 2 + (ys / 0.6) ** 2 <= 1).float() * 2 - 1
     w = ((m + 1) / 2).clamp(0.3, 1.0)
     return w.unsqueeze(0).repeat(3, 1, 1)
+
+
+# ---------------------------------------------------------------------------
+# StyleGAN2 (rosinality g_ema key layout; reference pix2latent/model/stylegan2.py:84-85)
+# ---------------------------------------------------------------------------
+SG2_STYLE_DIM = 512
+SG2_N_MLP = 8
+SG2_LR_MLP = 0.01
+
+
+def sg2_channels(channel_multiplier=2):
+    cm = channel_multiplier
+    return {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm,
+            512: 32 * cm, 1024: 16 * cm}
+
+
+def stylegan2_weights(size=512, seed=0, channel_multiplier=2):
+    """seeded random-init `g_ema` state-dict of Generator(size, 512, 8, channel_multiplier)."""
+    g = torch.Generator().manual_seed(seed)
+    ch = sg2_channels(channel_multiplier)
+    W = {}
+
+    def randn(*shape, std=1.0):
+        return torch.randn(*shape, generator=g) * std
+
+    for i in range(1, SG2_N_MLP + 1):
+        W['style.%d.weight' % i] = randn(SG2_STYLE_DIM, SG2_STYLE_DIM) / SG2_LR_MLP
+        W['style.%d.bias' % i] = randn(SG2_STYLE_DIM, std=0.1) / SG2_LR_MLP * SG2_LR_MLP
+    W['input.input'] = randn(1, ch[4], 4, 4)
+
+    def modconv(p, cin, cout, k, wstd=1.0):
+        W[p + '.weight'] = randn(1, cout, cin, k, k, std=wstd)
+        W[p + '.modulation.weight'] = randn(cin, SG2_STYLE_DIM)
+        W[p + '.modulation.bias'] = torch.ones(cin) + randn(cin, std=0.1)
+
+    def styled(p, cin, cout):
+        modconv(p + '.conv', cin, cout, 3)
+        W[p + '.noise.weight'] = randn(1, std=0.1)
+        W[p + '.activate.bias'] = randn(cout, std=0.1)
+
+    def torgb(p, cin):
+        modconv(p + '.conv', cin, 3, 1, wstd=0.15)     # keeps the image inside (-1, 1)
+        W[p + '.bias'] = randn(1, 3, 1, 1, std=0.05)
+
+    styled('conv1', ch[4], ch[4])
+    torgb('to_rgb1', ch[4])
+    cin = ch[4]
+    log_size = int(math.log2(size))
+    for j, i in enumerate(range(3, log_size + 1)):
+        cout = ch[2 ** i]
+        styled('convs.%d' % (2 * j), cin, cout)
+        styled('convs.%d' % (2 * j + 1), cout, cout)
+        torgb('to_rgbs.%d' % j, cout)
+        cin = cout
+    for i in range((log_size - 2) * 2 + 1):
+        r = 2 ** ((i + 5) // 2)
+        W['noises.noise_%d' % i] = randn(1, 1, r, r)
+    return W

@@ -47,7 +47,7 @@ def test_version_and_errors(lib):
 def test_struct_layouts_match_c(lib):
     """sizes implied by include/p2l.h on LP64"""
     from pix2latent_amd import _native as N
-    assert C.sizeof(N.P2LConv) == 20 * 4 + 8
+    assert C.sizeof(N.P2LConv) == 22 * 4 + 8
     assert C.sizeof(N.P2LGemm) == 7 * 4 + 4 + 3 * 8 + 4 * 4
     assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 14 * 8
     assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8

@@ -404,3 +404,64 @@ def test_affine_grid_sample_kernel(dev):
     # interpolation weights come from coordinates of magnitude ~W: fp32 rounding ~1e-5
     assert (got_f.cpu() - ref_f).abs().max().item() < 5e-5
     assert (got_i.cpu() - ref_i).abs().max().item() < 5e-5
+
+
+def test_conv_non_pow2_grid(dev, O):
+    """grid that is not a multiple of the 8x16 tile (partial border tiles)"""
+    g = torch.Generator().manual_seed(16)
+    B, C, Co, H = 2, 32, 64, 24
+    x = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    bias = torch.randn(Co, generator=g) * 0.1
+    y, _ = O.conv(nhwc(x, dev), O.pack_conv_weight(w.to(dev), 9, Co, C), B, H, H, C, Co, 9,
+                  bias=bias.to(dev), splitk=1)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), F.conv2d(x, w, bias, padding=1)) < 2e-5
+
+
+def test_styled_conv_epilogue_terms(dev, O):
+    """StyleGAN2 styled conv: modulation prologue, demod scale, noise, bias, lrelu*sqrt2"""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(17)
+    B, C, Co, H = 2, 64, 64, 16
+    x = torch.randn(B, C, H, H, generator=g)
+    s = 0.5 + torch.rand(B, C, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    d = 0.5 + torch.rand(B, Co, generator=g)
+    noise = torch.randn(B, 1, H, H, generator=g)
+    bias = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x * s.view(B, C, 1, 1), w, None, padding=1) * d.view(B, Co, 1, 1) + 0.3 * noise + bias.view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref, 0.2) * math.sqrt(2)
+    y, _ = O.conv(nhwc(x, dev), O.pack_conv_weight(w.to(dev), 9, Co, C), B, H, H, C, Co, 9,
+                  bias=bias.to(dev), pro=N.PRO_AFFINE, pro_s=s.to(dev), pro_t=torch.zeros(B, C, device=dev),
+                  pro_bstride=C, act=N.ACT_LRELU_SQRT2, oscale=d.to(dev),
+                  noise=noise.view(B, H * H).contiguous().to(dev), noise_w=0.3, splitk=1)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), ref) < 2e-5
+
+
+@pytest.mark.parametrize('h,Cin,Cout', [(8, 64, 64), (16, 128, 64), (4, 64, 64)])
+def test_transposed_conv_subpixel(dev, O, h, Cin, Cout):
+    """stride-2 transposed 3x3 conv (StyleGAN2 up-conv) as 4 phase convs on the low-res grid
+    of h+1 points (ups=2, ext=1) and its input-gradient (ups=3, ext=1)."""
+    g = torch.Generator().manual_seed(18)
+    B = 2
+    x = torch.randn(B, Cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    u_ref = F.conv_transpose2d(x, w.transpose(0, 1), stride=2)            # [B,Cout,2h+1,2h+1]
+    du = torch.randn_like(u_ref)
+    u_ref.backward(du)
+    H = 2 * h
+    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin, mode=1)
+    u, _ = O.conv(nhwc(x.detach(), dev), wsp, B, H, H, Cin, Cout, 9, ups=2, ext=1, splitk=1)
+    torch.cuda.synchronize()
+    got = nchw(u)
+    assert got.shape[-1] == H + 2
+    assert relerr(got[:, :, :H + 1, :H + 1], u_ref.detach()) < 2e-5
+    assert got[:, :, H + 1].abs().max().item() == 0.0 and got[:, :, :, H + 1].abs().max().item() == 0.0
+    dup = torch.zeros(B, Cout, H + 2, H + 2)
+    dup[:, :, :H + 1, :H + 1] = du
+    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True, mode=1)
+    dx, _ = O.conv(nhwc(dup, dev), wtsp, B, H, H, Cout, Cin, 9, ups=3, ext=1, splitk=1)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), x.grad) < 2e-5
