@@ -114,6 +114,7 @@ typedef struct P2LArb {
   const float* skip; int32_t skip_ld, skip_C, skip_ups;   /* GenBlock shortcut gradient   */
   float* ds; float* dt; int32_t dsdt_bstride;
   float* partial;
+  int32_t nomask;                            /* 1: plain scale backward g = da (StyleGAN2) */
 } P2LArb;
 int p2l_conv_arb_fusable(const P2LConv* d);
 int p2l_conv_arb_nblk(const P2LConv* d);
@@ -188,6 +189,11 @@ int p2l_linear_fwd(const float* x, const float* W, const float* bias, float* y,
                    int Bn, int K, int N, void* stream);
 int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn, int K,
                    int N, int accumulate, void* stream);
+/* same with an explicit row pitch of x / dx (rows of a [B, n_latent, 512] w+ tensor) */
+int p2l_linear_fwd_ld(const float* x, int x_ld, const float* W, const float* bias, float* y,
+                      int Bn, int K, int N, void* stream);
+int p2l_linear_bwd_ld(const float* dy, const float* W, float* dx, int dx_ld, int Bn, int K,
+                      int N, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Conditional BatchNorm folded to a per-(sample,channel) affine.            */
@@ -217,6 +223,13 @@ int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x, int x_ld,
                         float* dx, int dx_ld, float* ds, float* dt,
                         int dsdt_bstride, float* partial, int Bn, int H, int W,
                         int C, void* stream);
+
+/* plain scale backward (StyleGAN2 modulation a = x*s): dx = da*s + skip ;              */
+/* ds[b,c] = sum_p da*x.  `partial`/nblk as p2l_affine_relu_bwd; dt_scratch: B*C floats. */
+int p2l_scale_bwd(const float* da, int da_ld, const float* x, int x_ld, const float* s,
+                  int st_bstride, const float* skip, int skip_ld, int skip_C, float* dx,
+                  int dx_ld, float* ds, float* dt_scratch, int dsdt_bstride, float* partial,
+                  int Bn, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Row softmax for the attention matrix and its backward.                    */
@@ -414,6 +427,84 @@ int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
  * invert_transform). */
 int p2l_affine_grid_sample(const float* src, const float* theta, float* dst, int Bn,
                            int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* StyleGAN2 (rosinality) pieces; replace fused_bias_act / upfirdn2d and the   */
+/* torch ops inside Generator.forward (reference model/stylegan2.py:116-125).  */
+/* ------------------------------------------------------------------------- */
+int p2l_sg2_pixelnorm_fwd(const float* z, float* y, int Bn, int D, void* stream);
+int p2l_sg2_pixelnorm_bwd(const float* z, const float* dy, float* dz, int Bn, int D, void* stream);
+/* x = lrelu(x + bias*bias_mul, 0.2) * sqrt(2), in place ; g *= lrelu'(y) */
+int p2l_sg2_bias_lrelu_fwd(float* x, const float* bias, float bias_mul, int Bn, int D, void* stream);
+int p2l_sg2_lrelu_bwd(const float* y, float* g, int n, void* stream);
+/* d[b,o] = rsqrt(sum_i s[b,i]^2 Wsq[i][o] + 1e-8) and its gradient into ds */
+int p2l_sg2_demod_fwd(const float* s, const float* Wsq, float* d, int Bn, int Cin, int Cout,
+                      void* stream);
+int p2l_sg2_demod_bwd(const float* s, const float* Wsq, const float* d, const float* dd, float* ds,
+                      int Bn, int Cin, int Cout, int accumulate, void* stream);
+/* y[B,H,W,C] = lrelu(blur4x4(u[B,H+2,W+2,C]) * d[b,c] + nw*noise[b,p] + bias[c]) * sqrt2 */
+int p2l_sg2_blur_fwd(const float* u, const float* d, const float* noise, float nw,
+                     const float* bias, float* y, int Bn, int H, int W, int C, void* stream);
+/* activation backward of a styled conv: gd = dy*lrelu'(y)*d ; dd[b,c] = sum_p dy*lrelu'(y)*c
+ * with c = (pre - nw*noise - bias)/d recomputed from y ; dnoise[b,p] = nw*sum_c dy*lrelu'(y)
+ * (optional).  partial: B*nblk*C floats, strips: (C/64)*B*P floats (if dnoise). */
+int p2l_sg2_act_bwd_nblk(int P);
+int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const float* d, const float* noise,
+                           float nw, const float* bias, float* gd, float* dd, float* dnoise,
+                           float* partial, float* strips, int Bn, int P, int C, void* stream);
+int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C, void* stream);
+/* RGB skip upsample (upfirdn2d up=2, [1,3,3,1]) on NHWC16 images and its transpose */
+int p2l_sg2_rgb_up_fwd(const float* skip, float* out, int Bn, int h, int w, void* stream);
+int p2l_sg2_rgb_up_bwd(const float* dout, float* dskip, int Bn, int h, int w, int accumulate,
+                       void* stream);
+int p2l_sg2_clamp16_fwd(const float* x, float* y, int64_t P, void* stream);
+int p2l_sg2_clamp16_bwd(const float* x, const float* dy, float* dx, int64_t P, void* stream);
+int p2l_broadcast_rows(const float* src, float* dst, int64_t n, int Bn, void* stream);
+int p2l_add_inplace(float* a, const float* b, int64_t n, void* stream);
+
+#define P2L_SG2_MAX_CONVS 20
+#define P2L_SG2_MAX_RGBS 10
+typedef struct P2LSg2Conv {
+  int32_t cin, cout, up, res;     /* res = output resolution                         */
+  const float* w;                 /* packed forward weights, 1/sqrt(cin*9) folded;   */
+                                  /* up=1: sub-pixel mode 1 (transposed conv)        */
+  const float* wt;                /* packed input-gradient weights                   */
+  const float* wsq;               /* [cin][cout]: scale^2 * sum_k w^2 (demodulation) */
+  const float* mod_w;             /* [512][cin] modulation weight^T / sqrt(512)      */
+  const float* mod_b;             /* [cin]                                           */
+  const float* act_b;             /* [cout] FusedLeakyReLU bias                      */
+  float noise_w;
+  int32_t latent_idx, noise_off;  /* which w+ row; float offset into the flat noise  */
+} P2LSg2Conv;
+typedef struct P2LSg2Rgb {
+  int32_t cin, res, latent_idx, after_conv;   /* reads the output of conv[after_conv] */
+  const float* w;                 /* packed 1x1 cin -> 32 (3 real), 1/sqrt(cin) folded */
+  const float* wt;                /* packed input-gradient 16 (3 real) -> cin          */
+  const float* mod_w; const float* mod_b;
+  const float* bias;              /* [32]                                              */
+} P2LSg2Rgb;
+typedef struct P2LStyleGAN2 {
+  int32_t size, n_conv, n_rgb, style_dim, n_latent, noise_total;
+  const float* map_w[8];          /* [512][512] K-major, (weight*scale)^T              */
+  const float* map_b[8];          /* [512], lr_mul folded                              */
+  const float* const_input;       /* [4][4][C0] NHWC                                   */
+  P2LSg2Conv conv[P2L_SG2_MAX_CONVS];
+  P2LSg2Rgb rgb[P2L_SG2_MAX_RGBS];
+} P2LStyleGAN2;
+size_t p2l_sg2_ws_bytes(const P2LStyleGAN2* m, int Bn);
+/* latent: [B, n_latent, 512] w+ rows (broadcast w for z-mode); noise: [B, noise_total]
+ * explicit per-layer noise; img16: [B,size,size,16] clamped image */
+int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent, const float* noise, int Bn,
+                          void* ws, size_t ws_bytes, float* img16, void* stream);
+/* dlatent [B, n_latent, 512] ; dnoise [B, noise_total] or NULL */
+int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent, const float* noise, int Bn,
+                          void* ws, size_t ws_bytes, const float* dimg16, float* dlatent,
+                          float* dnoise, void* stream);
+/* mapping network: z [B,512] -> w [B,512]; acts: 9*B*512 floats kept for the backward */
+int p2l_sg2_mapping_fwd(const P2LStyleGAN2* m, const float* z, float* w, float* acts, int Bn,
+                        void* stream);
+int p2l_sg2_mapping_bwd(const P2LStyleGAN2* m, const float* z, const float* acts, const float* dw,
+                        float* dz, float* scratch /* 2*B*512 */, int Bn, void* stream);
 
 /* MFMA layout self-test: C[32x32] = A[32xK] * B[Kx32] via one wave. */
 int p2l_mfma_probe(const float* A, const float* B, float* C, int K,

@@ -51,7 +51,7 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     p0, p1 = pad
     x = F.pad(x, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
     kh, kw = kernel.shape
-    wk = torch.flip(kernel, [0, 1]).view(1, 1, kh, kw)
+    wk = torch.flip(kernel, [0, 1]).view(1, 1, kh, kw).to(x.dtype)
     x = F.conv2d(x.reshape(b * c, 1, x.shape[2], x.shape[3]), wk)
     x = x.view(b, c, x.shape[2], x.shape[3])
     return x[:, :, ::down, ::down]

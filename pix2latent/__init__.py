@@ -19,7 +19,7 @@ for _name in ('distribution', 'variable_manager', 'loss_functions', 'optimizer',
               'optimizer.gradient_optimizer', 'optimizer.basincma_optimizer',
               'optimizer.cma_optimizer', 'optimizer.base_cma_optimizer',
               'optimizer.ng_optimizer', 'optimizer.hybrid_ng_optimizer',
-              'optimizer.base_ng_optimizer', 'model.biggan', 'transform',
+              'optimizer.base_ng_optimizer', 'model.biggan', 'model.stylegan2', 'transform',
               'transform.spatial_transform', 'transform.transform_optimizer',
               'transform.transform_utils', 'transform.base_transform'):
     try:

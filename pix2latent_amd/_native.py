@@ -30,7 +30,8 @@ class P2LArb(C.Structure):
     _fields_ = [('x', C.c_void_p), ('x_ld', C.c_int32), ('s', C.c_void_p), ('t', C.c_void_p),
                 ('st_bstride', C.c_int32), ('skip', C.c_void_p), ('skip_ld', C.c_int32),
                 ('skip_C', C.c_int32), ('skip_ups', C.c_int32), ('ds', C.c_void_p),
-                ('dt', C.c_void_p), ('dsdt_bstride', C.c_int32), ('partial', C.c_void_p)]
+                ('dt', C.c_void_p), ('dsdt_bstride', C.c_int32), ('partial', C.c_void_p),
+                ('nomask', C.c_int32)]
 
 
 class P2LConvExtra(C.Structure):
@@ -69,6 +70,29 @@ class P2LBigGAN(C.Structure):
                 ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p), ('rgb_wt', C.c_void_p)]
 
 
+P2L_SG2_MAX_CONVS, P2L_SG2_MAX_RGBS = 20, 10
+
+
+class P2LSg2Conv(C.Structure):
+    _fields_ = [('cin', C.c_int32), ('cout', C.c_int32), ('up', C.c_int32), ('res', C.c_int32),
+                ('w', C.c_void_p), ('wt', C.c_void_p), ('wsq', C.c_void_p), ('mod_w', C.c_void_p),
+                ('mod_b', C.c_void_p), ('act_b', C.c_void_p), ('noise_w', C.c_float),
+                ('latent_idx', C.c_int32), ('noise_off', C.c_int32)]
+
+
+class P2LSg2Rgb(C.Structure):
+    _fields_ = [('cin', C.c_int32), ('res', C.c_int32), ('latent_idx', C.c_int32),
+                ('after_conv', C.c_int32), ('w', C.c_void_p), ('wt', C.c_void_p),
+                ('mod_w', C.c_void_p), ('mod_b', C.c_void_p), ('bias', C.c_void_p)]
+
+
+class P2LStyleGAN2(C.Structure):
+    _fields_ = [('size', C.c_int32), ('n_conv', C.c_int32), ('n_rgb', C.c_int32),
+                ('style_dim', C.c_int32), ('n_latent', C.c_int32), ('noise_total', C.c_int32),
+                ('map_w', C.c_void_p * 8), ('map_b', C.c_void_p * 8), ('const_input', C.c_void_p),
+                ('conv', P2LSg2Conv * P2L_SG2_MAX_CONVS), ('rgb', P2LSg2Rgb * P2L_SG2_MAX_RGBS)]
+
+
 class P2LVggLpips(C.Structure):
     _fields_ = [('w', C.c_void_p * 13), ('b', C.c_void_p * 13), ('wt', C.c_void_p * 13),
                 ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
@@ -96,7 +120,13 @@ EXPORTS = [
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
+    'p2l_sg2_pixelnorm_fwd', 'p2l_sg2_pixelnorm_bwd', 'p2l_sg2_bias_lrelu_fwd', 'p2l_sg2_lrelu_bwd',
+    'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
+    'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',
+    'p2l_sg2_clamp16_fwd', 'p2l_sg2_clamp16_bwd', 'p2l_broadcast_rows', 'p2l_add_inplace',
+    'p2l_sg2_ws_bytes', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
+    'p2l_sg2_mapping_bwd', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
     'p2l_conv_dgrad_arb', 'p2l_arb_finish',
 ]
 
@@ -118,7 +148,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.p2l_strerror.restype = C.c_char_p
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
-                     'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats'):
+                     'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

@@ -180,8 +180,10 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
           const f32x4 xv = ld4(k.arb_x, pix * (unsigned)k.arb_x_ld + (unsigned)n);
           const f32x4 pre = xv * s4 + t4;
           f32x4 g = v[s];
-          g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
-          g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+          if (!k.arb_nomask) {
+            g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
+            g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+          }
           f32x4 o = g * s4;
           if (has_skip) {
             const unsigned ld = (unsigned)k.arb_skip_ld;
@@ -669,7 +671,7 @@ extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   if (d->ups >= 2) return 1;             // sub-pixel modes never split K
   if (choose_tile(d, k) != P2L_OK) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
-  const int kc = (d->taps == 9) ? 16 : 32;
+  const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nblk = k.n_mtiles * (d->Cout / bn);
   const int nchunks = d->Cin / kc;
   if (nblk >= 192) return 1;
@@ -695,7 +697,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
                             void* workspace, size_t ws_bytes, void* stream) {
   if (!d || !x || !w) return P2L_EINVAL;
   if (d->taps != 1 && d->taps != 9) return P2L_EINVAL;
-  const int kc = (d->taps == 9) ? 16 : 32;
+  const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   if (d->Cin % kc || d->Cout % 32 || d->B < 1) return P2L_EINVAL;
   if (d->x_ld % 4 || d->x_ld < d->Cin) return P2L_EINVAL;
   if (d->pro != P2L_PRO_NONE && (!pro_s || !pro_t || d->pro_bstride % 4)) return P2L_EINVAL;
@@ -742,6 +744,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.arb_partial = arb->partial; k.arb_x_ld = arb->x_ld; k.arb_bstride = arb->st_bstride;
     k.arb_skip_ld = arb->skip_ld; k.arb_skip_C = arb->skip_C; k.arb_skip_ups = arb->skip_ups;
     k.arb_nblk = k.n_mtiles / d->B;
+    k.arb_nomask = arb->nomask;
   }
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
@@ -856,9 +859,12 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
                              : launch_conv<9, 64, 16, 5>(k, d->pro, d->ups, lds, st);
     else          rc = small ? launch_conv<9, 32, 16, 3>(k, d->pro, d->ups, lds, st)
                              : launch_conv<9, 32, 16, 5>(k, d->pro, d->ups, lds, st);
-  } else {
+  } else if (kc == 32) {
     if (bn == 64) rc = launch_conv<1, 64, 32, 4>(k, d->pro, 0, lds, st);
     else          rc = launch_conv<1, 32, 32, 4>(k, d->pro, 0, lds, st);
+  } else {          // 1x1 with Cin a multiple of 16 only (RGB image gradients)
+    if (bn == 64) rc = launch_conv<1, 64, 16, 2>(k, d->pro, 0, lds, st);
+    else          rc = launch_conv<1, 32, 16, 2>(k, d->pro, 0, lds, st);
   }
   if (rc) return rc;
   if (k.splitk > 1) {
@@ -972,7 +978,7 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
                                     int N_pad, int K_pad, int transpose_flip,
                                     float* w_packed, void* stream) {
   if (!w_oihw || !w_packed || (taps != 1 && taps != 9)) return P2L_EINVAL;
-  const int kc = (taps == 9) ? 16 : 32;
+  const int kc = (taps == 9) ? 16 : (K_pad % 32 == 0 ? 32 : 16);
   const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
   if (K_pad % kc || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
   const size_t total = (size_t)taps * K_pad * N_pad;

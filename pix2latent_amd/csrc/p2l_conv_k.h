@@ -36,6 +36,7 @@ struct ConvK {
   const float* arb_x; const float* arb_s; const float* arb_t; const float* arb_skip;
   float* arb_partial;
   int arb_x_ld, arb_bstride, arb_skip_ld, arb_skip_C, arb_skip_ups, arb_nblk;
+  int arb_nomask;   // 1: plain scale backward (g = da), StyleGAN2 modulation
   // sub-pixel mode of the TAPS=4 kernel (nearest-x2 upsample folded into the weights):
   //   1 = forward: low-res input, 4 output phases (blockIdx.y), output stride 2
   //   2 = input-gradient: the 4 phase planes of the high-res dY are 4 K-slices

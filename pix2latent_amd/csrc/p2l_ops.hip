@@ -27,7 +27,7 @@ template <int BG>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ W,
     const float* __restrict__ bias, float* __restrict__ y, int Bn, int b_begin,
-    int K, int N) {
+    int K, int N, int x_ld) {
   extern __shared__ float sm[];  // [BG][K] x slab, then [4][BG][64] reduce
   float* xs = sm;
   float* red = sm + BG * K;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
   const int nb = min(BG, Bn - b_begin);
   for (int i = tid; i < BG * K; i += 256) {
     const int b = i / K, kk = i - b * K;
-    xs[i] = (b < nb) ? x[(size_t)(b_begin + b) * K + kk] : 0.f;
+    xs[i] = (b < nb) ? x[(size_t)(b_begin + b) * x_ld + kk] : 0.f;
   }
   __syncthreads();
   float acc[BG];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(
 template <int BG>
 __global__ __launch_bounds__(1024) void linear_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ W,
-    float* __restrict__ dx, int Bn, int b_begin, int K, int N, int accumulate) {
+    float* __restrict__ dx, int Bn, int b_begin, int K, int N, int accumulate, int dx_ld) {
   __shared__ float red[BG][16];
   const int k = blockIdx.x, tid = threadIdx.x;
   const int nb = min(BG, Bn - b_begin);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(1024) void linear_bwd_kernel(
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[tid][w];
-    float* p = dx + (size_t)(b_begin + tid) * K + k;
+    float* p = dx + (size_t)(b_begin + tid) * dx_ld + k;
     *p = accumulate ? (*p + s) : s;
   }
 }
@@ -148,7 +148,7 @@ struct ArbK {
   const float* da; const float* x; const float* s; const float* t;
   const float* skip; float* dx; float* partial;
   int da_ld, x_ld, dx_ld, skip_ld, skip_C, skip_ups, st_bstride;
-  int Bn, P, C, H, W, nblk;
+  int Bn, P, C, H, W, nblk, nomask;
 };
 constexpr int ARB_SLAB = 256;
 
@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
     const f32x4 xv = *reinterpret_cast<const f32x4*>(k.x + pix * k.x_ld + c);
     const f32x4 dv = *reinterpret_cast<const f32x4*>(k.da + pix * k.da_ld + c);
     f32x4 g;
-    g.x = (xv.x * s4.x + t4.x > 0.f) ? dv.x : 0.f;
-    g.y = (xv.y * s4.y + t4.y > 0.f) ? dv.y : 0.f;
-    g.z = (xv.z * s4.z + t4.z > 0.f) ? dv.z : 0.f;
-    g.w = (xv.w * s4.w + t4.w > 0.f) ? dv.w : 0.f;
+    g.x = (k.nomask || xv.x * s4.x + t4.x > 0.f) ? dv.x : 0.f;
+    g.y = (k.nomask || xv.y * s4.y + t4.y > 0.f) ? dv.y : 0.f;
+    g.z = (k.nomask || xv.z * s4.z + t4.z > 0.f) ? dv.z : 0.f;
+    g.w = (k.nomask || xv.w * s4.w + t4.w > 0.f) ? dv.w : 0.f;
     as += g * xv;
     at += g;
     f32x4 o = g * s4;
@@ -715,25 +715,37 @@ __global__ void mfma_probe_kernel(const float* A, const float* B, float* C, int 
 
 #define ST(s) ((hipStream_t)(s))
 
+extern "C" int p2l_linear_fwd_ld(const float* x, int x_ld, const float* W, const float* bias,
+                                 float* y, int Bn, int K, int N, void* stream);
 extern "C" int p2l_linear_fwd(const float* x, const float* W, const float* bias,
                               float* y, int Bn, int K, int N, void* stream) {
+  return p2l_linear_fwd_ld(x, K, W, bias, y, Bn, K, N, stream);
+}
+extern "C" int p2l_linear_fwd_ld(const float* x, int x_ld, const float* W, const float* bias,
+                                 float* y, int Bn, int K, int N, void* stream) {
   if (!x || !W || !y || K % 4 || K > 1024 || Bn < 1) return P2L_EINVAL;
   constexpr int BG = 16;
   const size_t lds = (size_t)(BG * K + 4 * BG * 64) * sizeof(float);
   for (int b0 = 0; b0 < Bn; b0 += BG) {
     hipLaunchKernelGGL(linear_fwd_kernel<BG>, dim3(cdiv(N, 64)), dim3(256), lds,
-                       ST(stream), x, W, bias, y, Bn, b0, K, N);
+                       ST(stream), x, W, bias, y, Bn, b0, K, N, x_ld);
   }
   return p2l_check_launch();
 }
 
+extern "C" int p2l_linear_bwd_ld(const float* dy, const float* W, float* dx, int dx_ld, int Bn,
+                                 int K, int N, int accumulate, void* stream);
 extern "C" int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn,
                               int K, int N, int accumulate, void* stream) {
+  return p2l_linear_bwd_ld(dy, W, dx, K, Bn, K, N, accumulate, stream);
+}
+extern "C" int p2l_linear_bwd_ld(const float* dy, const float* W, float* dx, int dx_ld, int Bn,
+                                 int K, int N, int accumulate, void* stream) {
   if (!dy || !W || !dx || Bn < 1 || (N % 4)) return P2L_EINVAL;
   constexpr int BG = 16;
   for (int b0 = 0; b0 < Bn; b0 += BG)
     hipLaunchKernelGGL(linear_bwd_kernel<BG>, dim3(K), dim3(1024), 0, ST(stream), dy,
-                       W, dx, Bn, b0, K, N, accumulate);
+                       W, dx, Bn, b0, K, N, accumulate, dx_ld);
   return p2l_check_launch();
 }
 
@@ -782,6 +794,25 @@ extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn
   if (C % 64 || out_bstride % 4) return P2L_EINVAL;
   hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0, ST(stream),
                      partial, ds, dt, Bn, nblk, C, out_bstride);
+  return p2l_check_launch();
+}
+
+// plain scale backward (StyleGAN2 modulation x*s):  dx = da*s + skip ; ds[b,c] = sum_p da*x
+extern "C" int p2l_scale_bwd(const float* da, int da_ld, const float* x, int x_ld, const float* s,
+                             int st_bstride, const float* skip, int skip_ld, int skip_C,
+                             float* dx, int dx_ld, float* ds, float* dt_scratch, int dsdt_bstride,
+                             float* partial, int Bn, int H, int W, int C, void* stream) {
+  if (!da || !x || !s || !dx || !ds || !dt_scratch || !partial) return P2L_EINVAL;
+  if (C % 64 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
+  ArbK k{};
+  k.da = da; k.x = x; k.s = s; k.t = s; k.skip = skip; k.dx = dx; k.partial = partial;
+  k.da_ld = da_ld; k.x_ld = x_ld; k.dx_ld = dx_ld; k.skip_ld = skip_ld;
+  k.skip_C = skip_C; k.skip_ups = 0; k.st_bstride = st_bstride;
+  k.Bn = Bn; k.P = H * W; k.C = C; k.H = H; k.W = W; k.nomask = 1;
+  k.nblk = cdiv(k.P, ARB_SLAB);
+  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0, ST(stream), partial, ds,
+                     dt_scratch, Bn, k.nblk, C, dsdt_bstride);
   return p2l_check_launch();
 }
 

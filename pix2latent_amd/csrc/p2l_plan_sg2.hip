@@ -1,0 +1,282 @@
+// Native runtime for the StyleGAN2 generator (rosinality architecture) reached from
+// pix2latent/model/stylegan2.py:116-125: mapping network, synthesis forward and the
+// input-gradient backward to the latents (w / w+) and, optionally, the per-layer noise.
+//
+//   * modulated conv = the MFMA conv kernel with the style as a per-(sample, channel)
+//     scale in the staging prologue, shared (un-modulated) weights, and the
+//     demodulation factor d[b,o] as a per-(sample, channel) scale in the epilogue,
+//     where noise injection, bias and leaky-ReLU*sqrt2 are fused as well;
+//   * up-sampling conv = stride-2 transposed conv in sub-pixel form (4 phase 2x2 convs
+//     on the low-res grid of H+1 points, P2LConv.ups=2/ext=1), followed by ONE fused
+//     FIR kernel (4x4 blur + demod + noise + bias + lrelu);
+//   * ToRGB = 1x1 modulated conv (3 outputs padded to 32, stored as NHWC16) with the
+//     FIR-upsampled previous skip added through the conv's residual input;
+//   * backward: activation backward + demod/noise reductions in one kernel, blur
+//     transpose, input-gradient convs (sub-pixel ups=3 for the up convs) with the
+//     modulation backward (dx = dx'*s, ds = sum dx'*x) fused into their epilogue.
+// Noise layout at this boundary: layer-major, noise + Bn*noise_off[l] is [Bn][h*w].
+#include "p2l_common.h"
+
+namespace {
+
+struct Arena {
+  size_t off = 0;
+  size_t take(size_t n) { const size_t o = off; off += (n + 63) & ~(size_t)63; return o; }
+};
+#define RET_IF(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+struct SgLayout {
+  size_t s[P2L_SG2_MAX_CONVS], d[P2L_SG2_MAX_CONVS], y[P2L_SG2_MAX_CONVS];
+  size_t ds[P2L_SG2_MAX_CONVS], dd[P2L_SG2_MAX_CONVS];
+  size_t rs[P2L_SG2_MAX_RGBS], rds[P2L_SG2_MAX_RGBS], skip[P2L_SG2_MAX_RGBS];
+  size_t x0, zeros, ubuf, upbuf, g_a, g_b, g_c, g_d, gs_a, gs_b, part, part2, strips, scratch;
+  size_t total;
+};
+
+int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
+  if (!m || B < 1 || m->n_conv < 1 || m->n_conv > P2L_SG2_MAX_CONVS || m->n_rgb > P2L_SG2_MAX_RGBS)
+    return P2L_EINVAL;
+  Arena a;
+  size_t max_act = 0, max_u = 0, max_c = 0, max_part = 0, max_part2 = 0, max_strips = 0;
+  for (int l = 0; l < m->n_conv; ++l) {
+    const P2LSg2Conv& c = m->conv[l];
+    const size_t P = (size_t)c.res * c.res;
+    L.s[l] = a.take((size_t)B * c.cin);
+    L.d[l] = a.take((size_t)B * c.cout);
+    L.y[l] = a.take((size_t)B * P * c.cout);
+    L.ds[l] = a.take((size_t)B * c.cin);
+    L.dd[l] = a.take((size_t)B * c.cout);
+    const size_t cm = (size_t)(c.cin > c.cout ? c.cin : c.cout);
+    if (B * P * cm > max_act) max_act = B * P * cm;
+    if (c.up) {
+      const size_t u = (size_t)B * (c.res + 2) * (c.res + 2) * c.cout;
+      if (u > max_u) max_u = u;
+    }
+    if (cm > max_c) max_c = cm;
+    const size_t p1 = 2 * (size_t)B * cdiv(P, 128) * cm;            // fused arb partials
+    if (p1 > max_part) max_part = p1;
+    const size_t p2 = (size_t)B * p2l_sg2_act_bwd_nblk((int)P) * c.cout;
+    if (p2 > max_part2) max_part2 = p2;
+    const size_t st = (size_t)(c.cout / 64) * B * P;
+    if (st > max_strips) max_strips = st;
+  }
+  for (int j = 0; j < m->n_rgb; ++j) {
+    const P2LSg2Rgb& r = m->rgb[j];
+    L.rs[j] = a.take((size_t)B * r.cin);
+    L.rds[j] = a.take((size_t)B * r.cin);
+    L.skip[j] = a.take((size_t)B * r.res * r.res * 16);
+  }
+  L.x0 = a.take((size_t)B * 16 * m->conv[0].cin);
+  L.zeros = a.take((size_t)B * max_c);
+  L.ubuf = a.take(max_u ? max_u : 64);
+  const size_t img = (size_t)B * m->size * m->size * 16;
+  L.upbuf = a.take(img);
+  L.g_a = a.take(max_act);
+  L.g_b = a.take(max_act);
+  L.g_c = a.take(max_act);
+  L.g_d = a.take(max_u > max_act ? max_u : max_act);
+  L.gs_a = a.take(img);
+  L.gs_b = a.take(img);
+  L.part = a.take(max_part);
+  L.part2 = a.take(max_part2);
+  L.strips = a.take(max_strips);
+  L.scratch = a.take((size_t)B * max_c * 2);
+  L.total = a.off;
+  return P2L_OK;
+}
+
+P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
+  P2LConv d{};
+  d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.Cout = Cout; d.taps = taps;
+  d.x_ld = Cin; d.alpha = 1.f; d.y_ld = Cout; d.yp_ld = Cout; d.n_store = Cout; d.splitk = 1;
+  return d;
+}
+
+// input-gradient conv + modulation backward (dx = dx' * s + extra ; ds = sum_p dx' * x)
+int dgrad_scale(P2LConv& d, const float* gin, const float* w, const float* x, const float* s,
+                int C, const float* extra, float* dx, float* ds, float* tmp, float* part,
+                float* scratch, int B, int Hout, void* st) {
+  if (p2l_conv_arb_fusable(&d)) {
+    P2LArb a{};
+    a.x = x; a.x_ld = C; a.s = s; a.t = s; a.st_bstride = C;
+    a.skip = extra; a.skip_ld = C; a.skip_C = extra ? C : 0; a.skip_ups = 0;
+    a.ds = ds; a.dt = scratch; a.dsdt_bstride = C; a.partial = part; a.nomask = 1;
+    return p2l_conv_dgrad_arb(&d, &a, gin, w, dx, st);
+  }
+  RET_IF(p2l_conv_fwd(&d, gin, w, nullptr, nullptr, nullptr, nullptr, nullptr, tmp, nullptr,
+                      nullptr, 0, st));
+  return p2l_scale_bwd(tmp, C, x, C, s, C, extra, C, extra ? C : 0, dx, C, ds, scratch, C, part, B,
+                       Hout, Hout, C, st);
+}
+
+}  // namespace
+
+extern "C" size_t p2l_sg2_ws_bytes(const P2LStyleGAN2* m, int Bn) {
+  SgLayout L;
+  if (sg_layout(m, Bn, L)) return 0;
+  return L.total * sizeof(float);
+}
+
+// acts: [9][B][D]: slot 0 = PixelNorm(z), slot i+1 = output of mapping layer i
+extern "C" int p2l_sg2_mapping_fwd(const P2LStyleGAN2* m, const float* z, float* w, float* acts,
+                                   int B, void* st) {
+  const int D = m->style_dim;
+  RET_IF(p2l_sg2_pixelnorm_fwd(z, acts, B, D, st));
+  for (int i = 0; i < 8; ++i) {
+    float* out = acts + (size_t)(i + 1) * B * D;
+    RET_IF(p2l_linear_fwd(acts + (size_t)i * B * D, m->map_w[i], nullptr, out, B, D, D, st));
+    RET_IF(p2l_sg2_bias_lrelu_fwd(out, m->map_b[i], 1.f, B, D, st));
+  }
+  if (hipMemcpyAsync(w, acts + (size_t)8 * B * D, (size_t)B * D * sizeof(float),
+                     hipMemcpyDeviceToDevice, (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
+  return P2L_OK;
+}
+
+extern "C" int p2l_sg2_mapping_bwd(const P2LStyleGAN2* m, const float* z, const float* acts,
+                                   const float* dw, float* dz, float* scratch, int B, void* st) {
+  const int D = m->style_dim;
+  float* g = scratch;
+  float* g2 = scratch + (size_t)B * D;
+  if (hipMemcpyAsync(g, dw, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice,
+                     (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
+  for (int i = 7; i >= 0; --i) {
+    RET_IF(p2l_sg2_lrelu_bwd(acts + (size_t)(i + 1) * B * D, g, B * D, st));
+    RET_IF(p2l_linear_bwd(g, m->map_w[i], g2, B, D, D, 0, st));
+    float* t = g; g = g2; g2 = t;
+  }
+  return p2l_sg2_pixelnorm_bwd(z, g, dz, B, D, st);
+}
+
+extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
+                                     const float* noise, int B, void* ws, size_t ws_bytes,
+                                     float* img16, void* st) {
+  SgLayout L;
+  RET_IF(sg_layout(m, B, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !latent || !noise || !img16) return P2L_EWS;
+  float* W = (float*)ws;
+  const int D = m->style_dim, lat_ld = m->n_latent * D;
+  if (hipMemsetAsync(W + L.zeros, 0, (L.ubuf - L.zeros) * sizeof(float), (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
+  RET_IF(p2l_broadcast_rows(m->const_input, W + L.x0, (int64_t)16 * m->conv[0].cin, B, st));
+  const float* x = W + L.x0;
+  int rj = 0;
+  for (int l = 0; l < m->n_conv; ++l) {
+    const P2LSg2Conv& c = m->conv[l];
+    const float* lat = latent + (size_t)c.latent_idx * D;
+    const float* nz = noise + (size_t)B * c.noise_off;
+    RET_IF(p2l_linear_fwd_ld(lat, lat_ld, c.mod_w, c.mod_b, W + L.s[l], B, D, c.cin, st));
+    RET_IF(p2l_sg2_demod_fwd(W + L.s[l], c.wsq, W + L.d[l], B, c.cin, c.cout, st));
+    P2LConv d = mk(B, c.res, c.cin, c.cout, 9);
+    d.pro = P2L_PRO_AFFINE; d.pro_bstride = c.cin;
+    if (!c.up) {
+      d.act = P2L_ACT_LRELU_SQRT2;
+      P2LConvExtra ex{};
+      ex.oscale = W + L.d[l]; ex.oscale_bstride = c.cout; ex.noise = nz; ex.noise_w = c.noise_w;
+      RET_IF(p2l_conv_fwd_ex(&d, &ex, x, c.w, c.act_b, W + L.s[l], W + L.zeros, nullptr, nullptr,
+                             W + L.y[l], nullptr, nullptr, 0, st));
+    } else {
+      d.ups = 2; d.ext = 1;
+      RET_IF(p2l_conv_fwd(&d, x, c.w, nullptr, W + L.s[l], W + L.zeros, nullptr, nullptr,
+                          W + L.ubuf, nullptr, nullptr, 0, st));
+      RET_IF(p2l_sg2_blur_fwd(W + L.ubuf, W + L.d[l], nz, c.noise_w, c.act_b, W + L.y[l], B, c.res,
+                              c.res, c.cout, st));
+    }
+    x = W + L.y[l];
+    while (rj < m->n_rgb && m->rgb[rj].after_conv == l) {
+      const P2LSg2Rgb& r = m->rgb[rj];
+      RET_IF(p2l_linear_fwd_ld(latent + (size_t)r.latent_idx * D, lat_ld, r.mod_w, r.mod_b,
+                               W + L.rs[rj], B, D, r.cin, st));
+      const float* res = nullptr;
+      if (rj > 0) {
+        RET_IF(p2l_sg2_rgb_up_fwd(W + L.skip[rj - 1], W + L.upbuf, B, r.res / 2, r.res / 2, st));
+        res = W + L.upbuf;
+      }
+      P2LConv t = mk(B, r.res, r.cin, 32, 1);
+      t.pro = P2L_PRO_AFFINE; t.pro_bstride = r.cin; t.n_store = 16; t.y_ld = 16; t.res_ld = 16;
+      t.algo_flops = 2.0 * B * r.res * r.res * (double)r.cin * 3;
+      RET_IF(p2l_conv_fwd(&t, x, r.w, r.bias, W + L.rs[rj], W + L.zeros, res, nullptr,
+                          W + L.skip[rj], nullptr, nullptr, 0, st));
+      ++rj;
+    }
+  }
+  return p2l_sg2_clamp16_fwd(W + L.skip[m->n_rgb - 1], img16, (int64_t)B * m->size * m->size, st);
+}
+
+extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
+                                     const float* noise, int B, void* ws, size_t ws_bytes,
+                                     const float* dimg16, float* dlatent, float* dnoise,
+                                     void* st) {
+  SgLayout L;
+  RET_IF(sg_layout(m, B, L));
+  if (!ws || ws_bytes < L.total * sizeof(float) || !dimg16 || !dlatent) return P2L_EWS;
+  float* W = (float*)ws;
+  const int D = m->style_dim, lat_ld = m->n_latent * D;
+  (void)latent;
+  if (hipMemsetAsync(dlatent, 0, (size_t)B * lat_ld * sizeof(float), (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
+  float* gs_cur = W + L.gs_a;
+  float* gs_prev = W + L.gs_b;
+  RET_IF(p2l_sg2_clamp16_bwd(W + L.skip[m->n_rgb - 1], dimg16, gs_cur,
+                             (int64_t)B * m->size * m->size, st));
+  float* gy = W + L.g_a;     // dL/dy of the layer being processed
+  float* gd = W + L.g_b;     // activation-backward result
+  float* gx = W + L.g_c;     // gradient flowing to the previous layer
+  float* tmp = W + L.g_d;    // blur transpose / unfused temp
+  float* part = W + L.part;
+  float* scratch = W + L.scratch;
+  bool have_next = false;    // gx holds a gradient for the current layer's output
+  int rj = m->n_rgb - 1;
+  for (int l = m->n_conv - 1; l >= 0; --l) {
+    const P2LSg2Conv& c = m->conv[l];
+    const float* x_in = (l == 0) ? W + L.x0 : W + L.y[l - 1];
+    const int res_in = c.up ? c.res / 2 : c.res;
+    // ---- ToRGB reading y_l -------------------------------------------------
+    bool gy_ready = false;
+    while (rj >= 0 && m->rgb[rj].after_conv == l) {
+      const P2LSg2Rgb& r = m->rgb[rj];
+      P2LConv t = mk(B, r.res, 16, r.cin, 1);
+      t.algo_flops = 2.0 * B * r.res * r.res * (double)r.cin * 3;
+      RET_IF(dgrad_scale(t, gs_cur, r.wt, W + L.y[l], W + L.rs[rj], r.cin,
+                         have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, part, scratch, B, r.res,
+                         st));
+      RET_IF(p2l_linear_bwd_ld(W + L.rds[rj], r.mod_w, dlatent + (size_t)r.latent_idx * D, lat_ld, B,
+                               D, r.cin, 1, st));
+      if (rj > 0) {
+        RET_IF(p2l_sg2_rgb_up_bwd(gs_cur, gs_prev, B, r.res / 2, r.res / 2, 0, st));
+        float* t2 = gs_cur; gs_cur = gs_prev; gs_prev = t2;
+      }
+      gy_ready = true;
+      --rj;
+    }
+    const float* dy = gy_ready ? gy : gx;      // only the next conv consumed y_l
+    if (!gy_ready && !have_next) return P2L_EINVAL;
+    // ---- styled conv l -----------------------------------------------------
+    const float* nz = noise + (size_t)B * c.noise_off;
+    float* dnz = dnoise ? dnoise + (size_t)B * c.noise_off : nullptr;
+    RET_IF(p2l_sg2_styled_act_bwd(dy, W + L.y[l], W + L.d[l], nz, c.noise_w, c.act_b, gd, W + L.dd[l],
+                                  dnz, W + L.part2, W + L.strips, B, c.res * c.res, c.cout, st));
+    // gx may alias dy (when !gy_ready): the dgrad below writes gx only after gd was produced
+    float* gout = (dy == gx) ? gy : gx;
+    if (c.up) {
+      RET_IF(p2l_sg2_blur_bwd(gd, tmp, B, c.res, c.res, c.cout, st));
+      P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
+      d.ups = 3; d.ext = 1;
+      // unfused temp must not alias the conv input (tmp): use gd
+      RET_IF(dgrad_scale(d, tmp, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], gd, part,
+                         scratch, B, res_in, st));
+    } else {
+      P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
+      RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, part,
+                         scratch, B, res_in, st));
+    }
+    RET_IF(p2l_sg2_demod_bwd(W + L.s[l], c.wsq, W + L.d[l], W + L.dd[l], W + L.ds[l], B, c.cin, c.cout,
+                             1, st));
+    RET_IF(p2l_linear_bwd_ld(W + L.ds[l], c.mod_w, dlatent + (size_t)c.latent_idx * D, lat_ld, B, D,
+                             c.cin, 1, st));
+    if (gout != gx) { float* t2 = gy; gy = gx; gx = t2; }   // keep "gx = gradient for layer l-1"
+    have_next = true;
+  }
+  return P2L_OK;
+}

@@ -1,0 +1,419 @@
+// StyleGAN2-specific HBM-bound kernels (rosinality stylegan2-pytorch ops reached from
+// reference pix2latent/model/stylegan2.py:116-125; its two CUDA extensions
+// fused_bias_act / upfirdn2d are replaced by the kernels below):
+//   * mapping network pieces: PixelNorm, bias + leaky-ReLU*sqrt2 (fused_bias_act)
+//   * weight demodulation factors d[b,o] = rsqrt(sum_i s^2 Wsq + eps) and their gradient
+//   * the 4x4 FIR blur that follows the stride-2 transposed conv, fused with the
+//     demodulation scale, noise injection, bias and leaky ReLU (forward), and its
+//     transpose fused with the activation backward and the per-(b,c) / per-pixel
+//     reductions (backward)
+//   * the RGB skip upsample (upfirdn2d up=2) forward / transpose
+//   * clamp(-1,1) forward / backward on NHWC16 images
+// All reductions are fixed-order (CMA-ES ranks by the resulting losses).
+#include "p2l_common.h"
+
+namespace {
+
+#define ST(s) ((hipStream_t)(s))
+constexpr float kSqrt2 = 1.41421356237f;
+constexpr float kSlope = 0.2f;
+
+__global__ void pixelnorm_fwd_kernel(const float* z, float* y, int Bn, int D) {
+  // one wave per row
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= Bn) return;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) { const float v = z[(size_t)row * D + i]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / D + 1e-8f);
+  for (int i = lane; i < D; i += 64) y[(size_t)row * D + i] = z[(size_t)row * D + i] * r;
+}
+__global__ void pixelnorm_bwd_kernel(const float* z, const float* dy, float* dz, int Bn, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= Bn) return;
+  float ss = 0.f, dot = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float v = z[(size_t)row * D + i];
+    ss += v * v;
+    dot += v * dy[(size_t)row * D + i];
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float r = rsqrtf(ss / D + 1e-8f);
+  // y = z r, r = (mean z^2 + eps)^-1/2  =>  dz = r dy - z r^3 (z.dy)/D
+  const float c = r * r * r * dot / D;
+  for (int i = lane; i < D; i += 64)
+    dz[(size_t)row * D + i] = r * dy[(size_t)row * D + i] - z[(size_t)row * D + i] * c;
+}
+
+__global__ void bias_lrelu_fwd_kernel(float* x, const float* bias, float bias_mul, int n, int D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i] + bias[i % D] * bias_mul;
+  x[i] = v * (v > 0.f ? kSqrt2 : kSlope * kSqrt2);
+}
+__global__ void lrelu_bwd_kernel(const float* y, float* g, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  g[i] *= (y[i] > 0.f ? kSqrt2 : kSlope * kSqrt2);
+}
+
+// d[b,o] = rsqrt(sum_i s[b,i]^2 Wsq[i][o] + 1e-8)
+__global__ void demod_fwd_kernel(const float* s, const float* Wsq, float* d, int Bn, int Cin,
+                                 int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * Cout) return;
+  const int b = i / Cout, o = i - b * Cout;
+  float q = 0.f;
+  for (int c = 0; c < Cin; ++c) {
+    const float sv = s[(size_t)b * Cin + c];
+    q = fmaf(sv * sv, Wsq[(size_t)c * Cout + o], q);
+  }
+  d[i] = rsqrtf(q + 1e-8f);
+}
+// ds[b,i] (+)= 2 s[b,i] sum_o (dd[b,o] * -0.5 d^3) Wsq[i][o]
+__global__ void demod_bwd_kernel(const float* s, const float* Wsq, const float* d,
+                                 const float* dd, float* ds, int Bn, int Cin, int Cout,
+                                 int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * Cin) return;
+  const int b = i / Cin, c = i - b * Cin;
+  float a = 0.f;
+  for (int o = 0; o < Cout; ++o) {
+    const float dv = d[(size_t)b * Cout + o];
+    a = fmaf(dd[(size_t)b * Cout + o] * (-0.5f * dv * dv * dv), Wsq[(size_t)c * Cout + o], a);
+  }
+  const float r = 2.f * s[i] * a;
+  ds[i] = accumulate ? ds[i] + r : r;
+}
+
+// ---- FIR blur after the transposed conv ------------------------------------
+// u: [B, H+2, W+2, C] (rows/cols 0..H real, H+1 zero), y: [B, H, W, C]
+// pre = blur(u)[Y,X] * d[b,c] + nw * noise[b,Y*W+X] + bias[c] ;  y = lrelu(pre)*sqrt2
+// blur(u)[Y,X] = sum_{j,i} a_j a_i u[Y+j-1, X+i-1],  a = [.25 .75 .75 .25]
+__device__ __forceinline__ float fir_a(int j) { return (j == 0 || j == 3) ? 0.25f : 0.75f; }
+
+__global__ void blur_fwd_kernel(const float* u, const float* d, const float* noise, float nw,
+                                const float* bias, float* y, int Bn, int H, int W, int C) {
+  const int C4 = C >> 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * H * W * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  size_t p = idx / C4;
+  const int X = (int)(p % W);
+  p /= W;
+  const int Y = (int)(p % H);
+  const int b = (int)(p / H);
+  const int UW = W + 2, UH = H + 2;
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int yy = Y + j - 1;
+    if (yy < 0) continue;
+    f32x4 row = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xx = X + i - 1;
+      if (xx < 0) continue;
+      row += *reinterpret_cast<const f32x4*>(u + (((size_t)b * UH + yy) * UW + xx) * C + c) * fir_a(i);
+    }
+    acc += row * fir_a(j);
+  }
+  const f32x4 d4 = *reinterpret_cast<const f32x4*>(d + (size_t)b * C + c);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c);
+  const float nz = noise ? nw * noise[((size_t)b * H + Y) * W + X] : 0.f;
+  f32x4 v = acc * d4 + b4 + nz;
+  v.x *= v.x > 0.f ? kSqrt2 : kSlope * kSqrt2;
+  v.y *= v.y > 0.f ? kSqrt2 : kSlope * kSqrt2;
+  v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
+  v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
+  *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X) * C + c) = v;
+}
+
+// activation backward of a styled conv (with or without blur): given dy and the saved
+// output y:  g1 = dy * lrelu'(y) ;  gd = g1 * d[b,c] (gradient w.r.t. the un-scaled conv /
+// blur result, written to gd);  partial sums over the slab of
+//   sum_p g1 * c_val   with c_val = (pre - nw*noise - bias)/d  (the un-scaled conv result)
+// for the demodulation gradient, and per-pixel channel sums for the noise gradient.
+struct ActBwdK {
+  const float* dy; const float* y; const float* d; const float* noise; const float* bias;
+  float* gd; float* partial; float* dnoise;
+  float nw; int Bn, P, C, nblk;
+};
+constexpr int AB_SLAB = 256;
+__global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
+  __shared__ f32x4 red[256];
+  __shared__ float redn[256];
+  const int tid = threadIdx.x, cl = tid & 15, pl = tid >> 4;
+  const int slab = blockIdx.x, c = blockIdx.y * 64 + cl * 4, b = blockIdx.z;
+  const f32x4 d4 = *reinterpret_cast<const f32x4*>(k.d + (size_t)b * k.C + c);
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(k.bias + c);
+  f32x4 acc = {0, 0, 0, 0};
+  const int p_end = min(k.P, (slab + 1) * AB_SLAB);
+  for (int p = slab * AB_SLAB + pl; p < p_end; p += 16) {
+    const size_t o = ((size_t)b * k.P + p) * k.C + c;
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(k.y + o);
+    f32x4 g = *reinterpret_cast<const f32x4*>(k.dy + o);
+    f32x4 pre;
+    g.x *= yv.x > 0.f ? kSqrt2 : kSlope * kSqrt2; pre.x = yv.x / (yv.x > 0.f ? kSqrt2 : kSlope * kSqrt2);
+    g.y *= yv.y > 0.f ? kSqrt2 : kSlope * kSqrt2; pre.y = yv.y / (yv.y > 0.f ? kSqrt2 : kSlope * kSqrt2);
+    g.z *= yv.z > 0.f ? kSqrt2 : kSlope * kSqrt2; pre.z = yv.z / (yv.z > 0.f ? kSqrt2 : kSlope * kSqrt2);
+    g.w *= yv.w > 0.f ? kSqrt2 : kSlope * kSqrt2; pre.w = yv.w / (yv.w > 0.f ? kSqrt2 : kSlope * kSqrt2);
+    const float nz = k.noise ? k.nw * k.noise[(size_t)b * k.P + p] : 0.f;
+    const f32x4 cval = (pre - b4 - nz) / d4;
+    acc += g * cval;
+    *reinterpret_cast<f32x4*>(k.gd + o) = g * d4;
+    if (k.dnoise) {
+      // channel sum of g1 for this pixel: 16 lanes x float4 of this 64-channel strip
+      float sn = (g.x + g.y) + (g.z + g.w);
+      sn += __shfl_xor(sn, 1, 64); sn += __shfl_xor(sn, 2, 64);
+      sn += __shfl_xor(sn, 4, 64); sn += __shfl_xor(sn, 8, 64);
+      if (cl == 0) k.dnoise[((size_t)blockIdx.y * k.Bn + b) * k.P + p] = sn;   // per 64-ch strip
+    }
+  }
+  red[tid] = acc;
+  (void)redn;
+  __syncthreads();
+  if (pl == 0) {
+    f32x4 a = red[cl];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) a += red[j * 16 + cl];
+    *reinterpret_cast<f32x4*>(k.partial + ((size_t)b * k.nblk + slab) * k.C + c) = a;
+  }
+}
+__global__ void rows_sum_finish_kernel(const float* partial, float* out, int Bn, int nblk, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Bn * C) return;
+  const int b = i / C, c = i - b * C;
+  float a = 0.f;
+  for (int j = 0; j < nblk; ++j) a += partial[((size_t)b * nblk + j) * C + c];
+  out[i] = a;
+}
+// dnoise[b,p] = nw * sum over 64-channel strips
+__global__ void noise_grad_finish_kernel(const float* strips, float* dnoise, float nw, int nstrip,
+                                         size_t BP) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= BP) return;
+  float a = 0.f;
+  for (int s = 0; s < nstrip; ++s) a += strips[(size_t)s * BP + i];
+  dnoise[i] = nw * a;
+}
+
+// transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d)
+__global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C) {
+  const int C4 = C >> 2, UH = H + 2, UW = W + 2;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * UH * UW * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  size_t p = idx / C4;
+  const int xx = (int)(p % UW);
+  p /= UW;
+  const int yy = (int)(p % UH);
+  const int b = (int)(p / UH);
+  // u[yy,xx] feeds y[Y,X] with Y = yy - j + 1, X = xx - i + 1
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int Y = yy - j + 1;
+    if (Y < 0 || Y >= H) continue;
+    f32x4 row = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int X = xx - i + 1;
+      if (X < 0 || X >= W) continue;
+      row += *reinterpret_cast<const f32x4*>(g + (((size_t)b * H + Y) * W + X) * C + c) * fir_a(i);
+    }
+    acc += row * fir_a(j);
+  }
+  *reinterpret_cast<f32x4*>(du + idx * 4) = acc;
+}
+
+// RGB skip: out[B,2h,2w,16] = upfirdn2d(skip[B,h,w,16], up=2, pad=(2,1)); per dim:
+//   even 2q: .25 s[q-1] + .75 s[q] ; odd 2q+1: .75 s[q] + .25 s[q+1]
+__device__ __forceinline__ f32x4 ld4c(const float* s, int y, int x, int w) {
+  return *reinterpret_cast<const f32x4*>(s + ((size_t)y * w + x) * 16);
+}
+__device__ __forceinline__ void up_taps(int Y, int h, int& q0, float& w0, int& q1, float& w1) {
+  const int q = Y >> 1;
+  if (Y & 1) { q0 = q; w0 = 0.75f; q1 = q + 1; w1 = (q + 1 < h) ? 0.25f : 0.f; }
+  else { q0 = q - 1; w0 = (q - 1 >= 0) ? 0.25f : 0.f; q1 = q; w1 = 0.75f; }
+  if (q0 < 0) q0 = 0;
+  if (q1 >= h) q1 = h - 1;
+}
+__global__ void rgb_up_fwd_kernel(const float* skip, float* out, int Bn, int h, int w) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int H = 2 * h, W = 2 * w;
+  if (idx >= (size_t)Bn * H * W) return;
+  const int X = (int)(idx % W), Y = (int)((idx / W) % H), b = (int)(idx / ((size_t)W * H));
+  int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+  up_taps(Y, h, y0, wy0, y1, wy1);
+  up_taps(X, w, x0, wx0, x1, wx1);
+  const float* s = skip + (size_t)b * h * w * 16;
+  const f32x4 v = (ld4c(s, y0, x0, w) * wx0 + ld4c(s, y0, x1, w) * wx1) * wy0 +
+                  (ld4c(s, y1, x0, w) * wx0 + ld4c(s, y1, x1, w) * wx1) * wy1;
+  f32x4* o = reinterpret_cast<f32x4*>(out + idx * 16);
+  const f32x4 z = {0, 0, 0, 0};
+  o[0] = v; o[1] = z; o[2] = z; o[3] = z;
+}
+// transpose: dskip[m] = sum over outputs it feeds
+__global__ void rgb_up_bwd_kernel(const float* dout, float* dskip, int Bn, int h, int w,
+                                  int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * h * w) return;
+  const int x = (int)(idx % w), y = (int)((idx / w) % h), b = (int)(idx / ((size_t)w * h));
+  const int H = 2 * h, W = 2 * w;
+  // rows fed by y: 2y-1 (.25), 2y (.75), 2y+1 (.75), 2y+2 (.25)
+  const int ry[4] = {2 * y - 1, 2 * y, 2 * y + 1, 2 * y + 2};
+  const int rx[4] = {2 * x - 1, 2 * x, 2 * x + 1, 2 * x + 2};
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (ry[j] < 0 || ry[j] >= H) continue;
+    f32x4 row = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (rx[i] < 0 || rx[i] >= W) continue;
+      row += *reinterpret_cast<const f32x4*>(dout + (((size_t)b * H + ry[j]) * W + rx[i]) * 16) * fir_a(i);
+    }
+    acc += row * fir_a(j);
+  }
+  f32x4* o = reinterpret_cast<f32x4*>(dskip + idx * 16);
+  const f32x4 z = {0, 0, 0, 0};
+  o[0] = accumulate ? o[0] + acc : acc;
+  if (!accumulate) { o[1] = z; o[2] = z; o[3] = z; }
+}
+
+__global__ void clamp16_fwd_kernel(const float* x, float* y, size_t P) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 16);
+  v.x = fminf(fmaxf(v.x, -1.f), 1.f); v.y = fminf(fmaxf(v.y, -1.f), 1.f);
+  v.z = fminf(fmaxf(v.z, -1.f), 1.f); v.w = 0.f;
+  f32x4* o = reinterpret_cast<f32x4*>(y + i * 16);
+  const f32x4 z = {0, 0, 0, 0};
+  o[0] = v; o[1] = z; o[2] = z; o[3] = z;
+}
+// torch clamp backward: gradient passes where min <= x <= max
+__global__ void clamp16_bwd_kernel(const float* x, const float* dy, float* dx, size_t P) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 16);
+  f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 16);
+  g.x = (v.x >= -1.f && v.x <= 1.f) ? g.x : 0.f;
+  g.y = (v.y >= -1.f && v.y <= 1.f) ? g.y : 0.f;
+  g.z = (v.z >= -1.f && v.z <= 1.f) ? g.z : 0.f;
+  g.w = 0.f;
+  f32x4* o = reinterpret_cast<f32x4*>(dx + i * 16);
+  const f32x4 z = {0, 0, 0, 0};
+  o[0] = g; o[1] = z; o[2] = z; o[3] = z;
+}
+
+// repeat a [1,h,w,C] constant over the batch
+__global__ void broadcast_rows_kernel(const float* src, float* dst, size_t n, int Bn) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * Bn) return;
+  dst[i] = src[i % n];
+}
+__global__ void add_inplace_kernel(float* a, const float* b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+}  // namespace
+
+extern "C" int p2l_sg2_pixelnorm_fwd(const float* z, float* y, int Bn, int D, void* stream) {
+  hipLaunchKernelGGL(pixelnorm_fwd_kernel, dim3(cdiv(Bn, 4)), dim3(256), 0, ST(stream), z, y, Bn, D);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_pixelnorm_bwd(const float* z, const float* dy, float* dz, int Bn, int D,
+                                     void* stream) {
+  hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(cdiv(Bn, 4)), dim3(256), 0, ST(stream), z, dy, dz, Bn, D);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_bias_lrelu_fwd(float* x, const float* bias, float bias_mul, int Bn, int D,
+                                      void* stream) {
+  hipLaunchKernelGGL(bias_lrelu_fwd_kernel, dim3(cdiv(Bn * D, 256)), dim3(256), 0, ST(stream), x, bias,
+                     bias_mul, Bn * D, D);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_lrelu_bwd(const float* y, float* g, int n, void* stream) {
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), y, g, n);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_demod_fwd(const float* s, const float* Wsq, float* d, int Bn, int Cin,
+                                 int Cout, void* stream) {
+  hipLaunchKernelGGL(demod_fwd_kernel, dim3(cdiv(Bn * Cout, 256)), dim3(256), 0, ST(stream), s, Wsq, d,
+                     Bn, Cin, Cout);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_demod_bwd(const float* s, const float* Wsq, const float* d, const float* dd,
+                                 float* ds, int Bn, int Cin, int Cout, int accumulate,
+                                 void* stream) {
+  hipLaunchKernelGGL(demod_bwd_kernel, dim3(cdiv(Bn * Cin, 256)), dim3(256), 0, ST(stream), s, Wsq, d,
+                     dd, ds, Bn, Cin, Cout, accumulate);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_blur_fwd(const float* u, const float* d, const float* noise, float nw,
+                                const float* bias, float* y, int Bn, int H, int W, int C,
+                                void* stream) {
+  if (C % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(blur_fwd_kernel, dim3(cdiv((size_t)Bn * H * W * (C / 4), 256)), dim3(256), 0,
+                     ST(stream), u, d, noise, nw, bias, y, Bn, H, W, C);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_act_bwd_nblk(int P) { return cdiv(P, AB_SLAB); }
+// partial: Bn*nblk*C floats; strips: (C/64)*Bn*P floats (only when dnoise != NULL)
+extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const float* d,
+                                      const float* noise, float nw, const float* bias, float* gd,
+                                      float* dd, float* dnoise, float* partial, float* strips,
+                                      int Bn, int P, int C, void* stream) {
+  if (C % 64) return P2L_EINVAL;
+  ActBwdK k{};
+  k.dy = dy; k.y = y; k.d = d; k.noise = noise; k.bias = bias; k.gd = gd; k.partial = partial;
+  k.dnoise = dnoise ? strips : nullptr;
+  k.nw = nw; k.Bn = Bn; k.P = P; k.C = C; k.nblk = cdiv(P, AB_SLAB);
+  hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
+  hipLaunchKernelGGL(rows_sum_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0, ST(stream), partial,
+                     dd, Bn, k.nblk, C);
+  if (dnoise)
+    hipLaunchKernelGGL(noise_grad_finish_kernel, dim3(cdiv((size_t)Bn * P, 256)), dim3(256), 0,
+                       ST(stream), strips, dnoise, nw, C / 64, (size_t)Bn * P);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C,
+                                void* stream) {
+  if (C % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(blur_bwd_kernel, dim3(cdiv((size_t)Bn * (H + 2) * (W + 2) * (C / 4), 256)),
+                     dim3(256), 0, ST(stream), g, du, Bn, H, W, C);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_rgb_up_fwd(const float* skip, float* out, int Bn, int h, int w, void* stream) {
+  hipLaunchKernelGGL(rgb_up_fwd_kernel, dim3(cdiv((size_t)Bn * 4 * h * w, 256)), dim3(256), 0,
+                     ST(stream), skip, out, Bn, h, w);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_rgb_up_bwd(const float* dout, float* dskip, int Bn, int h, int w,
+                                  int accumulate, void* stream) {
+  hipLaunchKernelGGL(rgb_up_bwd_kernel, dim3(cdiv((size_t)Bn * h * w, 256)), dim3(256), 0, ST(stream),
+                     dout, dskip, Bn, h, w, accumulate);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_clamp16_fwd(const float* x, float* y, int64_t P, void* stream) {
+  hipLaunchKernelGGL(clamp16_fwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, ST(stream), x, y, (size_t)P);
+  return p2l_check_launch();
+}
+extern "C" int p2l_sg2_clamp16_bwd(const float* x, const float* dy, float* dx, int64_t P,
+                                   void* stream) {
+  hipLaunchKernelGGL(clamp16_bwd_kernel, dim3(cdiv(P, 256)), dim3(256), 0, ST(stream), x, dy, dx,
+                     (size_t)P);
+  return p2l_check_launch();
+}
+extern "C" int p2l_broadcast_rows(const float* src, float* dst, int64_t n, int Bn, void* stream) {
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(cdiv(n * Bn, 256)), dim3(256), 0, ST(stream), src, dst,
+                     (size_t)n, Bn);
+  return p2l_check_launch();
+}
+extern "C" int p2l_add_inplace(float* a, const float* b, int64_t n, void* stream) {
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), a, b, (size_t)n);
+  return p2l_check_launch();
+}

@@ -1,1 +1,2 @@
 from .biggan import BigGAN
+from .stylegan2 import StyleGAN2
