@@ -156,10 +156,14 @@ __global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
   __shared__ f32x4 red_s[256], red_t[256];
   const int tid = threadIdx.x, cl = tid & 15, pl = tid >> 4;
   const int slab = blockIdx.x, c = blockIdx.y * 64 + cl * 4, b = blockIdx.z;
-  const f32x4 s4 = *reinterpret_cast<const f32x4*>(k.s + (size_t)b * k.st_bstride + c);
-  const f32x4 t4 = *reinterpret_cast<const f32x4*>(k.t + (size_t)b * k.st_bstride + c);
+  const bool live = c < k.C;          // C % 64 == 32: the upper half of the last strip idles
+  f32x4 s4 = {0, 0, 0, 0}, t4 = {0, 0, 0, 0};
+  if (live) {
+    s4 = *reinterpret_cast<const f32x4*>(k.s + (size_t)b * k.st_bstride + c);
+    t4 = *reinterpret_cast<const f32x4*>(k.t + (size_t)b * k.st_bstride + c);
+  }
   f32x4 as = {0, 0, 0, 0}, at = {0, 0, 0, 0};
-  const int p_end = min(k.P, (slab + 1) * ARB_SLAB);
+  const int p_end = live ? min(k.P, (slab + 1) * ARB_SLAB) : 0;
   for (int p = slab * ARB_SLAB + pl; p < p_end; p += 16) {
     const size_t pix = (size_t)b * k.P + p;
     const f32x4 xv = *reinterpret_cast<const f32x4*>(k.x + pix * k.x_ld + c);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
   red_s[tid] = as;
   red_t[tid] = at;
   __syncthreads();
-  if (pl == 0) {
+  if (pl == 0 && live) {
     f32x4 a = red_s[cl], bsum = red_t[cl];
 #pragma unroll
     for (int j = 1; j < 16; ++j) {
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(256) void arb_finish_kernel(const float* partial, f
   const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
   const size_t half = (size_t)Bn * nblk * C;
   f32x4 a = {0, 0, 0, 0}, t = {0, 0, 0, 0};
-  for (int j = seg; j < nblk; j += 16) {
+  const bool live = c < C;
+  for (int j = seg; live && j < nblk; j += 16) {
     const size_t o = ((size_t)b * nblk + j) * C + c;
     a += *reinterpret_cast<const f32x4*>(partial + o);
     t += *reinterpret_cast<const f32x4*>(partial + half + o);
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void arb_finish_kernel(const float* partial, f
   red_s[tid] = a;
   red_t[tid] = t;
   __syncthreads();
-  if (seg == 0) {
+  if (seg == 0 && live) {
 #pragma unroll
     for (int j = 1; j < 16; ++j) {
       a += red_s[j * 16 + cl];
@@ -774,7 +779,7 @@ extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
                                    float* partial, int Bn, int H, int W, int C,
                                    void* stream) {
   if (!da || !x || !s || !t || !dx || !ds || !dt || !partial) return P2L_EINVAL;
-  if (C % 64 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
+  if (C % 32 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
   if (skip && (skip_ld % 4 || skip_C % 4)) return P2L_EINVAL;
   ArbK k{};
   k.da = da; k.x = x; k.s = s; k.t = t; k.skip = skip; k.dx = dx; k.partial = partial;
@@ -791,8 +796,8 @@ extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
 
 extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk,
                               int C, int out_bstride, void* stream) {
-  if (C % 64 || out_bstride % 4) return P2L_EINVAL;
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0, ST(stream),
+  if (C % 32 || out_bstride % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream),
                      partial, ds, dt, Bn, nblk, C, out_bstride);
   return p2l_check_launch();
 }
@@ -803,15 +808,15 @@ extern "C" int p2l_scale_bwd(const float* da, int da_ld, const float* x, int x_l
                              float* dx, int dx_ld, float* ds, float* dt_scratch, int dsdt_bstride,
                              float* partial, int Bn, int H, int W, int C, void* stream) {
   if (!da || !x || !s || !dx || !ds || !dt_scratch || !partial) return P2L_EINVAL;
-  if (C % 64 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
+  if (C % 32 || da_ld % 4 || x_ld % 4 || dx_ld % 4 || st_bstride % 4) return P2L_EINVAL;
   ArbK k{};
   k.da = da; k.x = x; k.s = s; k.t = s; k.skip = skip; k.dx = dx; k.partial = partial;
   k.da_ld = da_ld; k.x_ld = x_ld; k.dx_ld = dx_ld; k.skip_ld = skip_ld;
   k.skip_C = skip_C; k.skip_ups = 0; k.st_bstride = st_bstride;
   k.Bn = Bn; k.P = H * W; k.C = C; k.H = H; k.W = W; k.nomask = 1;
   k.nblk = cdiv(k.P, ARB_SLAB);
-  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0, ST(stream), partial, ds,
+  hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, cdiv(C, 64), Bn), dim3(256), 0, ST(stream), k);
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream), partial, ds,
                      dt_scratch, Bn, k.nblk, C, dsdt_bstride);
   return p2l_check_launch();
 }

@@ -57,7 +57,7 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
     if (p1 > max_part) max_part = p1;
     const size_t p2 = (size_t)B * p2l_sg2_act_bwd_nblk((int)P) * c.cout;
     if (p2 > max_part2) max_part2 = p2;
-    const size_t st = (size_t)(c.cout / 64) * B * P;
+    const size_t st = (size_t)(c.cout / ((c.cout % 64) ? 32 : 64)) * B * P;
     if (st > max_strips) max_strips = st;
   }
   for (int j = 0; j < m->n_rgb; ++j) {

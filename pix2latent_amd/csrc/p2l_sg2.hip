@@ -141,16 +141,18 @@ struct ActBwdK {
   float nw; int Bn, P, C, nblk;
 };
 constexpr int AB_SLAB = 256;
+// SW = channel strip width per block (64, or 32 for the 32-channel FFHQ 1024^2 layers)
+template <int SW>
 __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
+  constexpr int CL = SW / 4, PL = 256 / CL;
   __shared__ f32x4 red[256];
-  __shared__ float redn[256];
-  const int tid = threadIdx.x, cl = tid & 15, pl = tid >> 4;
-  const int slab = blockIdx.x, c = blockIdx.y * 64 + cl * 4, b = blockIdx.z;
+  const int tid = threadIdx.x, cl = tid % CL, pl = tid / CL;
+  const int slab = blockIdx.x, c = blockIdx.y * SW + cl * 4, b = blockIdx.z;
   const f32x4 d4 = *reinterpret_cast<const f32x4*>(k.d + (size_t)b * k.C + c);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(k.bias + c);
   f32x4 acc = {0, 0, 0, 0};
   const int p_end = min(k.P, (slab + 1) * AB_SLAB);
-  for (int p = slab * AB_SLAB + pl; p < p_end; p += 16) {
+  for (int p = slab * AB_SLAB + pl; p < p_end; p += PL) {
     const size_t o = ((size_t)b * k.P + p) * k.C + c;
     const f32x4 yv = *reinterpret_cast<const f32x4*>(k.y + o);
     f32x4 g = *reinterpret_cast<const f32x4*>(k.dy + o);
@@ -164,20 +166,20 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
     acc += g * cval;
     *reinterpret_cast<f32x4*>(k.gd + o) = g * d4;
     if (k.dnoise) {
-      // channel sum of g1 for this pixel: 16 lanes x float4 of this 64-channel strip
+      // channel sum of g1 for this pixel: CL lanes x float4 of this SW-channel strip
       float sn = (g.x + g.y) + (g.z + g.w);
       sn += __shfl_xor(sn, 1, 64); sn += __shfl_xor(sn, 2, 64);
-      sn += __shfl_xor(sn, 4, 64); sn += __shfl_xor(sn, 8, 64);
-      if (cl == 0) k.dnoise[((size_t)blockIdx.y * k.Bn + b) * k.P + p] = sn;   // per 64-ch strip
+      sn += __shfl_xor(sn, 4, 64);
+      if (CL == 16) sn += __shfl_xor(sn, 8, 64);
+      if (cl == 0) k.dnoise[((size_t)blockIdx.y * k.Bn + b) * k.P + p] = sn;   // per strip
     }
   }
   red[tid] = acc;
-  (void)redn;
   __syncthreads();
   if (pl == 0) {
     f32x4 a = red[cl];
 #pragma unroll
-    for (int j = 1; j < 16; ++j) a += red[j * 16 + cl];
+    for (int j = 1; j < PL; ++j) a += red[j * CL + cl];
     *reinterpret_cast<f32x4*>(k.partial + ((size_t)b * k.nblk + slab) * k.C + c) = a;
   }
 }
@@ -362,22 +364,26 @@ extern "C" int p2l_sg2_blur_fwd(const float* u, const float* d, const float* noi
   return p2l_check_launch();
 }
 extern "C" int p2l_sg2_act_bwd_nblk(int P) { return cdiv(P, AB_SLAB); }
-// partial: Bn*nblk*C floats; strips: (C/64)*Bn*P floats (only when dnoise != NULL)
+// partial: Bn*nblk*C floats; strips: (C/sw)*Bn*P floats, sw = C%64 ? 32 : 64 (only when dnoise != NULL)
 extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const float* d,
                                       const float* noise, float nw, const float* bias, float* gd,
                                       float* dd, float* dnoise, float* partial, float* strips,
                                       int Bn, int P, int C, void* stream) {
-  if (C % 64) return P2L_EINVAL;
+  if (C % 32) return P2L_EINVAL;
+  const int sw = (C % 64) ? 32 : 64;
   ActBwdK k{};
   k.dy = dy; k.y = y; k.d = d; k.noise = noise; k.bias = bias; k.gd = gd; k.partial = partial;
   k.dnoise = dnoise ? strips : nullptr;
   k.nw = nw; k.Bn = Bn; k.P = P; k.C = C; k.nblk = cdiv(P, AB_SLAB);
-  hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
+  if (sw == 64)
+    hipLaunchKernelGGL(styled_act_bwd_kernel<64>, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
+  else
+    hipLaunchKernelGGL(styled_act_bwd_kernel<32>, dim3(k.nblk, C / 32, Bn), dim3(256), 0, ST(stream), k);
   hipLaunchKernelGGL(rows_sum_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0, ST(stream), partial,
                      dd, Bn, k.nblk, C);
   if (dnoise)
     hipLaunchKernelGGL(noise_grad_finish_kernel, dim3(cdiv((size_t)Bn * P, 256)), dim3(256), 0,
-                       ST(stream), strips, dnoise, nw, C / 64, (size_t)Bn * P);
+                       ST(stream), strips, dnoise, nw, C / sw, (size_t)Bn * P);
   return p2l_check_launch();
 }
 extern "C" int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C,

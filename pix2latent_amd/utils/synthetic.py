@@ -140,10 +140,14 @@ def sg2_channels(channel_multiplier=2):
             512: 32 * cm, 1024: 16 * cm}
 
 
-def stylegan2_weights(size=512, seed=0, channel_multiplier=2):
-    """seeded random-init `g_ema` state-dict of Generator(size, 512, 8, channel_multiplier)."""
+def stylegan2_weights(size=512, seed=0, channel_multiplier=2, channels=None):
+    """seeded random-init `g_ema` state-dict of Generator(size, 512, 8, channel_multiplier).
+    `channels` ({resolution: width}) overrides the width table, so that tests can put the
+    narrow 64/32-channel layers of the 512^2 / 1024^2 models into a small network."""
     g = torch.Generator().manual_seed(seed)
-    ch = sg2_channels(channel_multiplier)
+    ch = dict(sg2_channels(channel_multiplier))
+    if channels:
+        ch.update(channels)
     W = {}
 
     def randn(*shape, std=1.0):

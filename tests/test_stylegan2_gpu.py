@@ -14,14 +14,19 @@ pytestmark = pytest.mark.gpu
 SIZE = 64
 
 
-@pytest.fixture(scope='module')
-def sg(dev):
+# 'wide' = the width table of the real models at 64^2 (512..512,256); 'narrow' puts the
+# 128/64/32-channel tail of the FFHQ 1024^2 generator into the same 64^2 network
+WIDTHS = {'wide': None, 'narrow': {4: 128, 8: 128, 16: 64, 32: 32, 64: 32}}
+
+
+@pytest.fixture(scope='module', params=['wide', 'narrow'])
+def sg(request, dev):
     import warnings
     warnings.simplefilter('ignore')
     from pix2latent_amd.utils import synthetic as S
     from pix2latent_amd.model.stylegan2 import StyleGAN2
     from oracle import stylegan2_ref as R
-    W = S.stylegan2_weights(SIZE, 0)
+    W = S.stylegan2_weights(SIZE, 0, channels=WIDTHS[request.param])
     model = StyleGAN2(model='cars', search='z', weights=W, size=SIZE, device=dev)
     g = torch.Generator().manual_seed(3)
     B = 3
