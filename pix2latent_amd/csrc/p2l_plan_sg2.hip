@@ -16,6 +16,7 @@
 //     modulation backward (dx = dx'*s, ds = sum dx'*x) fused into their epilogue.
 // Noise layout at this boundary: layer-major, noise + Bn*noise_off[l] is [Bn][h*w].
 #include "p2l_common.h"
+#include "p2l_sg2_k.h"
 
 namespace {
 
@@ -161,13 +162,33 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
     return P2L_ELAUNCH;
   RET_IF(p2l_broadcast_rows(m->const_input, W + L.x0, (int64_t)16 * m->conv[0].cin, B, st));
   const float* x = W + L.x0;
+  {
+    // every layer's style s = latent . mod_w + mod_b and demodulation scale
+    // d = rsqrt(s^2 . wsq + eps) depend only on the latents: two grouped launches
+    p2lsg2::GLinFwdK gs{}, gd{};
+    gs.Bn = gd.Bn = B; gs.mode = 0; gd.mode = 1;
+    for (int l = 0; l < m->n_conv; ++l) {
+      const P2LSg2Conv& c = m->conv[l];
+      p2lsg2::GLinItem& a = gs.g[gs.n++];
+      a.W = c.mod_w; a.bias = c.mod_b; a.x = latent + (size_t)c.latent_idx * D; a.x_ld = lat_ld;
+      a.y = W + L.s[l]; a.y_ld = c.cin; a.K = D; a.N = c.cin;
+      p2lsg2::GLinItem& e = gd.g[gd.n++];
+      e.W = c.wsq; e.bias = nullptr; e.x = W + L.s[l]; e.x_ld = c.cin;
+      e.y = W + L.d[l]; e.y_ld = c.cout; e.K = c.cin; e.N = c.cout;
+    }
+    for (int j = 0; j < m->n_rgb; ++j) {
+      const P2LSg2Rgb& r = m->rgb[j];
+      p2lsg2::GLinItem& a = gs.g[gs.n++];
+      a.W = r.mod_w; a.bias = r.mod_b; a.x = latent + (size_t)r.latent_idx * D; a.x_ld = lat_ld;
+      a.y = W + L.rs[j]; a.y_ld = r.cin; a.K = D; a.N = r.cin;
+    }
+    RET_IF(p2lsg2::grouped_linear_fwd(gs, st));
+    RET_IF(p2lsg2::grouped_linear_fwd(gd, st));
+  }
   int rj = 0;
   for (int l = 0; l < m->n_conv; ++l) {
     const P2LSg2Conv& c = m->conv[l];
-    const float* lat = latent + (size_t)c.latent_idx * D;
     const float* nz = noise + (size_t)B * c.noise_off;
-    RET_IF(p2l_linear_fwd_ld(lat, lat_ld, c.mod_w, c.mod_b, W + L.s[l], B, D, c.cin, st));
-    RET_IF(p2l_sg2_demod_fwd(W + L.s[l], c.wsq, W + L.d[l], B, c.cin, c.cout, st));
     P2LConv d = mk(B, c.res, c.cin, c.cout, 9);
     d.pro = P2L_PRO_AFFINE; d.pro_bstride = c.cin;
     if (!c.up) {
@@ -186,8 +207,6 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
     x = W + L.y[l];
     while (rj < m->n_rgb && m->rgb[rj].after_conv == l) {
       const P2LSg2Rgb& r = m->rgb[rj];
-      RET_IF(p2l_linear_fwd_ld(latent + (size_t)r.latent_idx * D, lat_ld, r.mod_w, r.mod_b,
-                               W + L.rs[rj], B, D, r.cin, st));
       const float* res = nullptr;
       if (rj > 0) {
         RET_IF(p2l_sg2_rgb_up_fwd(W + L.skip[rj - 1], W + L.upbuf, B, r.res / 2, r.res / 2, st));
@@ -241,8 +260,6 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       RET_IF(dgrad_scale(t, gs_cur, r.wt, W + L.y[l], W + L.rs[rj], r.cin,
                          have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, part, scratch, B, r.res,
                          st));
-      RET_IF(p2l_linear_bwd_ld(W + L.rds[rj], r.mod_w, dlatent + (size_t)r.latent_idx * D, lat_ld, B,
-                               D, r.cin, 1, st));
       if (rj > 0) {
         RET_IF(p2l_sg2_rgb_up_bwd(gs_cur, gs_prev, B, r.res / 2, r.res / 2, 0, st));
         float* t2 = gs_cur; gs_cur = gs_prev; gs_prev = t2;
@@ -271,12 +288,31 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, part,
                          scratch, B, res_in, st));
     }
-    RET_IF(p2l_sg2_demod_bwd(W + L.s[l], c.wsq, W + L.d[l], W + L.dd[l], W + L.ds[l], B, c.cin, c.cout,
-                             1, st));
-    RET_IF(p2l_linear_bwd_ld(W + L.ds[l], c.mod_w, dlatent + (size_t)c.latent_idx * D, lat_ld, B, D,
-                             c.cin, 1, st));
     if (gout != gx) { float* t2 = gy; gy = gx; gx = t2; }   // keep "gx = gradient for layer l-1"
     have_next = true;
   }
+  // style gradients of all layers at once: ds += demodulation backward; then
+  // dlatent[latent_idx] += ds . mod_w^T (convs, then ToRGBs: each launch touches every
+  // latent row at most once, and the two launches are ordered -> deterministic)
+  p2lsg2::GLinBwdK gm{}, gc{}, gr{};
+  gm.Bn = gc.Bn = gr.Bn = B; gm.mode = 1;
+  for (int l = 0; l < m->n_conv; ++l) {
+    const P2LSg2Conv& c = m->conv[l];
+    p2lsg2::GLinBwdItem& a = gm.g[gm.n++];
+    a.W = c.wsq; a.dy = W + L.dd[l]; a.d = W + L.d[l]; a.x = W + L.s[l]; a.dx = W + L.ds[l];
+    a.K = c.cin; a.N = c.cout; a.dx_ld = c.cin; a.accumulate = 1;
+    p2lsg2::GLinBwdItem& e = gc.g[gc.n++];
+    e.W = c.mod_w; e.dy = W + L.ds[l]; e.dx = dlatent + (size_t)c.latent_idx * D;
+    e.K = D; e.N = c.cin; e.dx_ld = lat_ld; e.accumulate = 1;
+  }
+  for (int j = 0; j < m->n_rgb; ++j) {
+    const P2LSg2Rgb& r = m->rgb[j];
+    p2lsg2::GLinBwdItem& e = gr.g[gr.n++];
+    e.W = r.mod_w; e.dy = W + L.rds[j]; e.dx = dlatent + (size_t)r.latent_idx * D;
+    e.K = D; e.N = r.cin; e.dx_ld = lat_ld; e.accumulate = 1;
+  }
+  RET_IF(p2lsg2::grouped_linear_bwd(gm, st));
+  RET_IF(p2lsg2::grouped_linear_bwd(gc, st));
+  RET_IF(p2lsg2::grouped_linear_bwd(gr, st));
   return P2L_OK;
 }

@@ -183,13 +183,24 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
     *reinterpret_cast<f32x4*>(k.partial + ((size_t)b * k.nblk + slab) * k.C + c) = a;
   }
 }
-__global__ void rows_sum_finish_kernel(const float* partial, float* out, int Bn, int nblk, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Bn * C) return;
-  const int b = i / C, c = i - b * C;
-  float a = 0.f;
-  for (int j = 0; j < nblk; ++j) a += partial[((size_t)b * nblk + j) * C + c];
-  out[i] = a;
+// grid (cdiv(C,64), B); 16 segments x 16 channel-float4 lanes: each thread adds its
+// segment's slabs in order, then the segments are combined in a fixed order
+__global__ __launch_bounds__(256) void rows_sum_finish_kernel(const float* partial, float* out,
+                                                              int Bn, int nblk, int C) {
+  __shared__ f32x4 red[256];
+  const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
+  const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
+  const bool live = c < C;
+  f32x4 a = {0, 0, 0, 0};
+  for (int j = seg; live && j < nblk; j += 16)
+    a += *reinterpret_cast<const f32x4*>(partial + ((size_t)b * nblk + j) * C + c);
+  red[tid] = a;
+  __syncthreads();
+  if (seg == 0 && live) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) a += red[j * 16 + cl];
+    *reinterpret_cast<f32x4*>(out + (size_t)b * C + c) = a;
+  }
 }
 // dnoise[b,p] = nw * sum over 64-channel strips
 __global__ void noise_grad_finish_kernel(const float* strips, float* dnoise, float nw, int nstrip,
@@ -379,7 +390,7 @@ extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const flo
     hipLaunchKernelGGL(styled_act_bwd_kernel<64>, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
   else
     hipLaunchKernelGGL(styled_act_bwd_kernel<32>, dim3(k.nblk, C / 32, Bn), dim3(256), 0, ST(stream), k);
-  hipLaunchKernelGGL(rows_sum_finish_kernel, dim3(cdiv(Bn * C, 256)), dim3(256), 0, ST(stream), partial,
+  hipLaunchKernelGGL(rows_sum_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream), partial,
                      dd, Bn, k.nblk, C);
   if (dnoise)
     hipLaunchKernelGGL(noise_grad_finish_kernel, dim3(cdiv((size_t)Bn * P, 256)), dim3(256), 0,

@@ -1,7 +1,8 @@
 """Print StyleGAN2 native-vs-oracle error magnitudes (diagnostic; run on the GPU box)."""
 import sys, time, warnings
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 warnings.simplefilter('ignore')
 from pix2latent_amd.utils import synthetic as S
 from pix2latent_amd.model.stylegan2 import StyleGAN2

@@ -1,7 +1,8 @@
 """StyleGAN2 full-size timing + size-independent checks (run on the GPU box)."""
 import sys, time, warnings
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 warnings.simplefilter('ignore')
 from pix2latent_amd.model.stylegan2 import StyleGAN2
 from pix2latent_amd import _native as N
