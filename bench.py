@@ -175,8 +175,17 @@ def main():
     flops = (C.c_double * 2)()
     ms = (C.c_double * 2)()
     cnt = (C.c_int32 * 2)()
-    N.check(lib.p2l_prof_end(flops, ms, cnt), 'p2l_prof_end')
+    abytes = (C.c_double * 2)()
+    N.check(lib.p2l_prof_end2(flops, ms, cnt, abytes), 'p2l_prof_end2')
     last_loss = [float(x) for x in opt.loss]
+    # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
+    sync()
+    t1 = time.perf_counter()
+    n_rescore = 3
+    for _ in range(n_rescore):
+        opt.step(variables, optimize=False)
+    sync()
+    rescore_rate = POP * n_rescore / (time.perf_counter() - t1)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -187,6 +196,16 @@ def main():
         evals = POP * args.steps
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
+        # PMC counters cannot be read from inside the timed process: `traffic` is the
+        # committed result of the separate rocprofv3 --pmc passes over this same command
+        # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                             'round1_traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+            traffic_src = 'profiles/round1_traffic.json'
         rec = {
             'metric': 'candidate-latent evals/sec (fwd+loss+bwd), BigGAN-256 pop=18',
             'value': round(evals / elapsed, 3),
@@ -210,6 +229,7 @@ def main():
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'gflop_per_eval_basis': GFLOP_PER_EVAL,
                 'end_to_end_tflops': round(GFLOP_PER_EVAL * evals / elapsed / 1e3, 2),
+                'fwd_only_rescore_evals_per_s': round(rescore_rate, 1),
                 'last_losses_min_max': [round(min(last_loss), 5), round(max(last_loss), 5)],
                 'last_losses': [round(x, 6) for x in last_loss],
             },
@@ -220,7 +240,10 @@ def main():
                 'peak': FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+                'traffic_source': traffic_src,
+                'algo_bytes_per_launch': round(abytes[0] / max(cnt[0], 1)),
                 'launches': int(cnt[0]),
                 'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
                 'algo_gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),

@@ -133,6 +133,9 @@ int p2l_set_conv_variant(int variant);
  * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */
 int p2l_prof_begin(int max_launches);
 int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
+/* same, plus the algorithmic bytes of the timed launches (each operand tensor once +
+ * packed weights); index 0 = 3x3 launches, 1 = 1x1 launches */
+int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]);
 
 /* Extra epilogue terms of the StyleGAN2 styled conv (p2l_conv_fwd_ex):
  *   v = acc * oscale[b][n] + noise_w * noise[b][pixel] + bias[n] ; act            */

@@ -53,6 +53,7 @@ struct ConvProf {
   int n = 0;
   std::vector<hipEvent_t> ev;
   std::vector<double> flops;
+  std::vector<double> bytes;
   std::vector<int> kind;
 } g_prof;
 
@@ -766,6 +767,19 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
         ? d->algo_flops
         : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
+    {
+      // algorithmic bytes: every operand tensor once (input at ITS resolution, outputs,
+      // residual / mask, the fused activation-backward operands) + the packed weights
+      const double opx = (double)d->B * d->H * d->W;
+      const double ipx = d->ups == 1 || d->ups == 2 ? opx / 4 : (d->ups == 3 ? opx * 4 : opx);
+      double by = ipx * d->Cin + (double)d->taps * d->Cin * d->Cout;
+      if (y) by += opx * d->n_store;
+      if (yp) by += opx / 4 * d->n_store;
+      if (res) by += (d->res_ups ? opx / 4 : opx) * d->n_store;
+      if (mask) by += opx * d->n_store;
+      if (arb) by += opx * d->n_store * (arb->skip ? 2.0 : 1.0);
+      g_prof.bytes[prof_slot] = 4.0 * by;
+    }
     (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
   }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
@@ -950,6 +964,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
     g_prof.ev.push_back(e);
   }
   g_prof.flops.assign(max_launches, 0.0);
+  g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
   g_prof.n = 0;
   g_prof.on = true;
@@ -957,9 +972,14 @@ extern "C" int p2l_prof_begin(int max_launches) {
 }
 
 extern "C" int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]) {
+  return p2l_prof_end2(flops, ms, count, nullptr);
+}
+
+extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]) {
   g_prof.on = false;
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
   count[0] = count[1] = 0;
+  if (bytes) bytes[0] = bytes[1] = 0.0;
   for (int i = 0; i < g_prof.n; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return P2L_ELAUNCH;
     float t = 0.f;
@@ -967,6 +987,7 @@ extern "C" int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]) {
       return P2L_ELAUNCH;
     const int k = g_prof.kind[i];
     flops[k] += g_prof.flops[i];
+    if (bytes) bytes[k] += g_prof.bytes[i];
     ms[k] += t;
     count[k] += 1;
   }

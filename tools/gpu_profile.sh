@@ -11,6 +11,7 @@ cd $R
 ls gpurun_out/pmc_fetch gpurun_out/pmc_write
 python tools/pmc_summary.py $(ls gpurun_out/pmc_fetch/*counter_collection.csv | head -1) gpurun_out/pmc_fetch_summary.csv
 python tools/pmc_summary.py $(ls gpurun_out/pmc_write/*counter_collection.csv | head -1) gpurun_out/pmc_write_summary.csv
+python tools/traffic_json.py gpurun_out/pmc_fetch_summary.csv gpurun_out/pmc_write_summary.csv gpurun_out/traffic.json
 rm -f gpurun_out/pmc_fetch/*counter_collection.csv gpurun_out/pmc_write/*counter_collection.csv gpurun_out/prof/*kernel_trace.csv
 echo "=== stats"; head -25 gpurun_out/prof/r1_kernel_stats.csv
 cat gpurun_out/prof_bench.json

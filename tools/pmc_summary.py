@@ -20,6 +20,6 @@ rows = sorted(((k[0], k[1], v[0], v[1], v[1] / v[0]) for k, v in acc.items()), k
 with open(dst, 'w') as f:
     w = csv.writer(f)
     w.writerow(['Kernel_Name', 'Counter', 'Dispatches', 'Sum', 'MeanPerDispatch'])
-    for t in rows[:60]:
+    for t in rows[:120]:
         w.writerow(t)
-print(open(dst).read()[:3000])
+print(open(dst).read()[:1500])
