@@ -34,7 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 GFLOP_PER_EVAL = 197.8              # BASELINE.md §2 (conv_to_rgb sliced to 3 channels)
 
 
-def build_problem(dev, seed=0, exec_batch_size=None):
+def build_problem(dev, seed=0, exec_batch_size=None, lpips_net='vgg'):
     from pix2latent_amd import VariableManager, distribution
     from pix2latent_amd.utils import synthetic as S, function_hooks as hook
     from pix2latent_amd.model.biggan import BigGAN
@@ -42,9 +42,10 @@ def build_problem(dev, seed=0, exec_batch_size=None):
     import pix2latent_amd.loss_functions as LF
     import warnings
     warnings.simplefilter('ignore')
-    W, Wv = S.biggan_weights(0), S.lpips_vgg_weights(1)
+    W = S.biggan_weights(0)
+    Wv = S.lpips_vgg_weights(1) if lpips_net == 'vgg' else S.lpips_alex_weights(2)
     model = BigGAN(weights=W, device=dev)
-    loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
+    loss_fn = LF.ProjectionLoss(lpips_net=lpips_net, weights=Wv, device=dev)
     g = torch.Generator().manual_seed(2)
     c_default = 0.05 * torch.randn(128, generator=g)
     target = S.synthetic_target(256, 1)
@@ -123,6 +124,9 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex'],
+                    help="LPIPS network: 'vgg' = BASELINE.json's metric (default); 'alex' = the "
+                         "reference's ProjectionLoss() default, reported as a side configuration")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) or "
                     "'gloo' (test only: lets several ranks share one GPU)")
     ap.add_argument('--exec-batch', type=int, default=POP,
@@ -150,7 +154,7 @@ def main():
 
     from pix2latent_amd import _native as N
     torch.manual_seed(0)
-    opt, vm, problem = build_problem(dev, exec_batch_size=args.exec_batch)
+    opt, vm, problem = build_problem(dev, exec_batch_size=args.exec_batch, lpips_net=args.lpips_net)
     opt.setup_cma(vm)
     assert opt.num_samples == POP
     variables = opt.cma_init(vm)
@@ -194,6 +198,8 @@ def main():
 
     if rank == 0:
         evals = POP * args.steps
+        # generator fwd+dgrad 58.80 GMAC + LPIPS net fwd+dgrad (VGG16 40.08 | AlexNet 1.74 GMAC)
+        gflop_eval = GFLOP_PER_EVAL if args.lpips_net == 'vgg' else 2 * (58.80 + 1.737)
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
         # PMC counters cannot be read from inside the timed process: `traffic` is the
@@ -221,14 +227,16 @@ def main():
             'data': 'synthetic',
             'config': {
                 'workload': 'BigGAN-deep-256 BasinCMA inner step (pycma popsize 18, z in R^128): '
-                            'Clamp hook -> generator fwd -> weighted L1 + 10*LPIPS-VGG16 -> '
-                            'bwd to (z,c) -> Adam; 256x256 synthetic target',
+                            'Clamp hook -> generator fwd -> weighted L1 + 10*LPIPS-%s -> '
+                            'bwd to (z,c) -> Adam; 256x256 synthetic target'
+                            % ('VGG16' if args.lpips_net == 'vgg' else 'AlexNet'),
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
+                'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
-                'gflop_per_eval_basis': GFLOP_PER_EVAL,
-                'end_to_end_tflops': round(GFLOP_PER_EVAL * evals / elapsed / 1e3, 2),
+                'gflop_per_eval_basis': gflop_eval,
+                'end_to_end_tflops': round(gflop_eval * evals / elapsed / 1e3, 2),
                 'fwd_only_rescore_evals_per_s': round(rescore_rate, 1),
                 'last_losses_min_max': [round(min(last_loss), 5), round(max(last_loss), 5)],
                 'last_losses': [round(x, 6) for x in last_loss],

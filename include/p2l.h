@@ -424,6 +424,59 @@ int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
                      int H, int W, void* ws, size_t ws_bytes, float* dimg16,
                      void* stream);
 
+/* ---- LPIPS-AlexNet variant of the same loss --------------------------------------
+ * ProjectionLoss() defaults to lpips_net='alex' (pix2latent/loss_functions.py:87,131);
+ * every examples/invert_*.py uses that default.  torchvision alexnet.features:
+ * conv(3,64,11,s4,p2) | pool3/2 conv(64,192,5,p2) | pool3/2 conv(192,384,3,p1) |
+ * conv(384,256,3,p1) | conv(256,256,3,p1), ReLU after each = the 5 LPIPS taps.        */
+typedef struct P2LGConv {         /* generic NHWC conv: any size / stride / padding     */
+  int32_t B, Hi, Wi, Cin;         /* Cin % 16 == 0 (image: nhwc16)                      */
+  int32_t Cout;                   /* % 64 == 0                                          */
+  int32_t KH, KW, stride, pad;
+  int32_t x_ld, y_ld, res_ld, mask_ld;
+  int32_t n_store;                /* 0 = Cout                                           */
+  int32_t relu;
+  int32_t reserved0;
+} P2LGConv;
+/* y = [mask>0] relu?( conv(pro_s*x+pro_t zero-padded) + bias + res );
+ * w packed by p2l_pack_conv_weight(taps = KH*KW, K chunk 16).                          */
+int p2l_gconv_fwd(const P2LGConv* d, const float* x, const float* w_packed, const float* bias,
+                  const float* pro_s, const float* pro_t, const float* res, const float* mask,
+                  float* y, void* stream);
+/* 3x3 stride-2 max-pool, no padding (Ho = (Hi-3)/2+1)                                  */
+int p2l_maxpool3s2_fwd(const float* x, float* y, int Bn, int Hi, int Wi, int C, void* stream);
+/* dx = (pool-backward(gpooled) [first maximum in scan order] + gtap) * (x > 0)          */
+int p2l_maxpool3s2_bwd(const float* x, const float* gpooled, const float* gtap, float* dx,
+                       int Bn, int Hi, int Wi, int C, void* stream);
+/* input gradient of a strided KxK conv to the 3 image channels; w_t3: [K*K][3][Co]      */
+int p2l_conv1_dgrad(const float* g, const float* w_t3, float* dimg16, int Bn, int H, int W,
+                    int Co, int K, int S, int pad, void* stream);
+
+typedef struct P2LAlexLpips {
+  const float* w[5];              /* packed forward (conv0: Cin padded to 16)           */
+  const float* b[5];
+  const float* wt[5];             /* [1..4]: packed input-gradient; [0]: [121][3][64]
+                                     pre-multiplied by 1/scale (p2l_conv1_dgrad)        */
+  const float* lin[5];            /* [C_k] LPIPS linear weights, C = 64,192,384,256,256 */
+  const float* in_s;              /* [16] scaling layer: 1/scale (0 padded)             */
+  const float* in_t;              /* [16] -shift/scale                                  */
+} P2LAlexLpips;
+size_t p2l_alex_cache_floats(int Bn, int H, int W, size_t nft_off[5], size_t wt_off[5],
+                             size_t* wsum_off);
+size_t p2l_alexloss_ws_bytes(int Bn, int H, int W);
+int p2l_alexloss_prepare(const P2LAlexLpips* v, const float* target, const float* weight,
+                         const float* loss_mask, int Bn, int H, int W,
+                         const P2LLossCache* cache, void* ws, size_t ws_bytes, void* stream);
+int p2l_alexloss_fwd(const P2LAlexLpips* v, const float* img16, const float* target,
+                     const float* weight, const float* loss_mask, const P2LLossCache* cache,
+                     float beta, int use_lpips, int Bn, int H, int W, void* ws,
+                     size_t ws_bytes, float* loss, float* loss_l1, float* loss_lpips,
+                     void* stream);
+int p2l_alexloss_bwd(const P2LAlexLpips* v, const float* img16, const float* target,
+                     const float* weight, const float* loss_mask, const P2LLossCache* cache,
+                     float beta, int use_lpips, const float* gloss, int Bn, int H, int W,
+                     void* ws, size_t ws_bytes, float* dimg16, void* stream);
+
 /* Fused F.affine_grid + F.grid_sample (bilinear, zeros, align_corners=False) on NCHW
  * images; theta is [B][6] row-major 2x3.  Replaces the warps of
  * pix2latent/transform/spatial_transform.py:69-104 (SpatialTransform.transform /

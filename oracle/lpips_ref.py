@@ -7,9 +7,11 @@ side of the pix2latent hot path.
   (tools/make_golden.py).
 * The LPIPS network itself is PARITY UNPINNED: `lpips>=0.1`
   (requirements.txt:15; call sites loss_functions.py:15,131,142) and the
-  torchvision VGG16 weights are absent here.  `lpips_spatial` restates the
-  published algorithm of lpips.LPIPS(net='vgg', version='0.1', spatial=True)
-  from recall.
+  torchvision VGG16 / AlexNet weights are absent here.  `lpips_spatial` restates the
+  published algorithm of lpips.LPIPS(net='vgg'|'alex', version='0.1', spatial=True)
+  from recall.  The network is chosen by the keys of the weight dict
+  ('vgg.conv*' or 'alex.conv*'); 'alex' is the reference default
+  (loss_functions.py:87 `lpips_net='alex'`).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.
@@ -28,6 +30,15 @@ VGG_CFG = [(3, 64), (64, 64), 'M', (64, 128), (128, 128), 'M',
            (512, 512), (512, 512), (512, 512)]
 VGG_TAPS_AFTER_CONV = (1, 3, 6, 9, 12)   # 0-based conv indices whose ReLU output is tapped
 VGG_CHNS = (64, 128, 256, 512, 512)
+
+
+# torchvision alexnet.features [3P-recall]: conv(3,64,k11,s4,p2) relu | maxpool(3,2)
+# conv(64,192,k5,p2) relu | maxpool(3,2) conv(192,384,k3,p1) relu | conv(384,256,k3,p1)
+# relu | conv(256,256,k3,p1) relu ; lpips taps relu1..relu5
+ALEX_CFG = [(3, 64, 11, 4, 2), (64, 192, 5, 1, 2), (192, 384, 3, 1, 1), (384, 256, 3, 1, 1),
+            (256, 256, 3, 1, 1)]
+ALEX_POOL_BEFORE = (1, 2)      # 3x3 stride-2 max-pool in front of conv index 1 and 2
+ALEX_CHNS = (64, 192, 384, 256, 256)
 
 
 def l1_loss(out, target):                       # loss_functions.py:20-22
@@ -84,6 +95,19 @@ def vgg_features(Wv, x):
     return taps
 
 
+def alex_features(Wa, x):
+    """torchvision alexnet.features sliced as lpips.pretrained_networks.alexnet does
+    [3P-recall]: returns relu1 .. relu5."""
+    taps = []
+    for i, (_, _, k, s, p) in enumerate(ALEX_CFG):
+        if i in ALEX_POOL_BEFORE:
+            x = F.max_pool2d(x, 3, 2)
+        x = F.relu(F.conv2d(x, Wa['alex.conv%d.weight' % i], Wa['alex.conv%d.bias' % i],
+                            stride=s, padding=p))
+        taps.append(x)
+    return taps
+
+
 def normalize_tensor(f, eps=1e-10):
     """lpips.normalize_tensor [3P-recall]."""
     norm = torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True))
@@ -92,10 +116,11 @@ def normalize_tensor(f, eps=1e-10):
 
 def lpips_spatial(Wv, in0, in1):
     """lpips.LPIPS(net='vgg', spatial=True).forward(in0, in1) -> [B,1,H,W]  [3P-recall]."""
-    shift = torch.tensor(LPIPS_SHIFT).view(1, 3, 1, 1)
-    scale = torch.tensor(LPIPS_SCALE).view(1, 3, 1, 1)
-    f0 = vgg_features(Wv, (in0 - shift) / scale)
-    f1 = vgg_features(Wv, (in1 - shift) / scale)
+    shift = torch.tensor(LPIPS_SHIFT, dtype=in0.dtype).view(1, 3, 1, 1)
+    scale = torch.tensor(LPIPS_SCALE, dtype=in0.dtype).view(1, 3, 1, 1)
+    feats = alex_features if 'alex.conv0.weight' in Wv else vgg_features
+    f0 = feats(Wv, (in0 - shift) / scale)
+    f1 = feats(Wv, (in1 - shift) / scale)
     val = None
     for kk in range(len(f0)):
         d = (normalize_tensor(f0[kk]) - normalize_tensor(f1[kk])) ** 2

@@ -98,6 +98,17 @@ class P2LVggLpips(C.Structure):
                 ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
 
 
+class P2LGConv(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'B', 'Hi', 'Wi', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'x_ld', 'y_ld', 'res_ld',
+        'mask_ld', 'n_store', 'relu', 'reserved0')]
+
+
+class P2LAlexLpips(C.Structure):
+    _fields_ = [('w', C.c_void_p * 5), ('b', C.c_void_p * 5), ('wt', C.c_void_p * 5),
+                ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
+
+
 class P2LLossCache(C.Structure):
     _fields_ = [('nft', C.c_void_p * 5), ('wt', C.c_void_p * 5), ('wsum', C.c_void_p)]
 
@@ -128,6 +139,9 @@ EXPORTS = [
     'p2l_sg2_ws_bytes', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
     'p2l_sg2_mapping_bwd', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
     'p2l_conv_dgrad_arb', 'p2l_arb_finish',
+    'p2l_gconv_fwd', 'p2l_maxpool3s2_fwd', 'p2l_maxpool3s2_bwd', 'p2l_conv1_dgrad',
+    'p2l_alex_cache_floats', 'p2l_alexloss_ws_bytes', 'p2l_alexloss_prepare', 'p2l_alexloss_fwd',
+    'p2l_alexloss_bwd',
 ]
 
 _lib = None
@@ -148,7 +162,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.p2l_strerror.restype = C.c_char_p
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
-                     'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes'):
+                     'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
+                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

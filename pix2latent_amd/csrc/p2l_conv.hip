@@ -998,8 +998,9 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
 extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
                                     int N_pad, int K_pad, int transpose_flip,
                                     float* w_packed, void* stream) {
-  if (!w_oihw || !w_packed || (taps != 1 && taps != 9)) return P2L_EINVAL;
-  const int kc = (taps == 9) ? 16 : (K_pad % 32 == 0 ? 32 : 16);
+  // taps = KH*KW: 1 and 9 feed conv_mfma_kernel, anything else (25, 121) p2l_gconv_fwd
+  if (!w_oihw || !w_packed || taps < 1) return P2L_EINVAL;
+  const int kc = (taps != 1) ? 16 : (K_pad % 32 == 0 ? 32 : 16);
   const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
   if (K_pad % kc || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
   const size_t total = (size_t)taps * K_pad * N_pad;

@@ -473,9 +473,15 @@ __global__ void l1_bwd_kernel(const float* img16, const float* target,
 }
 
 // LPIPS: LP lanes cooperate on one pixel, each holding C/(4*LP) float4.
+// LP = largest power of two dividing C/4, capped at a wave (C = 192 -> 16 lanes x 3 float4)
+constexpr int lpips_lp(int c4) {
+  int lp = 1;
+  while (lp < 64 && c4 % (lp * 2) == 0) lp *= 2;
+  return lp;
+}
 template <int C>
 struct LpipsCfg {
-  static constexpr int LP = (C / 4 >= 64) ? 64 : C / 4;
+  static constexpr int LP = lpips_lp(C / 4);
   static constexpr int VPL = C / (4 * LP);
   static constexpr int PPW = 64 / LP;  // pixels per wave
 };
@@ -585,9 +591,12 @@ __global__ void bilinear_adjoint_kernel(const float* wsrc, float* wt, int H, int
   if (q >= h * w) return;
   const int qy = q / w, qx = q - qy * w;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-  const int ry = H / h, rx = W / w;
-  const int py0 = max(0, (qy - 1) * ry), py1 = min(H, (qy + 2) * ry);
-  const int px0 = max(0, (qx - 1) * rx), px1 = min(W, (qx + 2) * rx);
+  // conservative source range (any ratio, e.g. 63 -> 256): fy in (qy-1, qy+1); the exact
+  // membership test is inside the loop
+  const int py0 = qy == 0 ? 0 : max(0, (int)floorf((qy - 0.5f) / sy - 0.5f) - 1);
+  const int py1 = qy == h - 1 ? H : min(H, (int)ceilf((qy + 1.5f) / sy - 0.5f) + 2);
+  const int px0 = qx == 0 ? 0 : max(0, (int)floorf((qx - 0.5f) / sx - 0.5f) - 1);
+  const int px1 = qx == w - 1 ? W : min(W, (int)ceilf((qx + 1.5f) / sx - 0.5f) + 2);
   float acc = 0.f;
   for (int py = py0; py < py1; ++py) {
     const float fy = fmaxf(sy * (py + 0.5f) - 0.5f, 0.f);
@@ -917,7 +926,9 @@ extern "C" int p2l_l1_loss_bwd(const float* img16, const float* target,
   switch (C) {                          \
     case 64: CALL(64); break;           \
     case 128: CALL(128); break;         \
+    case 192: CALL(192); break;         \
     case 256: CALL(256); break;         \
+    case 384: CALL(384); break;         \
     case 512: CALL(512); break;         \
     default: return P2L_EUNSUP;         \
   }
@@ -934,7 +945,7 @@ extern "C" int p2l_lpips_normalize(const float* f, float* nf, int64_t P, int C,
 }
 
 extern "C" int p2l_lpips_tap_nblk(int P, int C) {
-  const int lp = (C / 4 >= 64) ? 64 : C / 4;
+  const int lp = lpips_lp(C / 4);
   return cdiv(P, 4 * (64 / lp));
 }
 
@@ -973,7 +984,7 @@ extern "C" int p2l_lpips_tap_bwd(const float* f, const float* nft,
 
 extern "C" int p2l_bilinear_adjoint(const float* wsrc, float* wt, int Bn, int H, int W,
                                     int h, int w, void* stream) {
-  if (H % h || W % w) return P2L_EINVAL;
+  if (h < 1 || w < 1 || h > H || w > W) return P2L_EINVAL;
   hipLaunchKernelGGL(bilinear_adjoint_kernel, dim3(cdiv(h * w, 256), Bn), dim3(256), 0,
                      ST(stream), wsrc, wt, H, W, h, w);
   return p2l_check_launch();

@@ -94,6 +94,7 @@ def weight_regularization(orig_model, curr_model, reg='l1', weight_dict=None):
 # ---------------------------------------------------------------------------
 class _VggLpipsParams(object):
     """packed VGG16 + LPIPS-lin parameters on the device (P2LVggLpips)."""
+    prefix = 'vgg'
 
     def __init__(self, weights, device):
         self.lib = N.lib()
@@ -136,14 +137,48 @@ class _VggLpipsParams(object):
         return dst.data_ptr()
 
 
+class _AlexLpipsParams(object):
+    """packed torchvision-AlexNet features + LPIPS-lin parameters (P2LAlexLpips)."""
+    prefix = 'alex'
+
+    def __init__(self, weights, device):
+        self.lib = N.lib()
+        self.dev = torch.device(device)
+        self.keep = []
+        self.desc = N.P2LAlexLpips()
+        inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
+        for i, (cin, cout, k) in enumerate(synthetic.ALEX_CONVS):
+            w = weights['alex.conv%d.weight' % i].float()
+            if i == 0:
+                self.desc.w[i] = self._pack(w, k * k, cout, 16, False)
+                # direct input-gradient kernel: [k*k][3][cout], 1/scale folded in
+                w3 = (w * inv_scale.view(1, 3, 1, 1)).permute(2, 3, 1, 0).reshape(k * k, 3, cout)
+                self.desc.wt[i] = self._t(w3)
+            else:
+                self.desc.w[i] = self._pack(w, k * k, cout, cin, False)
+                self.desc.wt[i] = self._pack(w, k * k, cin, cout, True)
+            self.desc.b[i] = self._t(weights['alex.conv%d.bias' % i])
+        for k in range(5):
+            self.desc.lin[k] = self._t(weights['lpips.lin%d.weight' % k].reshape(-1))
+        s16, t16 = torch.zeros(16), torch.zeros(16)
+        for c in range(3):
+            s16[c] = 1.0 / LPIPS_SCALE[c]
+            t16[c] = -LPIPS_SHIFT[c] / LPIPS_SCALE[c]
+        self.desc.in_s = self._t(s16)
+        self.desc.in_t = self._t(t16)
+
+    _t = _VggLpipsParams._t
+    _pack = _VggLpipsParams._pack
+
+
 class _CacheSlot(object):
     """target-dependent state of one (target, weight, loss_mask) chunk."""
 
-    def __init__(self, lib, B, H, W, dev):
+    def __init__(self, cache_floats, B, H, W, dev):
         nft_off = (C.c_size_t * 5)()
         wt_off = (C.c_size_t * 5)()
         wsum_off = C.c_size_t(0)
-        n = lib.p2l_loss_cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
+        n = cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
         self.buf = torch.empty(n, device=dev, dtype=torch.float32)
         self.desc = N.P2LLossCache()
         base = self.buf.data_ptr()
@@ -167,7 +202,16 @@ class _LossEngine(object):
 
     def __init__(self, vgg_params):
         self.lib = N.lib()
-        self.vgg = vgg_params
+        self.vgg = vgg_params          # _VggLpipsParams or _AlexLpipsParams
+        lib = self.lib
+        if vgg_params.prefix == 'alex':
+            self.f_ws, self.f_cache = lib.p2l_alexloss_ws_bytes, lib.p2l_alex_cache_floats
+            self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_alexloss_prepare, lib.p2l_alexloss_fwd,
+                                                      lib.p2l_alexloss_bwd)
+        else:
+            self.f_ws, self.f_cache = lib.p2l_projloss_ws_bytes, lib.p2l_loss_cache_floats
+            self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_projloss_prepare, lib.p2l_projloss_fwd,
+                                                      lib.p2l_projloss_bwd)
         self.shape = None
         self.ws = None
         self.slots = {}          # key -> _CacheSlot (insertion order = LRU order)
@@ -178,9 +222,9 @@ class _LossEngine(object):
     def _alloc(self, B, H, W, dev):
         if self.shape == (B, H, W):
             return
-        nbytes = self.lib.p2l_projloss_ws_bytes(B, H, W)
+        nbytes = self.f_ws(B, H, W)
         if nbytes == 0:
-            raise N.NativeError('p2l_projloss_ws_bytes rejected shape %s' % ((B, H, W),))
+            raise N.NativeError('loss workspace sizing rejected shape %s' % ((B, H, W),))
         self.ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         self.ws_bytes = nbytes
         self.img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
@@ -228,13 +272,11 @@ class _LossEngine(object):
             if len(self.slots) >= self.MAX_SLOTS:
                 slot = self.slots.pop(next(iter(self.slots)))     # recycle the LRU slot
             else:
-                slot = _CacheSlot(self.lib, B, H, W, out.device)
+                slot = _CacheSlot(self.f_cache, B, H, W, out.device)
             vref = C.byref(self.vgg.desc) if use_lpips else None
-            N.check(self.lib.p2l_projloss_prepare(vref, N.ptr(target), N.ptr(weight),
-                                                  N.ptr(loss_mask), B, H, W,
-                                                  C.byref(slot.desc), N.ptr(self.ws),
-                                                  C.c_size_t(self.ws_bytes), N.stream()),
-                    'p2l_projloss_prepare')
+            N.check(self.f_prepare(vref, N.ptr(target), N.ptr(weight), N.ptr(loss_mask), B, H, W,
+                                   C.byref(slot.desc), N.ptr(self.ws), C.c_size_t(self.ws_bytes),
+                                   N.stream()), 'p2l_%sloss_prepare' % self.vgg.prefix)
             # keep the tensors alive so that data_ptr identity stays meaningful
             slot.held = (target, weight, loss_mask)
         self.slots[key] = slot      # most recently used last
@@ -265,11 +307,11 @@ class _ProjLossFn(torch.autograd.Function):
         l1 = torch.empty_like(loss)
         lp = torch.empty_like(loss)
         vref = C.byref(eng.vgg.desc) if use_lpips else None
-        N.check(lib.p2l_projloss_fwd(vref, N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
-                                     N.ptr(loss_mask), C.byref(slot.desc), N.f32(beta),
-                                     use_lpips, B, H, W, N.ptr(eng.ws),
-                                     C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
-                                     N.ptr(lp), N.stream()), 'p2l_projloss_fwd')
+        N.check(eng.f_fwd(vref, N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
+                          N.ptr(loss_mask), C.byref(slot.desc), N.f32(beta),
+                          use_lpips, B, H, W, N.ptr(eng.ws),
+                          C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
+                          N.ptr(lp), N.stream()), 'p2l_%sloss_fwd' % eng.vgg.prefix)
         ctx.eng, ctx.beta, ctx.mode = eng, beta, mode
         ctx.save_for_backward(out_c, target, weight, loss_mask if loss_mask is not None
                               else torch.empty(0))
@@ -298,12 +340,12 @@ class _ProjLossFn(torch.autograd.Function):
             # LPIPS only: run the combined backward with the L1 term switched off
             raise N.NativeError('PerceptualLoss backward is only available through '
                                 'ProjectionLoss in this build')
-        N.check(lib.p2l_projloss_bwd(C.byref(eng.vgg.desc) if use_lpips else None,
-                                     N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
-                                     N.ptr(loss_mask), C.byref(ctx.slot.desc), N.f32(ctx.beta),
-                                     use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
-                                     C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
-                'p2l_projloss_bwd')
+        N.check(eng.f_bwd(C.byref(eng.vgg.desc) if use_lpips else None,
+                          N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
+                          N.ptr(loss_mask), C.byref(ctx.slot.desc), N.f32(ctx.beta),
+                          use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
+                          C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
+                'p2l_%sloss_bwd' % eng.vgg.prefix)
         dout = torch.empty(B, 3, H, W, device=out_c.device, dtype=torch.float32)
         N.check(lib.p2l_nhwc16_to_nchw3(N.ptr(eng.dimg16), N.ptr(dout), B, H, W, N.stream()),
                 'p2l_nhwc16_to_nchw3')
@@ -314,23 +356,29 @@ _VGG_PARAMS = {}
 
 
 def _vgg_params(net, weights, device):
-    if net != 'vgg':
-        raise NotImplementedError(
-            "lpips_net='%s': only the VGG16 LPIPS network has a native MI355X path in this "
-            "build (BASELINE north_star measures VGG16); pass lpips_net='vgg'" % net)
-    key = (id(weights), str(device))
+    """packed LPIPS network parameters: 'alex' (the reference default,
+    loss_functions.py:87) or 'vgg' (BASELINE north_star).  A weight dict keyed 'alex.conv*' /
+    'vgg.conv*' selects the network by itself."""
+    if weights is not None:
+        net = 'alex' if 'alex.conv0.weight' in weights else 'vgg'
+    if net in ('vgg16',):
+        net = 'vgg'
+    if net not in ('vgg', 'alex'):
+        raise NotImplementedError("lpips_net='%s': LPIPS networks with a native path are "
+                                  "'alex' and 'vgg'" % net)
+    key = (net, id(weights), str(device))
     if key not in _VGG_PARAMS:
         if weights is None:
-            path = os.environ.get('P2L_LPIPS_VGG_WEIGHTS')
+            path = os.environ.get('P2L_LPIPS_%s_WEIGHTS' % net.upper())
             if path:
                 w = torch.load(path, map_location='cpu')
             else:
-                warnings.warn('LPIPS-VGG16: no pretrained weights available (no network); '
-                              'using seeded random-init weights of the same architecture')
-                w = synthetic.lpips_vgg_weights()
+                warnings.warn('LPIPS-%s: no pretrained weights available (no network); using '
+                              'seeded random-init weights of the same architecture' % net)
+                w = synthetic.lpips_alex_weights() if net == 'alex' else synthetic.lpips_vgg_weights()
         else:
             w = weights
-        _VGG_PARAMS[key] = _VggLpipsParams(w, device)
+        _VGG_PARAMS[key] = (_AlexLpipsParams if net == 'alex' else _VggLpipsParams)(w, device)
     return _VGG_PARAMS[key]
 
 
@@ -342,8 +390,7 @@ def _native_ok(output, target, weight):
 class ProjectionLoss(nn.Module):
     """ The default loss that is used in the paper (reference loss_functions.py:86-100).
 
-    lpips_net keeps the reference default 'alex' in the signature, but only 'vgg'
-    has a native path; pass lpips_net='vgg'.
+    lpips_net: 'alex' (reference default) or 'vgg'; both are native HIP plans.
     """
 
     def __init__(self, lpips_net='alex', beta=10, weights=None, device='cuda'):

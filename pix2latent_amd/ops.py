@@ -229,3 +229,44 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
     N.check(_lib().p2l_conv_dgrad_arb(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
                                       N.ptr(dx), N.stream()), 'conv_dgrad_arb')
     return dx, ds, dt
+
+
+# ---- LPIPS-AlexNet building blocks (csrc/p2l_alex.hip) ---------------------------------
+def gconv(x, w_packed, B, Hi, Wi, Cin, Cout, K, stride, pad, bias=None, pro_s=None, pro_t=None,
+          res=None, mask=None, relu=False):
+    """generic NHWC conv (any size / stride / padding); x: [B,Hi,Wi,Cin] -> [B,Ho,Wo,Cout]"""
+    Ho, Wo = (Hi + 2 * pad - K) // stride + 1, (Wi + 2 * pad - K) // stride + 1
+    d = N.P2LGConv()
+    d.B, d.Hi, d.Wi, d.Cin, d.Cout = B, Hi, Wi, Cin, Cout
+    d.KH = d.KW = K
+    d.stride, d.pad = stride, pad
+    d.x_ld, d.y_ld, d.res_ld, d.mask_ld = x.shape[-1], Cout, Cout, Cout
+    d.relu = int(relu)
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device)
+    N.check(_lib().p2l_gconv_fwd(C.byref(d), N.ptr(x), N.ptr(w_packed), N.ptr(bias), N.ptr(pro_s),
+                                 N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y), N.stream()),
+            'gconv_fwd')
+    return y
+
+
+def maxpool3s2_fwd(x):
+    B, Hi, Wi, Cc = x.shape
+    y = torch.empty(B, (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1, Cc, device=x.device)
+    N.check(_lib().p2l_maxpool3s2_fwd(N.ptr(x), N.ptr(y), B, Hi, Wi, Cc, N.stream()), 'maxpool3s2_fwd')
+    return y
+
+
+def maxpool3s2_bwd(x, gpooled, gtap=None):
+    B, Hi, Wi, Cc = x.shape
+    dx = torch.empty_like(x)
+    N.check(_lib().p2l_maxpool3s2_bwd(N.ptr(x), N.ptr(gpooled), N.ptr(gtap), N.ptr(dx), B, Hi, Wi, Cc,
+                                      N.stream()), 'maxpool3s2_bwd')
+    return dx
+
+
+def conv1_dgrad(g, w_t3, H, W, K, S, pad):
+    B, Co = g.shape[0], g.shape[-1]
+    d = torch.empty(B, H, W, 16, device=g.device)
+    N.check(_lib().p2l_conv1_dgrad(N.ptr(g), N.ptr(w_t3), N.ptr(d), B, H, W, Co, K, S, pad, N.stream()),
+            'conv1_dgrad')
+    return d

@@ -9,7 +9,7 @@ state-dicts with the upstream key layout from seeded tensors).
   them out with `remove_spectral_norm` (utils/misc.py:150-157), i.e.
   W = weight_orig / (u^T . W_mat . v) with the stored u, v (eval mode, no power
   iteration).
-* torchvision `vgg16` `features.N.{weight,bias}` + lpips `lin{k}.model.1.weight`
+* torchvision `vgg16` / `alexnet` `features.N.{weight,bias}` + lpips `lin{k}.model.1.weight`
   (reference pix2latent/loss_functions.py:131).
 """
 import torch
@@ -98,6 +98,31 @@ def load_lpips_vgg(vgg16_sd, lpips_sd):
         out['vgg.conv%d.weight' % i] = w
         out['vgg.conv%d.bias' % i] = b
     for k, c in enumerate(synthetic.VGG_CHNS):
+        key = 'lin%d.model.1.weight' % k
+        w = lpips_sd[key].float()
+        if tuple(w.shape) != (1, c, 1, 1):
+            raise ValueError('lpips %s has shape %s' % (key, tuple(w.shape)))
+        out['lpips.lin%d.weight' % k] = w
+    return out
+
+
+_ALEX_FEATURE_IDX = (0, 3, 6, 8, 10)     # torchvision alexnet.features conv positions
+
+
+def load_lpips_alex(alexnet_sd, lpips_sd):
+    """torchvision alexnet state_dict + lpips v0.1 'alex' linear layers -> flat dict
+    ('alex.conv{i}.{weight,bias}', 'lpips.lin{k}.weight'), the format
+    `ProjectionLoss(weights=...)` / $P2L_LPIPS_ALEX_WEIGHTS take."""
+    out = {}
+    for i, idx in enumerate(_ALEX_FEATURE_IDX):
+        w = alexnet_sd['features.%d.weight' % idx].float()
+        b = alexnet_sd['features.%d.bias' % idx].float()
+        cin, cout, k = synthetic.ALEX_CONVS[i]
+        if tuple(w.shape) != (cout, cin, k, k):
+            raise ValueError('alexnet features.%d.weight has shape %s' % (idx, tuple(w.shape)))
+        out['alex.conv%d.weight' % i] = w
+        out['alex.conv%d.bias' % i] = b
+    for k, c in enumerate(synthetic.ALEX_CHNS):
         key = 'lin%d.model.1.weight' % k
         w = lpips_sd[key].float()
         if tuple(w.shape) != (1, c, 1, 1):

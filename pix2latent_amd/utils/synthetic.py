@@ -102,6 +102,23 @@ def lpips_vgg_weights(seed=1):
     return Wv
 
 
+ALEX_CONVS = [(3, 64, 11), (64, 192, 5), (192, 384, 3), (384, 256, 3), (256, 256, 3)]
+ALEX_CHNS = (64, 192, 384, 256, 256)
+
+
+def lpips_alex_weights(seed=2):
+    """seeded random-init torchvision-AlexNet features + lpips lin layers
+    (keys 'alex.conv{0..4}.{weight,bias}', 'lpips.lin{0..4}.weight')."""
+    g = torch.Generator().manual_seed(seed)
+    Wa = {}
+    for i, (cin, cout, k) in enumerate(ALEX_CONVS):
+        Wa['alex.conv%d.weight' % i] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))
+        Wa['alex.conv%d.bias' % i] = torch.randn(cout, generator=g) * 0.01
+    for k, c in enumerate(ALEX_CHNS):
+        Wa['lpips.lin%d.weight' % k] = (torch.rand(1, c, 1, 1, generator=g) / c)
+    return Wa
+
+
 def synthetic_target(size=256, seed=1):
     """smooth image in [-1,1] + a little noise, [3,size,size]."""
     g = torch.Generator().manual_seed(seed)

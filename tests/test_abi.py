@@ -52,6 +52,8 @@ def test_struct_layouts_match_c(lib):
     assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 14 * 8
     assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8
     assert C.sizeof(N.P2LLossCache) == 11 * 8
+    assert C.sizeof(N.P2LGConv) == 16 * 4
+    assert C.sizeof(N.P2LAlexLpips) == (5 * 4 + 2) * 8
 
 
 def test_host_side_planning_calls(lib):
@@ -86,7 +88,10 @@ def test_product_path_fails_loudly_without_gpu():
                         'generator.gen_z.bias': torch.zeros(8)}, device='cpu')
     import pix2latent_amd.loss_functions as LF
     with pytest.raises(NotImplementedError):
-        LF.ProjectionLoss(lpips_net='alex')
+        LF.ProjectionLoss(lpips_net='squeeze')
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    with pytest.raises(N.NativeError, match='no CPU fallback'):
+        StyleGAN2(weights={}, size=64, device='cpu')
 
 
 def test_oracle_not_imported_by_product():

@@ -55,6 +55,26 @@ def test_lpips_vgg_loader_key_mapping():
         assert torch.equal(out[k], Wv[k])
 
 
+def test_lpips_alex_loader_key_mapping():
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.utils.checkpoint import load_lpips_alex
+    Wa = S.lpips_alex_weights(5)
+    alex = {}
+    for i, n in enumerate((0, 3, 6, 8, 10)):
+        alex['features.%d.weight' % n] = Wa['alex.conv%d.weight' % i]
+        alex['features.%d.bias' % n] = Wa['alex.conv%d.bias' % i]
+    lp = {'lin%d.model.1.weight' % k: Wa['lpips.lin%d.weight' % k] for k in range(5)}
+    out = load_lpips_alex(alex, lp)
+    assert set(out) == set(Wa)
+    for k in Wa:
+        assert torch.equal(out[k], Wa[k])
+    bad = dict(alex)
+    bad['features.3.weight'] = torch.zeros(192, 64, 3, 3)
+    import pytest
+    with pytest.raises(ValueError):
+        load_lpips_alex(bad, lp)
+
+
 def test_save_variables_roundtrip(tmp_path):
     """result file layout read by the reference's editor (vars.input.z.data[i])"""
     from pix2latent_amd import VariableManager, save_variables
