@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 POP = 18
 MAX_BATCH = 9
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6      # dense v_mfma_f32_32x32x16_bf16 = 16 x the fp32 MFMA rate
 GFLOP_PER_EVAL = 197.8              # BASELINE.md §2 (conv_to_rgb sliced to 3 channels)
 
 
@@ -202,6 +203,7 @@ def main():
         gflop_eval = GFLOP_PER_EVAL if args.lpips_net == 'vgg' else 2 * (58.80 + 1.737)
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
+        bf3 = N.default_wfmt() == N.WFMT_BF16X3
         # PMC counters cannot be read from inside the timed process: `traffic` is the
         # committed result of the separate rocprofv3 --pmc passes over this same command
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
@@ -223,7 +225,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': ('f32 (3x3 convs: fp32-equivalent 3-way bf16 operand split on the bf16 MFMA '
+                      'pipe, 6 products, fp32 accumulate; everything else exact fp32)'
+                      if bf3 else 'f32'),
             'data': 'synthetic',
             'config': {
                 'workload': 'BigGAN-deep-256 BasinCMA inner step (pycma popsize 18, z in R^128): '
@@ -233,6 +237,7 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
+                'conv3x3_arithmetic': 'bf16x3' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'gflop_per_eval_basis': gflop_eval,
@@ -242,12 +247,20 @@ def main():
                 'last_losses': [round(x, 6) for x in last_loss],
             },
             'roofline': {
-                'kernel': 'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)',
+                'kernel': ('conv_mfma_kernel<TAPS=9,BF3> (3x3 implicit GEMM, 6 x '
+                           'v_mfma_f32_32x32x16_bf16 per 16 channels on 3-way split fp32 operands)'
+                           if bf3 else
+                           'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                 'bound': 'mfma',
                 'achieved': round(conv_tflops, 2),
-                'peak': FP32_MFMA_PEAK_TFLOPS,
+                # bf16x3: 6 bf16 MFMA products per fp32 product -> the matrix-pipe ceiling in
+                # algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 6
+                'peak': round(BF16_MFMA_PEAK_TFLOPS / 6, 1) if bf3 else FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
-                'frac': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                'frac': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
+                                             else FP32_MFMA_PEAK_TFLOPS), 4),
+                'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                'issued_bf16_mfma_tflops': round(6 * conv_tflops, 1) if bf3 else None,
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,

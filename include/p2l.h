@@ -85,7 +85,7 @@ typedef struct P2LConv {
   int32_t ext;      /* ups 2/3 only: 1 = stride-2 TRANSPOSED conv geometry: the   */
                     /* high-res buffer is [B,H+2,W+2,*] (rows/cols 0..H real,     */
                     /* H+1 zero) and the low-res grid of ups=2 has H/2+1 points   */
-  int32_t reserved0;
+  int32_t wfmt;     /* P2L_WFMT_*: format of w_packed (3x3 / sub-pixel only)       */
   double algo_flops; /* algorithmic FLOPs of this launch for the profiler;    */
                      /* 0 = 2*B*H*W*Cin*Cout*taps (set it when Cin/Cout are   */
                      /* zero-padded, e.g. the 3-channel image convs)          */
@@ -164,6 +164,21 @@ int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps, int N_pad,
 int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
                                 int K_pad, int transpose_flip, int mode,
                                 float* w_packed, void* stream);
+
+/* Weight formats of the 3x3 / sub-pixel conv kernels.
+ *   P2L_WFMT_F32   : fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ *   P2L_WFMT_BF16X3: fp32-EQUIVALENT arithmetic on the bf16 matrix pipe: each fp32 operand
+ *     is split into three bf16 pieces (x = x1+x2+x3 to 2^-24 relative) and the product is
+ *     accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 cross terms (dropped terms
+ *     <= 2^-23 relative).  gfx950 runs bf16 MFMA at 16x the fp32-MFMA rate, so this costs
+ *     2.67x fewer matrix cycles.  Weights are pre-split by the *_bf3 pack functions into
+ *     buffers of 1.5 x the fp32 packed size; activations are split inside the kernel.   */
+enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1 };
+int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
+                             int K_pad, int transpose_flip, float* w_packed, void* stream);
+int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                                    int transpose_flip, int mode, float* w_packed,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Batched GEMM fp32 (attention bmm's and their gradients).                  */
@@ -369,6 +384,8 @@ typedef struct P2LBigGAN {
   const float* rgb_w;             /* packed 3x3 ch -> 32 (3 real)            */
   const float* rgb_b;             /* [32]                                    */
   const float* rgb_wt;            /* packed input-gradient 16 (3 real) -> ch */
+  int32_t wfmt;                   /* P2L_WFMT_* of every 3x3 / sub-pixel weight */
+  int32_t reserved1;
 } P2LBigGAN;
 
 size_t p2l_biggan_ws_bytes(const P2LBigGAN* m, int Bn);
@@ -394,6 +411,8 @@ typedef struct P2LVggLpips {
   const float* lin[5];            /* [C_k] LPIPS linear weights               */
   const float* in_s;              /* [16] scaling layer: 1/scale (0 padded)   */
   const float* in_t;              /* [16] -shift/scale                        */
+  int32_t wfmt;                   /* P2L_WFMT_* of the 13 conv weights (both copies) */
+  int32_t reserved1;
 } P2LVggLpips;
 
 /* cached, target-dependent state (caller allocates):                         */
@@ -546,6 +565,8 @@ typedef struct P2LStyleGAN2 {
   const float* const_input;       /* [4][4][C0] NHWC                                   */
   P2LSg2Conv conv[P2L_SG2_MAX_CONVS];
   P2LSg2Rgb rgb[P2L_SG2_MAX_RGBS];
+  int32_t wfmt;                   /* P2L_WFMT_* of every styled-conv 3x3 weight          */
+  int32_t reserved1;
 } P2LStyleGAN2;
 size_t p2l_sg2_ws_bytes(const P2LStyleGAN2* m, int Bn);
 /* latent: [B, n_latent, 512] w+ rows (broadcast w for z-mode); noise: [B, noise_total]

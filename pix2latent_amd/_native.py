@@ -23,7 +23,7 @@ class P2LConv(C.Structure):
                 ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
                 ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
                 ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('ext', C.c_int32),
-                ('reserved0', C.c_int32), ('algo_flops', C.c_double)]
+                ('wfmt', C.c_int32), ('algo_flops', C.c_double)]
 
 
 class P2LArb(C.Structure):
@@ -67,7 +67,8 @@ class P2LBigGAN(C.Structure):
                 ('att_w', C.c_void_p * 4), ('att_wt', C.c_void_p * 4),
                 ('gamma', C.c_float),
                 ('tail_s', C.c_void_p), ('tail_t', C.c_void_p),
-                ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p), ('rgb_wt', C.c_void_p)]
+                ('rgb_w', C.c_void_p), ('rgb_b', C.c_void_p), ('rgb_wt', C.c_void_p),
+                ('wfmt', C.c_int32), ('reserved1', C.c_int32)]
 
 
 P2L_SG2_MAX_CONVS, P2L_SG2_MAX_RGBS = 20, 10
@@ -90,12 +91,14 @@ class P2LStyleGAN2(C.Structure):
     _fields_ = [('size', C.c_int32), ('n_conv', C.c_int32), ('n_rgb', C.c_int32),
                 ('style_dim', C.c_int32), ('n_latent', C.c_int32), ('noise_total', C.c_int32),
                 ('map_w', C.c_void_p * 8), ('map_b', C.c_void_p * 8), ('const_input', C.c_void_p),
-                ('conv', P2LSg2Conv * P2L_SG2_MAX_CONVS), ('rgb', P2LSg2Rgb * P2L_SG2_MAX_RGBS)]
+                ('conv', P2LSg2Conv * P2L_SG2_MAX_CONVS), ('rgb', P2LSg2Rgb * P2L_SG2_MAX_RGBS),
+                ('wfmt', C.c_int32), ('reserved1', C.c_int32)]
 
 
 class P2LVggLpips(C.Structure):
     _fields_ = [('w', C.c_void_p * 13), ('b', C.c_void_p * 13), ('wt', C.c_void_p * 13),
-                ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
+                ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p),
+                ('wfmt', C.c_int32), ('reserved1', C.c_int32)]
 
 
 class P2LGConv(C.Structure):
@@ -114,6 +117,18 @@ class P2LLossCache(C.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
+WFMT_F32, WFMT_BF16X3 = 0, 1
+
+
+def default_wfmt():
+    """weight / arithmetic format of the 3x3 convs: bf16x3 (fp32-equivalent on the bf16
+    matrix pipe, see include/p2l.h) unless P2L_CONV_WFMT=f32 asks for the exact-fp32 MFMA."""
+    v = os.environ.get('P2L_CONV_WFMT', 'bf16x3').lower()
+    if v in ('f32', 'fp32', '0'):
+        return WFMT_F32
+    if v in ('bf16x3', 'bf3', '1'):
+        return WFMT_BF16X3
+    raise ValueError('P2L_CONV_WFMT=%r (expected f32 or bf16x3)' % v)
 POOL_NONE, POOL_MAX, POOL_SUM = 0, 1, 2
 PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 
@@ -121,7 +136,8 @@ PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
-    'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
+    'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
+    'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',

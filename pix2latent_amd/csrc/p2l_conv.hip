@@ -236,12 +236,35 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
   }
 }
 
-template <int TAPS, int BN, int KC, int A_ITERS, int PRO, bool UPS>
+// BF3 = fp32-equivalent arithmetic on the bf16 matrix pipe (16x the fp32 MFMA rate):
+// every fp32 operand is split into three bf16 pieces x = x1 + x2 + x3 (round-to-nearest
+// residuals, |x - (x1+x2+x3)| <= 2^-24 |x|) and a.b is accumulated in fp32 from the six
+// products a1b1 a1b2 a2b1 a2b2 a1b3 a3b1 (the dropped a2b3 a3b2 a3b3 are <= 2^-23 |ab|),
+// i.e. 6 v_mfma_f32_32x32x16_bf16 (32 cycles each) instead of 8 v_mfma_f32_32x32x2_f32
+// (64 cycles each) per 16 channels: 2.67x fewer matrix cycles at fp32-level accuracy.
+// Activations are split while they are staged into LDS; weights are pre-split by
+// p2l_pack_conv_weight_bf3.  LDS row = [x1 k0-7 | x1 k8-15 | x2 .. | x3 ..] = 96 bytes with
+// the 16-byte chunk index XOR-ed with bit 3 of the row (16 consecutive rows then cover all
+// 64 banks exactly once per ds_read_b128, no padding).  The C layout is the same as the
+// fp32 instruction's, so the epilogues are shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = __builtin_convertvector(v, bf16x4);
+  const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+  m = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+  l = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int TAPS, int BN, int KC, int A_ITERS, int PRO, bool UPS, bool BF3 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
-  constexpr int PITCH = KC + 4;      // floats per LDS row
+  static_assert(!BF3 || KC == 16, "bf16x3 path works on 16-channel chunks");
+  constexpr int PITCH = BF3 ? 24 : KC + 4;   // floats per LDS row (BF3: 96 B, swizzled)
   constexpr int VPR = KC / 4;        // float4 per row
   constexpr int NT = BN / 32;        // accumulators per wave
-  constexpr int B_ITEMS = TAPS * BN * VPR;
+  constexpr int B_ITEMS = BF3 ? TAPS * BN * 6 : TAPS * BN * VPR;   // 16-byte items
   constexpr int B_ITERS = (B_ITEMS + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -349,11 +372,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     for (int it = 0; it < B_ITERS; ++it) {
       const int j = tid + 256 * it;
       if (j < B_ITEMS) {
-        const int tap = j / (BN * VPR);
-        const int rem = j - tap * (BN * VPR);  // row*VPR + v
-        const size_t off =
-            (((size_t)(wslab + tap) * ncc + cc) * k.Cout + n0) * KC + rem * 4;
-        wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
+        if (BF3) {
+          const int tap = j / (BN * 6);
+          const int rem = j - tap * (BN * 6);    // row*6 + 16-byte chunk
+          const size_t off = (((size_t)(wslab + tap) * ncc + cc) * k.Cout + n0) * 24 + rem * 4;
+          wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
+        } else {
+          const int tap = j / (BN * VPR);
+          const int rem = j - tap * (BN * VPR);  // row*VPR + v
+          const size_t off =
+              (((size_t)(wslab + tap) * ncc + cc) * k.Cout + n0) * KC + rem * 4;
+          wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
+        }
       }
     }
   };
@@ -373,15 +403,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           }
         }
         if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(As + a_loff[it]) = v;
+        if (BF3) {
+          // a_loff = row*24 + v*4 (floats): row base + which quarter of the 16 channels
+          const int row = a_loff[it] / 24, q4 = (a_loff[it] - row * 24) >> 2;
+          const int sw = (row >> 3) & 1;
+          bf16x4 ph, pm, pl;
+          split3(v, ph, pm, pl);
+          char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
+          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 0) ^ sw) * 16) = ph;
+          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 2) ^ sw) * 16) = pm;
+          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 4) ^ sw) * 16) = pl;
+        } else {
+          *reinterpret_cast<f32x4*>(As + a_loff[it]) = v;
+        }
       }
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
       const int j = tid + 256 * it;
       if (j < B_ITEMS) {
-        const int row = j / VPR, v = j - row * VPR;  // row = tap*BN + n
-        *reinterpret_cast<f32x4*>(Bs + row * PITCH + v * 4) = wr[it];
+        if (BF3) {
+          const int row = j / 6, c6 = j - row * 6;     // row = tap*BN + n
+          *reinterpret_cast<f32x4*>(Bs + row * 24 + ((c6 ^ ((row >> 3) & 1)) * 4)) = wr[it];
+        } else {
+          const int row = j / VPR, v = j - row * VPR;  // row = tap*BN + n
+          *reinterpret_cast<f32x4*>(Bs + row * PITCH + v * 4) = wr[it];
+        }
       }
     }
   };
@@ -402,6 +449,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
   const float* a_frag = As + a_row0 * PITCH + lhi * 4;
   const float* b_frag = Bs + l31 * PITCH + lhi * 4;
+  // BF3: B rows are tap*BN + j*32 + l31 (multiples of 16 + l31): swizzle bit from l31 only
+  const int b_sw = (l31 >> 3) & 1;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -435,6 +484,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
       const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
+      if (BF3) {
+        const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+        const int asw = (arow >> 3) & 1;
+        const float* ar = As + arow * 24;
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + ((0 + lhi) ^ asw) * 4);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + ((2 + lhi) ^ asw) * 4);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + ((4 + lhi) ^ asw) * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float* br = Bs + (tap * BN + j * 32 + l31) * 24;
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(br + ((0 + lhi) ^ b_sw) * 4);
+          const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(br + ((2 + lhi) ^ b_sw) * 4);
+          const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(br + ((4 + lhi) ^ b_sw) * 4);
+          // smallest terms first
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+        }
+        continue;
+      }
       const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
 #pragma unroll
       for (int kk = 0; kk < KC / 8; ++kk) {
@@ -518,9 +590,20 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
 
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
 // its input-gradient conv O->I (K=O, N=I, taps mirrored).
+// bf16x3 packed element: row (idx / 16) holds [x1 k0-15 | x2 k0-15 | x3 k0-15] (96 bytes)
+__device__ __forceinline__ void store_bf3(float* dst, size_t idx, float v) {
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  __bf16* row = reinterpret_cast<__bf16*>(dst) + (idx >> 4) * 48;
+  const int kk = (int)(idx & 15);
+  row[kk] = h; row[16 + kk] = m; row[32 + kk] = l;
+}
+
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
     const float* __restrict__ src, float* __restrict__ dst, int O, int I,
-    int taps, int N_pad, int K_pad, int kc, int flip) {
+    int taps, int N_pad, int K_pad, int kc, int flip, int bf3) {
   const size_t total = (size_t)taps * K_pad * N_pad;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -538,7 +621,8 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
   } else {
     if (n < I && c < O) v = src[((size_t)c * I + n) * taps + (taps - 1 - tap)];
   }
-  dst[idx] = v;
+  if (bf3) store_bf3(dst, idx, v);
+  else dst[idx] = v;
 }
 
 // Sub-pixel weights.  dst layout [16 slabs = phase*4 + tap][K_pad/16][N_pad][16]; each
@@ -568,7 +652,7 @@ __device__ __forceinline__ unsigned sp_tapset(int mode, int flip, int p, int i) 
 __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restrict__ src,
                                                           float* __restrict__ dst, int O, int I,
                                                           int N_pad, int K_pad, int flip,
-                                                          int mode) {
+                                                          int mode, int bf3) {
   const size_t per = (size_t)K_pad * N_pad;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= 16 * per) return;
@@ -591,7 +675,8 @@ __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restric
           v += flip ? src[((size_t)c * I + n) * 9 + dy * 3 + dx]
                     : src[((size_t)n * I + c) * 9 + dy * 3 + dx];
   }
-  dst[idx] = v;
+  if (bf3) store_bf3(dst, idx, v);
+  else dst[idx] = v;
 }
 
 // The GEMM M grid: output pixels, except in the sub-pixel modes (ups 2 / 3) where it is
@@ -637,12 +722,12 @@ int choose_bn(const P2LConv* d, int n_mtiles) {
   return (t32 < 0.93 * t64) ? 32 : 64;
 }
 
-template <int TAPS, int BN, int KC, int A_ITERS>
+template <int TAPS, int BN, int KC, int A_ITERS, bool BF3 = false>
 int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles, k.splitk), block(256);
 #define P2L_LAUNCH(PRO, UPS)                                                     \
   do {                                                                           \
-    auto kfn = conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS>;                \
+    auto kfn = conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS, BF3>;           \
     static bool attr_set = false;                                                \
     if (!attr_set) {                                                             \
       (void)hipFuncSetAttribute((const void*)kfn,                                \
@@ -705,6 +790,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (d->pool != P2L_POOL_NONE && !yp) return P2L_EINVAL;
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
+  if (d->wfmt != P2L_WFMT_F32 && (d->wfmt != P2L_WFMT_BF16X3 || d->taps != 9)) return P2L_EUNSUP;
   if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
   if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
   if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
@@ -808,13 +894,18 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.ups = 0;
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256);
-    size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * 20 * sizeof(float);
+    const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
+    size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
     if (lds_epi > lds_sp) lds_sp = lds_epi;
     dim3 grid(k.n_mtiles * k.n_ntiles, d->ups == 2 ? 4 : 1), block(256);
 #define P2L_LAUNCH_SP(BNV, AIT, PROV)                                                     \
     do {                                                                                  \
-      auto kfn = conv_mfma_kernel<4, BNV, 16, AIT, PROV, false>;                          \
+      if (bf3) { P2L_LAUNCH_SP2(BNV, AIT, PROV, true); } else { P2L_LAUNCH_SP2(BNV, AIT, PROV, false); } \
+    } while (0)
+#define P2L_LAUNCH_SP2(BNV, AIT, PROV, BF3V)                                              \
+    do {                                                                                  \
+      auto kfn = conv_mfma_kernel<4, BNV, 16, AIT, PROV, false, BF3V>;                    \
       static bool attr_set = false;                                                       \
       if (!attr_set) {                                                                    \
         (void)hipFuncSetAttribute((const void*)kfn,                                       \
@@ -836,6 +927,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
 #undef P2L_LAUNCH_SP_PRO
 #undef P2L_LAUNCH_SP
+#undef P2L_LAUNCH_SP2
     rc = p2l_check_launch();
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
@@ -860,7 +952,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
-  size_t lds = (size_t)(a_rows + d->taps * bn) * (kc + 4) * sizeof(float);
+  const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
+  size_t lds = (size_t)(a_rows + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
   {
     // the vectorised epilogue re-uses the staging LDS for 4 wave tiles of 32 x (bn+4)
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
@@ -869,6 +962,12 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
 
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256);
+    if (bf3) {
+      if (bn == 64) rc = small ? launch_conv<9, 64, 16, 3, true>(k, d->pro, d->ups, lds, st)
+                               : launch_conv<9, 64, 16, 5, true>(k, d->pro, d->ups, lds, st);
+      else          rc = small ? launch_conv<9, 32, 16, 3, true>(k, d->pro, d->ups, lds, st)
+                               : launch_conv<9, 32, 16, 5, true>(k, d->pro, d->ups, lds, st);
+    } else
     if (bn == 64) rc = small ? launch_conv<9, 64, 16, 3>(k, d->pro, d->ups, lds, st)
                              : launch_conv<9, 64, 16, 5>(k, d->pro, d->ups, lds, st);
     else          rc = small ? launch_conv<9, 32, 16, 3>(k, d->pro, d->ups, lds, st)
@@ -945,7 +1044,20 @@ extern "C" int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, in
   const size_t total = (size_t)16 * K_pad * N_pad;
   hipLaunchKernelGGL(pack_subpix_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, w_oihw, w_packed, O, I, N_pad, K_pad, transpose_flip,
-                     mode);
+                     mode, 0);
+  return p2l_check_launch();
+}
+
+extern "C" int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I, int N_pad,
+                                               int K_pad, int transpose_flip, int mode,
+                                               float* w_packed, void* stream) {
+  if (!w_oihw || !w_packed || mode < 0 || mode > 1) return P2L_EINVAL;
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  if (K_pad % 16 || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
+  const size_t total = (size_t)16 * K_pad * N_pad;
+  hipLaunchKernelGGL(pack_subpix_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, w_packed, O, I, N_pad, K_pad, transpose_flip,
+                     mode, 1);
   return p2l_check_launch();
 }
 
@@ -1006,6 +1118,20 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
   const size_t total = (size_t)taps * K_pad * N_pad;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256),
                      0, (hipStream_t)stream, w_oihw, w_packed, O, I, taps, N_pad,
-                     K_pad, kc, transpose_flip);
+                     K_pad, kc, transpose_flip, 0);
+  return p2l_check_launch();
+}
+
+// bf16x3 pre-split weights for the BF3 conv kernels: 1.5 x taps*K_pad*N_pad floats
+extern "C" int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
+                                        int K_pad, int transpose_flip, float* w_packed,
+                                        void* stream) {
+  if (!w_oihw || !w_packed || taps != 9) return P2L_EINVAL;
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  if (K_pad % 16 || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
+  const size_t total = (size_t)taps * K_pad * N_pad;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256),
+                     0, (hipStream_t)stream, w_oihw, w_packed, O, I, taps, N_pad,
+                     K_pad, 16, transpose_flip, 1);
   return p2l_check_launch();
 }

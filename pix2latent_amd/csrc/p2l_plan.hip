@@ -62,8 +62,14 @@ struct ConvCall {
   const float* ps = nullptr; const float* pt = nullptr; const float* res = nullptr;
   const float* mask = nullptr; float* y = nullptr; float* yp = nullptr;
 };
+// weight format of the 3x3 convs of the model whose plan is running on this thread
+// (set at every extern "C" entry from the model struct's wfmt)
+thread_local int g_plan_wfmt = P2L_WFMT_F32;
+
 ConvCall mk_conv(int B, int H, int W, int Cin, int Cout, int taps) {
   ConvCall c;
+  c.d.wfmt = (taps == 9) ? g_plan_wfmt : P2L_WFMT_F32;
+  c.d.ext = 0;
   c.d.B = B; c.d.H = H; c.d.W = W; c.d.Cin = Cin; c.d.Cout = Cout; c.d.taps = taps;
   c.d.ups = 0; c.d.x_ld = Cin; c.d.pro = P2L_PRO_NONE; c.d.pro_bstride = 0;
   c.d.alpha = 1.f; c.d.act = P2L_ACT_NONE; c.d.pool = P2L_POOL_NONE;
@@ -276,6 +282,7 @@ extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Li
 
 extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c, int B,
                               void* ws, size_t ws_bytes, float* img16, void* st) {
+  g_plan_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   BGLayout L;
   RET_IF(bg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !z || !c || !img16) return P2L_EWS;
@@ -376,6 +383,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
 extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_bytes,
                               const float* img16, float* dimg16, float* dz, float* dc,
                               void* st) {
+  g_plan_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   BGLayout L;
   RET_IF(bg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !img16 || !dimg16 || !dz || !dc)
@@ -627,6 +635,7 @@ extern "C" int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
                                     const float* weight, const float* loss_mask, int B,
                                     int H, int W, const P2LLossCache* cache, void* ws,
                                     size_t ws_bytes, void* st) {
+  g_plan_wfmt = v ? v->wfmt : P2L_WFMT_F32;
   PLLayout L;
   RET_IF(pl_layout(B, H, W, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !target) return P2L_EWS;
@@ -657,6 +666,7 @@ extern "C" int p2l_projloss_fwd(const P2LVggLpips* v, const float* img16,
                                 float beta, int use_lpips, int B, int H, int W, void* ws,
                                 size_t ws_bytes, float* loss, float* loss_l1,
                                 float* loss_lpips, void* st) {
+  g_plan_wfmt = v ? v->wfmt : P2L_WFMT_F32;
   PLLayout L;
   RET_IF(pl_layout(B, H, W, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !img16 || !loss) return P2L_EWS;
@@ -687,6 +697,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
                                 const float* loss_mask, const P2LLossCache* cache,
                                 float beta, int use_lpips, const float* gloss, int B, int H,
                                 int W, void* ws, size_t ws_bytes, float* dimg16, void* st) {
+  g_plan_wfmt = v ? v->wfmt : P2L_WFMT_F32;
   PLLayout L;
   RET_IF(pl_layout(B, H, W, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !img16 || !gloss || !dimg16)

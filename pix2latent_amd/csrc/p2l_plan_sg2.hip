@@ -86,8 +86,11 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   return P2L_OK;
 }
 
+thread_local int g_sg_wfmt = P2L_WFMT_F32;   // set at the synthesis entry points
+
 P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
   P2LConv d{};
+  d.wfmt = (taps == 9) ? g_sg_wfmt : P2L_WFMT_F32;
   d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.Cout = Cout; d.taps = taps;
   d.x_ld = Cin; d.alpha = 1.f; d.y_ld = Cout; d.yp_ld = Cout; d.n_store = Cout; d.splitk = 1;
   return d;
@@ -153,6 +156,7 @@ extern "C" int p2l_sg2_mapping_bwd(const P2LStyleGAN2* m, const float* z, const 
 extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
                                      const float* noise, int B, void* ws, size_t ws_bytes,
                                      float* img16, void* st) {
+  g_sg_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   SgLayout L;
   RET_IF(sg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !latent || !noise || !img16) return P2L_EWS;
@@ -227,6 +231,7 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
                                      const float* noise, int B, void* ws, size_t ws_bytes,
                                      const float* dimg16, float* dlatent, float* dnoise,
                                      void* st) {
+  g_sg_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   SgLayout L;
   RET_IF(sg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !dimg16 || !dlatent) return P2L_EWS;

@@ -101,6 +101,8 @@ class _VggLpipsParams(object):
         self.dev = torch.device(device)
         self.keep = []
         self.desc = N.P2LVggLpips()
+        self.wfmt = N.default_wfmt()       # all 13 convs are 3x3
+        self.desc.wfmt = self.wfmt
         inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
         for i, (cin, cout) in enumerate(synthetic.VGG_CONVS):
             w = weights['vgg.conv%d.weight' % i].float()
@@ -129,9 +131,15 @@ class _VggLpipsParams(object):
     def _pack(self, w, taps, n_pad, k_pad, flip):
         O, I = w.shape[0], w.shape[1]
         src = w.detach().to(self.dev, torch.float32).contiguous()
-        dst = torch.empty(taps * n_pad * k_pad, device=self.dev, dtype=torch.float32)
-        N.check(self.lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                              N.ptr(dst), N.stream()), 'p2l_pack_conv_weight')
+        if taps == 9 and getattr(self, 'wfmt', N.WFMT_F32) == N.WFMT_BF16X3:
+            dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=self.dev, dtype=torch.float32)
+            N.check(self.lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad,
+                                                      int(flip), N.ptr(dst), N.stream()),
+                    'p2l_pack_conv_weight_bf3')
+        else:
+            dst = torch.empty(taps * n_pad * k_pad, device=self.dev, dtype=torch.float32)
+            N.check(self.lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
+                                                  N.ptr(dst), N.stream()), 'p2l_pack_conv_weight')
         torch.cuda.current_stream().synchronize()
         self.keep.append(dst)
         return dst.data_ptr()
@@ -204,7 +212,8 @@ class _LossEngine(object):
         self.lib = N.lib()
         self.vgg = vgg_params          # _VggLpipsParams or _AlexLpipsParams
         lib = self.lib
-        if vgg_params.prefix == 'alex':
+        self.prefix = getattr(vgg_params, 'prefix', 'vgg')     # None = L1-only engine
+        if self.prefix == 'alex':
             self.f_ws, self.f_cache = lib.p2l_alexloss_ws_bytes, lib.p2l_alex_cache_floats
             self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_alexloss_prepare, lib.p2l_alexloss_fwd,
                                                       lib.p2l_alexloss_bwd)
@@ -276,7 +285,7 @@ class _LossEngine(object):
             vref = C.byref(self.vgg.desc) if use_lpips else None
             N.check(self.f_prepare(vref, N.ptr(target), N.ptr(weight), N.ptr(loss_mask), B, H, W,
                                    C.byref(slot.desc), N.ptr(self.ws), C.c_size_t(self.ws_bytes),
-                                   N.stream()), 'p2l_%sloss_prepare' % self.vgg.prefix)
+                                   N.stream()), 'p2l_%sloss_prepare' % self.prefix)
             # keep the tensors alive so that data_ptr identity stays meaningful
             slot.held = (target, weight, loss_mask)
         self.slots[key] = slot      # most recently used last
@@ -311,7 +320,7 @@ class _ProjLossFn(torch.autograd.Function):
                           N.ptr(loss_mask), C.byref(slot.desc), N.f32(beta),
                           use_lpips, B, H, W, N.ptr(eng.ws),
                           C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
-                          N.ptr(lp), N.stream()), 'p2l_%sloss_fwd' % eng.vgg.prefix)
+                          N.ptr(lp), N.stream()), 'p2l_%sloss_fwd' % eng.prefix)
         ctx.eng, ctx.beta, ctx.mode = eng, beta, mode
         ctx.save_for_backward(out_c, target, weight, loss_mask if loss_mask is not None
                               else torch.empty(0))
@@ -345,7 +354,7 @@ class _ProjLossFn(torch.autograd.Function):
                           N.ptr(loss_mask), C.byref(ctx.slot.desc), N.f32(ctx.beta),
                           use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
                           C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
-                'p2l_%sloss_bwd' % eng.vgg.prefix)
+                'p2l_%sloss_bwd' % eng.prefix)
         dout = torch.empty(B, 3, H, W, device=out_c.device, dtype=torch.float32)
         N.check(lib.p2l_nhwc16_to_nchw3(N.ptr(eng.dimg16), N.ptr(dout), B, H, W, N.stream()),
                 'p2l_nhwc16_to_nchw3')
@@ -366,7 +375,7 @@ def _vgg_params(net, weights, device):
     if net not in ('vgg', 'alex'):
         raise NotImplementedError("lpips_net='%s': LPIPS networks with a native path are "
                                   "'alex' and 'vgg'" % net)
-    key = (net, id(weights), str(device))
+    key = (net, id(weights), str(device), N.default_wfmt())
     if key not in _VGG_PARAMS:
         if weights is None:
             path = os.environ.get('P2L_LPIPS_%s_WEIGHTS' % net.upper())

@@ -87,7 +87,7 @@ class BigGAN(nn.Module):
     """
 
     def __init__(self, model_version='biggan-deep-256', weights=None, device='cuda',
-                 seed=0):
+                 seed=0, wfmt=None):
         super(BigGAN, self).__init__()
         if model_version != 'biggan-deep-256':
             raise ValueError('only biggan-deep-256 is implemented, got %s' % model_version)
@@ -117,6 +117,9 @@ class BigGAN(nn.Module):
         self.generator = _GeneratorView(weights)
         self._keep = []          # device tensors referenced by the C struct
         self._desc = N.P2LBigGAN()
+        # arithmetic of the 3x3 convs: bf16x3 split (fp32-equivalent, default) or exact fp32
+        self._wfmt = N.default_wfmt() if wfmt is None else wfmt
+        self._desc.wfmt = self._wfmt
         self._ws = None
         self._ws_B = -1
         self._ticket = 0
@@ -133,10 +136,16 @@ class BigGAN(nn.Module):
     def _pack_conv(self, w, taps, n_pad, k_pad, flip):
         O, I = w.shape[0], w.shape[1]
         src = w.detach().to(self._dev, torch.float32).contiguous()
-        dst = torch.empty(taps * n_pad * k_pad, device=self._dev, dtype=torch.float32)
-        N.check(self._lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad,
-                                               int(flip), N.ptr(dst), N.stream()),
-                'p2l_pack_conv_weight')
+        if taps == 9 and self._wfmt == N.WFMT_BF16X3:
+            dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=self._dev, dtype=torch.float32)
+            N.check(self._lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad,
+                                                       int(flip), N.ptr(dst), N.stream()),
+                    'p2l_pack_conv_weight_bf3')
+        else:
+            dst = torch.empty(taps * n_pad * k_pad, device=self._dev, dtype=torch.float32)
+            N.check(self._lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad,
+                                                   int(flip), N.ptr(dst), N.stream()),
+                    'p2l_pack_conv_weight')
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst
@@ -144,10 +153,16 @@ class BigGAN(nn.Module):
     def _pack_subpix(self, w, n_pad, k_pad, flip):
         O, I = w.shape[0], w.shape[1]
         src = w.detach().to(self._dev, torch.float32).contiguous()
-        dst = torch.empty(16 * n_pad * k_pad, device=self._dev, dtype=torch.float32)
-        N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 0,
-                                                      N.ptr(dst), N.stream()),
-                'p2l_pack_conv_weight_subpix')
+        if self._wfmt == N.WFMT_BF16X3:
+            dst = torch.empty(16 * n_pad * k_pad * 3 // 2, device=self._dev, dtype=torch.float32)
+            N.check(self._lib.p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad,
+                                                              int(flip), 0, N.ptr(dst), N.stream()),
+                    'p2l_pack_conv_weight_subpix_bf3')
+        else:
+            dst = torch.empty(16 * n_pad * k_pad, device=self._dev, dtype=torch.float32)
+            N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 0,
+                                                          N.ptr(dst), N.stream()),
+                    'p2l_pack_conv_weight_subpix')
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst

@@ -96,7 +96,8 @@ class _MappingFn(torch.autograd.Function):
 
 
 class StyleGAN2(nn.Module):
-    def __init__(self, model='cars', search='z', weights=None, size=None, device='cuda', seed=0):
+    def __init__(self, model='cars', search='z', weights=None, size=None, device='cuda', seed=0,
+                 wfmt=None):
         super(StyleGAN2, self).__init__()
         self._dev = torch.device(device)
         if self._dev.type != 'cuda':
@@ -115,6 +116,8 @@ class StyleGAN2(nn.Module):
         self._lib = N.lib()
         self._keep = []
         self._desc = N.P2LStyleGAN2()
+        self._wfmt = N.default_wfmt() if wfmt is None else wfmt
+        self._desc.wfmt = self._wfmt
         self._ws, self._ws_B, self._ticket = None, -1, 0
         self._pack(weights)
         self.search = search
@@ -141,8 +144,15 @@ class StyleGAN2(nn.Module):
         O, I = w.shape[0], w.shape[1]
         src = w.detach().to(self._dev, torch.float32).contiguous()
         n = (16 if subpix else taps) * n_pad * k_pad
-        dst = torch.empty(n, device=self._dev, dtype=torch.float32)
-        if subpix:
+        bf3 = taps == 9 and self._wfmt == N.WFMT_BF16X3
+        dst = torch.empty(n * 3 // 2 if bf3 else n, device=self._dev, dtype=torch.float32)
+        if subpix and bf3:
+            N.check(self._lib.p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+                                                              1, N.ptr(dst), N.stream()), 'pack_subpix_bf3')
+        elif bf3:
+            N.check(self._lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
+                                                       N.ptr(dst), N.stream()), 'pack_conv_bf3')
+        elif subpix:
             N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 1,
                                                           N.ptr(dst), N.stream()), 'pack_subpix')
         else:

@@ -22,18 +22,29 @@ def mfma_probe(A, B):
     return Cm
 
 
-def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False):
+def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False, wfmt=N.WFMT_F32):
     O, I = w_oihw.shape[0], w_oihw.shape[1]
     src = w_oihw.contiguous().float()
+    if wfmt == N.WFMT_BF16X3:
+        dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=src.device)
+        N.check(_lib().p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
+                                                N.ptr(dst), N.stream()), 'pack_conv_weight_bf3')
+        return dst
     dst = torch.empty(taps * n_pad * k_pad, device=src.device)
     N.check(_lib().p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
                                         N.ptr(dst), N.stream()), 'pack_conv_weight')
     return dst
 
 
-def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0):
+def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0, wfmt=N.WFMT_F32):
     O, I = w_oihw.shape[0], w_oihw.shape[1]
     src = w_oihw.contiguous().float()
+    if wfmt == N.WFMT_BF16X3:
+        dst = torch.empty(16 * n_pad * k_pad * 3 // 2, device=src.device)
+        N.check(_lib().p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad, int(flip),
+                                                       mode, N.ptr(dst), N.stream()),
+                'pack_subpix_bf3')
+        return dst
     dst = torch.empty(16 * n_pad * k_pad, device=src.device)
     N.check(_lib().p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), mode,
                                                N.ptr(dst), N.stream()), 'pack_subpix')
@@ -43,8 +54,9 @@ def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0):
 def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
-         splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0):
+         splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0, wfmt=N.WFMT_F32):
     d = N.P2LConv()
+    d.wfmt = wfmt
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.ups = int(ups)
     d.x_ld = x_ld if x_ld is not None else Cin
@@ -201,10 +213,11 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
 
 
 def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
-                   skip=None, skip_C=0, skip_ups=False, subpix=False):
+                   skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32):
     """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
     H, W = resolution of dy; Cin = channels of dy, Cout = channels of x."""
     d = N.P2LConv()
+    d.wfmt = wfmt
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.x_ld = Cin
     d.alpha = 1.0

@@ -50,7 +50,7 @@ def test_struct_layouts_match_c(lib):
     assert C.sizeof(N.P2LConv) == 22 * 4 + 8
     assert C.sizeof(N.P2LGemm) == 7 * 4 + 4 + 3 * 8 + 4 * 4
     assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 14 * 8
-    assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8
+    assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8 + 8
     assert C.sizeof(N.P2LLossCache) == 11 * 8
     assert C.sizeof(N.P2LGConv) == 16 * 4
     assert C.sizeof(N.P2LAlexLpips) == (5 * 4 + 2) * 8

@@ -59,9 +59,17 @@ CONV_CASES = [
 ]
 
 
+WFMTS = [0, 1]        # P2L_WFMT_F32 (exact fp32 MFMA), P2L_WFMT_BF16X3 (3-way bf16 split, 6 products)
+
+
+@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: '-'.join('%s%s' % (k, v) for k, v in c.items()))
-def test_conv_fwd(dev, O, case):
+def test_conv_fwd(dev, O, case, wfmt):
+    """both weight formats must meet the SAME tolerance: bf16x3 is an fp32-equivalent
+    arithmetic (include/p2l.h P2L_WFMT_BF16X3), not a reduced-precision mode"""
     from pix2latent_amd import _native as N
+    if wfmt and case['taps'] != 9:
+        pytest.skip('bf16x3 applies to the 3x3 kernels')
     g = torch.Generator().manual_seed(1)
     B, H, Cin, Cout, taps = case['B'], case['H'], case['Cin'], case['Cout'], case['taps']
     k = 3 if taps == 9 else 1
@@ -110,8 +118,8 @@ def test_conv_fwd(dev, O, case):
     n_store = case.get('n_store')
     kc = 16 if taps == 9 else 32
     assert Cin % kc == 0
-    wp = O.pack_conv_weight(w.to(dev), taps, Cout, Cin)
-    y, yp = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, taps,
+    wp = O.pack_conv_weight(w.to(dev), taps, Cout, Cin, wfmt=wfmt)
+    y, yp = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, taps, wfmt=wfmt,
                    bias=bias.to(dev) if bias is not None else None, pro=pro, pro_s=ps, pro_t=pt,
                    pro_bstride=Cin if ps is not None else 0, ups=ups,
                    alpha=case.get('alpha', 1.0), act=act, pool=pool, res=res_t,
@@ -129,8 +137,9 @@ def test_conv_fwd(dev, O, case):
         assert relerr(got, exp) < tol, 'pooled'
 
 
+@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 96)])
-def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout):
+def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
     """3x3 conv on a nearest-x2 upsampled input in sub-pixel form (ups=2) and its
     input-gradient (ups=3) against F.interpolate + F.conv2d and autograd."""
     from pix2latent_amd import _native as N
@@ -145,18 +154,19 @@ def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout):
     y_ref = F.conv2d(F.interpolate(a, scale_factor=2, mode='nearest'), w, bias, padding=1)
     dy = torch.randn(B, Cout, 2 * h, 2 * h, generator=g)
     y_ref.backward(dy)
-    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin)
-    y, _ = O.conv(nhwc(x, dev), wsp, B, 2 * h, 2 * h, Cin, Cout, 9, bias=bias.to(dev),
+    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin, wfmt=wfmt)
+    y, _ = O.conv(nhwc(x, dev), wsp, B, 2 * h, 2 * h, Cin, Cout, 9, bias=bias.to(dev), wfmt=wfmt,
                   pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin, ups=2)
     torch.cuda.synchronize()
     assert relerr(nchw(y), y_ref.detach()) < 2e-5
-    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True)
-    da, _ = O.conv(nhwc(dy, dev), wtsp, B, 2 * h, 2 * h, Cout, Cin, 9, ups=3)
+    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True, wfmt=wfmt)
+    da, _ = O.conv(nhwc(dy, dev), wtsp, B, 2 * h, 2 * h, Cout, Cin, 9, ups=3, wfmt=wfmt)
     torch.cuda.synchronize()
     assert relerr(nchw(da), a.grad) < 2e-5
 
 
-def test_conv_subpixel_dgrad_fused_arb(dev, O):
+@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
+def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
     g = torch.Generator().manual_seed(14)
     B, C, Co, h = 2, 64, 64, 16
     x = torch.randn(B, C, h, h, generator=g, requires_grad=True)
@@ -166,9 +176,9 @@ def test_conv_subpixel_dgrad_fused_arb(dev, O):
     dy = torch.randn(B, Co, 2 * h, 2 * h, generator=g)
     a = F.interpolate(F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1)), scale_factor=2, mode='nearest')
     F.conv2d(a, w, None, padding=1).backward(dy)
-    wt = O.pack_conv_weight_subpix(w.to(dev), C, Co, flip=True)
+    wt = O.pack_conv_weight_subpix(w.to(dev), C, Co, flip=True, wfmt=wfmt)
     dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, 2 * h, 2 * h, Co, C, 9, nhwc(x.detach(), dev),
-                                  s.detach().to(dev), t.detach().to(dev), C, subpix=True)
+                                  s.detach().to(dev), t.detach().to(dev), C, subpix=True, wfmt=wfmt)
     torch.cuda.synchronize()
     assert relerr(nchw(dx), x.grad) < 2e-5
     assert relerr(ds.cpu(), s.grad) < 5e-5
@@ -184,7 +194,7 @@ def test_conv_fwd_v2_variants(dev, O, case, variant):
     from pix2latent_amd import _native as N
     N.check(N.lib().p2l_set_conv_variant(variant))
     try:
-        test_conv_fwd(dev, O, case)
+        test_conv_fwd(dev, O, case, 0)
     finally:
         N.check(N.lib().p2l_set_conv_variant(-1))
 
@@ -210,9 +220,10 @@ def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
     assert relerr(nchw(dx)[:, :Cin], x.grad) < 2e-5
 
 
+@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('taps,ups,skip', [(9, False, None), (9, True, None), (1, False, 'same'),
                                            (1, False, 'ups')])
-def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip):
+def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt):
     """dgrad conv with the consumer's CBN+ReLU backward (and GenBlock shortcut gradient)
     fused into its epilogue, vs autograd through relu(x*s+t) -> (nearest x2) -> conv."""
     g = torch.Generator().manual_seed(12)
@@ -238,9 +249,11 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip):
         sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
         exp_dx[:, :C // 2] += F.avg_pool2d(sk, 2, 2) * 4
         sk_t, skip_C = nhwc(sk, dev), C // 2
-    wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True)
+    if wfmt and taps != 9:
+        pytest.skip('bf16x3 applies to the 3x3 kernels')
+    wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True, wfmt=wfmt)
     dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, Ho, Ho, Co, C, taps, nhwc(x.detach(), dev),
-                                  s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups,
+                                  s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups, wfmt=wfmt,
                                   skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'))
     torch.cuda.synchronize()
     assert relerr(nchw(dx), exp_dx) < 2e-5
