@@ -250,6 +250,14 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// position of logical 16-byte chunk c (0..5) inside LDS row `row`: lowest bit XOR-ed with
+// bit 3 of the row.  Rows 8 or 24 apart start on the same bank (96-byte pitch = 24 dwords)
+// and get distinct 16-byte windows this way; a window may only move by +-4 dwords (row
+// bases are multiples of 8 dwords), so rows 16 apart - which the 2x2-quad pixel order does
+// put into one ds_read_b128 lane group - still collide: measured 19 % of LDS cycles, at
+// 33 % LDS utilisation (a rotation over all 6 chunks was tried: 46 % conflicts).
+__device__ __forceinline__ int bf3_chunk(int c, int row) { return c ^ ((row >> 3) & 1); }
+
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
   h = __builtin_convertvector(v, bf16x4);
   const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
@@ -406,13 +414,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         if (BF3) {
           // a_loff = row*24 + v*4 (floats): row base + which quarter of the 16 channels
           const int row = a_loff[it] / 24, q4 = (a_loff[it] - row * 24) >> 2;
-          const int sw = (row >> 3) & 1;
           bf16x4 ph, pm, pl;
           split3(v, ph, pm, pl);
           char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
-          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 0) ^ sw) * 16) = ph;
-          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 2) ^ sw) * 16) = pm;
-          *reinterpret_cast<bf16x4*>(rb + (((q4 >> 1) + 4) ^ sw) * 16) = pl;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 0, row) * 16) = ph;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 2, row) * 16) = pm;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 4, row) * 16) = pl;
         } else {
           *reinterpret_cast<f32x4*>(As + a_loff[it]) = v;
         }
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       if (j < B_ITEMS) {
         if (BF3) {
           const int row = j / 6, c6 = j - row * 6;     // row = tap*BN + n
-          *reinterpret_cast<f32x4*>(Bs + row * 24 + ((c6 ^ ((row >> 3) & 1)) * 4)) = wr[it];
+          *reinterpret_cast<f32x4*>(Bs + row * 24 + bf3_chunk(c6, row) * 4) = wr[it];
         } else {
           const int row = j / VPR, v = j - row * VPR;  // row = tap*BN + n
           *reinterpret_cast<f32x4*>(Bs + row * PITCH + v * 4) = wr[it];
@@ -449,8 +456,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
   const float* a_frag = As + a_row0 * PITCH + lhi * 4;
   const float* b_frag = Bs + l31 * PITCH + lhi * 4;
-  // BF3: B rows are tap*BN + j*32 + l31 (multiples of 16 + l31): swizzle bit from l31 only
-  const int b_sw = (l31 >> 3) & 1;
+  // BF3: B rows are tap*BN + j*32 + l31 (multiples of 32 + l31): rotation from l31 only
+  const int b_c1 = bf3_chunk(0 + lhi, l31) * 4, b_c2 = bf3_chunk(2 + lhi, l31) * 4,
+            b_c3 = bf3_chunk(4 + lhi, l31) * 4;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -486,25 +494,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
       if (BF3) {
         const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
-        const int asw = (arow >> 3) & 1;
         const float* ar = As + arow * 24;
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + ((0 + lhi) ^ asw) * 4);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + ((2 + lhi) ^ asw) * 4);
-        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + ((4 + lhi) ^ asw) * 4);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+        bf16x8 b1[NT], b2[NT], b3[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float* br = Bs + (tap * BN + j * 32 + l31) * 24;
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(br + ((0 + lhi) ^ b_sw) * 4);
-          const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(br + ((2 + lhi) ^ b_sw) * 4);
-          const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(br + ((4 + lhi) ^ b_sw) * 4);
-          // smallest terms first
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+          b1[j] = *reinterpret_cast<const bf16x8*>(br + b_c1);
+          b2[j] = *reinterpret_cast<const bf16x8*>(br + b_c2);
+          b3[j] = *reinterpret_cast<const bf16x8*>(br + b_c3);
         }
+        // smallest terms first; the NT accumulators alternate so that consecutive MFMAs
+        // never depend on each other
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[j], acc[j], 0, 0, 0);
         continue;
       }
       const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
