@@ -1,0 +1,34 @@
+"""inner-step time vs local candidate count (what one rank of an N-GPU job runs:
+pop 18 -> 18 | 9 | 5,4 | 3,2 candidates per rank)"""
+import os, sys, time, warnings
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+warnings.simplefilter('ignore')
+from pix2latent_amd import VariableManager, distribution
+from pix2latent_amd.utils import synthetic as S, function_hooks as hook
+from pix2latent_amd.model.biggan import BigGAN
+from pix2latent_amd.optimizer import GradientOptimizer
+import pix2latent_amd.loss_functions as LF
+dev = 'cuda'
+W, Wv = S.biggan_weights(0), S.lpips_vgg_weights(1)
+model = BigGAN(weights=W, device=dev)
+loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
+target, weight = S.synthetic_target(256, 1), S.synthetic_weight_mask(256)
+NS = (int(os.environ["P2L_ONLY_N"]),) if os.environ.get("P2L_ONLY_N") else (18, 9, 5, 3, 2)
+for n in NS:
+    vm = VariableManager(device=dev)
+    vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(), learning_rate=0.05,
+                hook_fn=hook.Clamp(2.0))
+    vm.register('c', (128,), 'input', default=0.05 * torch.randn(128), learning_rate=0.01)
+    vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=target)
+    vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, exec_batch_size=n)
+    variables = vm.initialize(num_samples=n)
+    for i in range(3):
+        opt.step(variables, optimize=True, transform=(i == 0))
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(8):
+        opt.step(variables, optimize=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / 8 * 1e3
+    print('local candidates %2d: %.2f ms/step  %.0f evals/s per GPU  (%.2f ms per candidate)' % (n, ms, n / ms * 1e3, ms / n))
