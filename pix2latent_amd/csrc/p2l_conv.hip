@@ -632,316 +632,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
 }
 
-// bf16x3 3x3 / sub-pixel conv, software-pipelined per TAP ROW: a stage = one row of taps
-// (3 taps of the 3x3, 2 of a sub-pixel phase) of one 16-channel chunk.  The activation tile
-// of a chunk and the weight rows of a stage are double-buffered in LDS (2 x 17 KB + 2 x
-// 18 KB at BN = 64, still 2 blocks per CU), so the stores of stage s+1 go into the idle
-// buffers while other waves are still in the MFMAs of stage s: ONE barrier per stage and no
-// separate write phase (the single-buffered loop above needs two barriers per chunk and
-// parks every wave while the tile is rewritten; PMC: 27 % of wave cycles in s_waitcnt /
-// s_barrier).  Staging registers for the weights drop from 14 to 5 float4.
-template <int TAPS, int BN, int A_ITERS, int PRO, bool UPS>
-__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const ConvK k) {
-  constexpr int KC = 16;
-  constexpr bool BF3 = true;
-  static_assert(TAPS == 9 || TAPS == 4, "tap-row pipeline is for the 3x3 / sub-pixel kernels");
-  constexpr int TR = (TAPS == 9) ? 3 : 2;      // taps per row = stages per chunk
-  static_assert(!BF3 || KC == 16, "bf16x3 path works on 16-channel chunks");
-  constexpr int PITCH = BF3 ? 24 : KC + 4;   // floats per LDS row (BF3: 96 B, swizzled)
-  constexpr int VPR = KC / 4;        // float4 per row
-  constexpr int NT = BN / 32;        // accumulators per wave
-  constexpr int B_ITEMS = TR * BN * 6;         // 16-byte items of ONE tap row
-  constexpr int B_ITERS = (B_ITEMS + 255) / 256;
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
-  const int HW_ = TW + 2, HH_ = TH + 2;
-  const int a_rows = (TAPS != 1) ? TB * HH_ * HW_ : 128;
-  // [A buf 0 | A buf 1 | B buf 0 | B buf 1]
-  float* const As0 = smem;
-  float* const Bs0 = smem + 2 * a_rows * PITCH;
-  constexpr int B_BUF = TR * BN * PITCH;
-  const int A_BUF = a_rows * PITCH;
-
-  // ---- which tile -------------------------------------------------------
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
-  const int tiles_per_image = k.tiles_x * k.tiles_y;
-  const int bt = mt / tiles_per_image;
-  const int tile_in_image = mt - bt * tiles_per_image;
-  const int ty = tile_in_image / k.tiles_x, tx = tile_in_image - ty * k.tiles_x;
-  const int n0 = nt * BN;
-  const int y0 = ty << k.th_log, x0 = tx << k.tw_log, b0 = bt << k.tb_log;
-
-  // blockIdx.y: split-K slice, or (sub-pixel forward) the output phase
-  const bool sp_fwd = (TAPS == 4) && k.sp_mode == 1;
-  const bool sp_bwd = (TAPS == 4) && k.sp_mode == 2;
-  const int z = sp_fwd ? 0 : blockIdx.y;
-  const int ph_y = sp_fwd ? (int)(blockIdx.y >> 1) : 0, ph_x = sp_fwd ? (int)(blockIdx.y & 1) : 0;
-  const int c_begin = z * k.chunks_per_split;
-  const int c_end = min(k.nchunks, c_begin + k.chunks_per_split);
-
-  // ---- per-thread staging descriptors (fixed across chunks) --------------
-  // Loads are issued unconditionally from a clamped (always valid) address and
-  // zeroed at LDS-write time: a divergent "load or zero" makes hipcc branch
-  // around every load and drain vmcnt per element.
-  int a_goff[A_ITERS];   // float offset of the source pixel's chunk-0 vector
-  int a_soff[A_ITERS];   // float offset into pro_s / pro_t
-  int a_loff[A_ITERS];   // LDS float offset, -1 = no item
-  unsigned a_valid = 0;  // bit it: source pixel exists (else zero padding)
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
-    const int j = tid + 256 * it;
-    const int p = j / VPR, v = j - p * VPR;
-    a_goff[it] = 0;
-    a_soff[it] = 0;
-    a_loff[it] = (p < a_rows) ? p * PITCH + v * 4 : -1;
-    if (p < a_rows) {
-      int tb, iy, ix;
-      if (TAPS != 1) {
-        tb = p / (HH_ * HW_);
-        const int rem = p - tb * (HH_ * HW_);
-        const int hy = rem / HW_, hx = rem - hy * HW_;
-        iy = y0 + hy - 1;
-        ix = x0 + hx - 1;
-      } else {
-        const int Q = p >> 2, s = p & 3;
-        const int qx = Q & ((TW >> 1) - 1);
-        const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
-        tb = Q >> (k.tw_log + k.th_log - 2);
-        iy = y0 + 2 * qy + (s >> 1);
-        ix = x0 + 2 * qx + (s & 1);
-      }
-      const int b = b0 + tb;
-      if (b < k.B && iy >= 0 && iy < k.iH && ix >= 0 && ix < k.iW) {
-        int pix;
-        if (UPS)
-          pix = (b * (k.H >> 1) + (iy >> 1)) * (k.W >> 1) + (ix >> 1);
-        else if (sp_bwd)      // phase plane (0,0) of the high-res gradient buffer
-          pix = (b * k.ibH + 2 * iy) * k.ibW + 2 * ix;
-        else
-          pix = (b * k.ibH + iy) * k.ibW + ix;
-        a_goff[it] = pix * k.x_ld + v * 4;
-        a_soff[it] = b * k.pro_bstride + v * 4;
-        a_valid |= 1u << it;
-      }
-    }
-  }
-
-  f32x4 xr[A_ITERS], sr[A_ITERS], tr[A_ITERS], wr[B_ITERS];
-
-  // sub-pixel input-gradient: chunk c = (phase plane cls, channel chunk cc)
-  auto chunk_geom = [&](int c, int& cc, int& wslab, int& a_extra, int& ncc) {
-    cc = c; wslab = 0; a_extra = 0;
-    if (TAPS == 4) {
-      if (sp_bwd) {
-        const int cls = c / k.sp_ncc;
-        cc = c - cls * k.sp_ncc;
-        wslab = cls * 4;
-        a_extra = ((cls >> 1) * k.ibW + (cls & 1)) * k.x_ld;
-      } else {
-        wslab = (ph_y * 2 + ph_x) * 4;
-      }
-    }
-    ncc = (TAPS == 4 && sp_bwd) ? k.sp_ncc : k.nchunks;
-  };
-  auto load_a = [&](int c) {
-    int cc, wslab, a_extra, ncc;
-    chunk_geom(c, cc, wslab, a_extra, ncc);
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)(a_goff[it] + a_extra) + cc * KC);
-      if (PRO != P2L_PRO_NONE) {
-        sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + a_soff[it] + cc * KC);
-        tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + a_soff[it] + cc * KC);
-      }
-    }
-  };
-  // stage s = (chunk c, tap row r): weights of taps r*TR .. r*TR+TR-1
-  auto load_b = [&](int c, int r) {
-    int cc, wslab, a_extra, ncc;
-    chunk_geom(c, cc, wslab, a_extra, ncc);
-#pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int j = tid + 256 * it;
-      if (j < B_ITEMS) {
-        const int t = j / (BN * 6);
-        const int rem = j - t * (BN * 6);      // row*6 + 16-byte chunk
-        const size_t off =
-            (((size_t)(wslab + r * TR + t) * ncc + cc) * k.Cout + n0) * 24 + rem * 4;
-        wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
-      }
-    }
-  };
-  auto write_a = [&](float* As) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      if (a_loff[it] >= 0) {
-        f32x4 v = xr[it];
-        if (PRO != P2L_PRO_NONE) {
-          v = v * sr[it] + tr[it];
-          if (PRO == P2L_PRO_AFFINE_RELU) {
-            v.x = fmaxf(v.x, 0.f);
-            v.y = fmaxf(v.y, 0.f);
-            v.z = fmaxf(v.z, 0.f);
-            v.w = fmaxf(v.w, 0.f);
-          }
-        }
-        if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row = a_loff[it] / 24, q4 = (a_loff[it] - row * 24) >> 2;
-        bf16x4 ph, pm, pl;
-        split3(v, ph, pm, pl);
-        char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
-        *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 0, row) * 16) = ph;
-        *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 2, row) * 16) = pm;
-        *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 4, row) * 16) = pl;
-      }
-    }
-  };
-  auto write_b = [&](float* Bs) {
-#pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int j = tid + 256 * it;
-      if (j < B_ITEMS) {
-        const int row = j / 6, c6 = j - row * 6;     // row = t*BN + n
-        *reinterpret_cast<f32x4*>(Bs + row * 24 + bf3_chunk(c6, row) * 4) = wr[it];
-      }
-    }
-  };
-
-  // ---- fragment addressing ----------------------------------------------
-  int a_row0;
-  {
-    const int i = wave * 32 + l31;
-    if (TAPS != 1) {
-      const int Q = i >> 2, s = i & 3;
-      const int qx = Q & ((TW >> 1) - 1);
-      const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
-      const int tb = Q >> (k.tw_log + k.th_log - 2);
-      a_row0 = (tb * HH_ + 2 * qy + (s >> 1)) * HW_ + 2 * qx + (s & 1);
-    } else {
-      a_row0 = i;
-    }
-  }
-  // BF3: B rows are tap*BN + j*32 + l31 (multiples of 32 + l31): rotation from l31 only
-  const int b_c1 = bf3_chunk(0 + lhi, l31) * 4, b_c2 = bf3_chunk(2 + lhi, l31) * 4,
-            b_c3 = bf3_chunk(4 + lhi, l31) * 4;
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  const int n_stage = (c_end - c_begin) * TR;
-  if (n_stage > 0) {
-    load_a(c_begin);
-    load_b(c_begin, 0);
-    write_a(As0);
-    write_b(Bs0);
-  }
-  __syncthreads();
-
-  for (int s = 0; s < n_stage; ++s) {
-    const int ci = s / TR, r = s - ci * TR;
-    const int c = c_begin + ci;
-    const bool more_b = (s + 1 < n_stage);
-    const bool more_a = (r == 0) && (c + 1 < c_end);
-    if (more_b) load_b(r + 1 < TR ? c : c + 1, r + 1 < TR ? r + 1 : 0);
-    if (more_a) load_a(c + 1);            // two more stages to land before it is written
-
-    const float* As = As0 + (ci & 1) * A_BUF;
-    const float* Bs = Bs0 + (s & 1) * B_BUF;
-    // window origin inside the halo: 3x3 -> (0,0); sub-pixel forward -> the output
-    // phase; sub-pixel input-gradient -> (1 - plane parity)
-    int win_row = 0;
-    if (TAPS == 4) {
-      int oy = ph_y, ox = ph_x;
-      if (sp_bwd) {
-        const int cls = c / k.sp_ncc;
-        oy = 1 - (cls >> 1);
-        ox = 1 - (cls & 1);
-      }
-      win_row = oy * HW_ + ox;
-    }
-#pragma unroll
-    for (int t = 0; t < TR; ++t) {
-      const int arow = a_row0 + win_row + r * HW_ + t;      // tap (dy = r, dx = t)
-      const float* ar = As + arow * 24;
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
-      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
-      bf16x8 b1[NT], b2[NT], b3[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float* br = Bs + (t * BN + j * 32 + l31) * 24;
-        b1[j] = *reinterpret_cast<const bf16x8*>(br + b_c1);
-        b2[j] = *reinterpret_cast<const bf16x8*>(br + b_c2);
-        b3[j] = *reinterpret_cast<const bf16x8*>(br + b_c3);
-      }
-      // smallest terms first; the NT accumulators alternate so that consecutive MFMAs
-      // never depend on each other
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[j], acc[j], 0, 0, 0);
-    }
-    // stores of the next stage go to the buffers nobody reads in this stage: B[(s+1)&1] was
-    // last read in stage s-1 and A[(ci+1)&1] in chunk ci-1, both behind the previous barrier
-    if (more_b) write_b(Bs0 + ((s + 1) & 1) * B_BUF);
-    if (r == TR - 1 && c + 1 < c_end) write_a(As0 + ((ci + 1) & 1) * A_BUF);
-    __syncthreads();
-  }
-
-  // ---- epilogue -----------------------------------------------------------
-  // lane owns column n of 4 quads (g): Q = wave*8 + 2g + lhi, 4 sub-pixels each
-  int q_pix0[4], q_b[4], q_oy[4], q_ox[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int Q = wave * 8 + 2 * g + lhi;
-    const int qx = Q & ((TW >> 1) - 1);
-    const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
-    const int tb = Q >> (k.tw_log + k.th_log - 2);
-    q_b[g] = b0 + tb;
-    q_oy[g] = y0 + 2 * qy;
-    q_ox[g] = x0 + 2 * qx;
-    q_pix0[g] = (q_b[g] * k.H + q_oy[g]) * k.W + q_ox[g];
-  }
-  if (k.splitk > 1) {
-    const size_t mtot = (size_t)k.B * k.H * k.W;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 32 + l31;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (q_b[g] >= k.B) continue;
-        float* wp = k.ws + ((size_t)z * mtot + (size_t)q_pix0[g]) * k.Cout + n;
-        wp[0] = acc[j][g * 4 + 0];
-        wp[k.Cout] = acc[j][g * 4 + 1];
-        wp[(size_t)k.W * k.Cout] = acc[j][g * 4 + 2];
-        wp[(size_t)(k.W + 1) * k.Cout] = acc[j][g * 4 + 3];
-      }
-    }
-  } else {
-    epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image,
-                     sp_fwd ? 1 : 0, ph_y, ph_x);
-  }
-}
-
-
 // Deterministic split-K finish: one thread per (quad, channel).
 __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
   const int Hh = k.H >> 1, Wh = k.W >> 1;
@@ -1102,15 +792,12 @@ int choose_bn(const P2LConv* d, int n_mtiles) {
   return (t32 < 0.93 * t64) ? 32 : 64;
 }
 
-// The tap-row pipelined bf16x3 kernel (conv_bf3_kernel) measured SLOWER than the
-// single-buffered loop (149-166 vs 158-183 TFLOP/s on the 64..512-channel layers: three
-// barriers + three vmcnt drains per chunk cost more than the separate write phase they
-// remove), so it is compiled out; kept as the starting point for a deeper-prefetch version.
-constexpr bool kTapRowPipeline = false;
+// (A tap-row pipelined, double-buffered variant of the bf16x3 kernel - one barrier per 3 taps
+// instead of two per chunk - measured slower, 149-166 vs 158-188 TFLOP/s, and was removed;
+// see DESIGN.md 4.1 and the repository history.)
 template <int TAPS, int BN, int KC, int A_ITERS, int PRO, bool UPS, bool BF3>
 constexpr auto pick_kernel() {
-  if constexpr (BF3 && TAPS != 1 && kTapRowPipeline) return conv_bf3_kernel<TAPS, BN, A_ITERS, PRO, UPS>;
-  else return conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS, BF3>;
+  return conv_mfma_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS, BF3>;
 }
 
 template <int TAPS, int BN, int KC, int A_ITERS, bool BF3 = false>
@@ -1286,9 +973,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256) && k.tb_log == 0;
     const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
-    // bf16x3: double-buffered activation tile + double-buffered tap row (2 taps)
-    size_t lds_sp = (bf3 && kTapRowPipeline) ? (size_t)(2 * a_rows_sp + 2 * 2 * bn) * 24 * sizeof(float)
-                        : (size_t)(a_rows_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
+    size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
     if (lds_epi > lds_sp) lds_sp = lds_epi;
     dim3 grid(k.n_mtiles * k.n_ntiles, d->ups == 2 ? 4 : 1), block(256);
@@ -1346,8 +1031,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
   const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
-  size_t lds = (bf3 && kTapRowPipeline) ? (size_t)(2 * a_rows + 2 * 3 * bn) * 24 * sizeof(float)
-                   : (size_t)(a_rows + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
+  size_t lds = (size_t)(a_rows + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
   {
     // the vectorised epilogue re-uses the staging LDS for 4 wave tiles of 32 x (bn+4)
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
