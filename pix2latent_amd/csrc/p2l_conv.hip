@@ -388,9 +388,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       const int j = tid + 256 * it;
       if (j < B_ITEMS) {
         if (BF3) {
-          const int tap = j / (BN * 6);
-          const int rem = j - tap * (BN * 6);    // row*6 + 16-byte chunk
-          const size_t off = (((size_t)(wslab + tap) * ncc + cc) * k.Cout + n0) * 24 + rem * 4;
+          // tile-image layout: span t of this block = TAPS*32 rows of 32-channel tile
+          // n0/32 + t, chunk cc; item j copies 16 bytes, LDS offset = global span offset
+          constexpr int SPAN = TAPS * 32 * 6;                 // 16-byte items per span
+          constexpr int SL = (TAPS == 4) ? 16 : TAPS;         // slabs per (chunk, tile)
+          const int t = (NT > 1 && j >= SPAN) ? 1 : 0;
+          const size_t off =
+              ((((size_t)cc * (k.Cout >> 5) + (n0 >> 5) + t) * SL + wslab) * 32) * 24 +
+              (size_t)(j - t * SPAN) * 4;
           wr[it] = *reinterpret_cast<const f32x4*>(k.w + off);
         } else {
           const int tap = j / (BN * VPR);
@@ -437,8 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       const int j = tid + 256 * it;
       if (j < B_ITEMS) {
         if (BF3) {
-          const int row = j / 6, c6 = j - row * 6;     // row = tap*BN + n
-          *reinterpret_cast<f32x4*>(Bs + row * 24 + bf3_chunk(c6, row) * 4) = wr[it];
+          *reinterpret_cast<f32x4*>(Bs + j * 4) = wr[it];     // already in LDS order
         } else {
           const int row = j / VPR, v = j - row * VPR;  // row = tap*BN + n
           *reinterpret_cast<f32x4*>(Bs + row * PITCH + v * 4) = wr[it];
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
   const float* a_frag = As + a_row0 * PITCH + lhi * 4;
   const float* b_frag = Bs + l31 * PITCH + lhi * 4;
-  // BF3: B rows are tap*BN + j*32 + l31 (multiples of 32 + l31): rotation from l31 only
+  // BF3: B rows are (j*TAPS + tap)*32 + l31 (multiples of 32 + l31): swizzle bit from l31 only
   const int b_c1 = bf3_chunk(0 + lhi, l31) * 4, b_c2 = bf3_chunk(2 + lhi, l31) * 4,
             b_c3 = bf3_chunk(4 + lhi, l31) * 4;
 
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         a[2] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
       };
       auto ldb = [&](int tap, int j, bf16x8 (&b)[3]) {
-        const float* br = Bs + (tap * BN + j * 32 + l31) * 24;
+        const float* br = Bs + ((j * TAPS + tap) * 32 + l31) * 24;     // [n-tile][tap][row]
         b[0] = *reinterpret_cast<const bf16x8*>(br + b_c1);
         b[1] = *reinterpret_cast<const bf16x8*>(br + b_c2);
         b[2] = *reinterpret_cast<const bf16x8*>(br + b_c3);
@@ -661,14 +665,25 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
 // its input-gradient conv O->I (K=O, N=I, taps mirrored).
 // bf16x3 packed element: row (idx / 16) holds [x1 k0-15 | x2 k0-15 | x3 k0-15] (96 bytes)
-__device__ __forceinline__ void store_bf3(float* dst, size_t idx, float v) {
+// bf16x3 packed weights are an IMAGE of the kernel's LDS weight tile, so staging them is a
+// flat copy (no per-item index arithmetic in the K loop):
+//   [16-channel chunk q][32-channel tile n/32][slab (tap, or phase*4+tap)][row n%32][96 bytes]
+// with the 96-byte row = [x1 k0-7 | x1 k8-15 | x2 .. | x3 ..] and the 16-byte chunk index
+// already XOR-swizzled by bit 3 of the row (bf3_chunk).  A block reads BN/32 contiguous spans
+// of TAPS*32 rows.
+__device__ __forceinline__ void store_bf3(float* dst, int n_slabs, int N_pad, int slab, int q, int n,
+                                          int kk, float v) {
   const __bf16 h = (__bf16)v;
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
-  __bf16* row = reinterpret_cast<__bf16*>(dst) + (idx >> 4) * 48;
-  const int kk = (int)(idx & 15);
-  row[kk] = h; row[16 + kk] = m; row[32 + kk] = l;
+  const int r = n & 31;
+  const size_t row = (((size_t)q * (N_pad >> 5) + (n >> 5)) * n_slabs + slab) * 32 + r;
+  __bf16* rp = reinterpret_cast<__bf16*>(dst) + row * 48;
+  const int hi = kk >> 3, lo = kk & 7;
+  rp[bf3_chunk(0 + hi, r) * 8 + lo] = h;
+  rp[bf3_chunk(2 + hi, r) * 8 + lo] = m;
+  rp[bf3_chunk(4 + hi, r) * 8 + lo] = l;
 }
 
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(
   } else {
     if (n < I && c < O) v = src[((size_t)c * I + n) * taps + (taps - 1 - tap)];
   }
-  if (bf3) store_bf3(dst, idx, v);
+  if (bf3) store_bf3(dst, taps, N_pad, tap, q, n, kk, v);
   else dst[idx] = v;
 }
 
@@ -745,7 +760,7 @@ __global__ __launch_bounds__(256) void pack_subpix_kernel(const float* __restric
           v += flip ? src[((size_t)c * I + n) * 9 + dy * 3 + dx]
                     : src[((size_t)n * I + c) * 9 + dy * 3 + dx];
   }
-  if (bf3) store_bf3(dst, idx, v);
+  if (bf3) store_bf3(dst, 16, N_pad, slab, q, n, kk, v);
   else dst[idx] = v;
 }
 
