@@ -250,6 +250,8 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+constexpr bool kDmaWeights = true;   // bf16x3 3x3: weight tile by LDS-direct DMA (see the kernel)
+
 // position of logical 16-byte chunk c (0..5) inside LDS row `row`: lowest bit XOR-ed with
 // bit 3 of the row.  Rows 8 or 24 apart start on the same bank (96-byte pitch = 24 dwords)
 // and get distinct 16-byte windows this way; a window may only move by +-4 dwords (row
@@ -477,66 +479,175 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  if (c_begin < c_end) {
-    load_regs(c_begin);
-    write_lds();
-  }
-  __syncthreads();
-
-  for (int c = c_begin; c < c_end; ++c) {
-    const bool more = (c + 1 < c_end);
-    if (more) load_regs(c + 1);
-
-    // window origin inside the halo: 3x3 -> (0,0); sub-pixel forward -> the output
-    // phase; sub-pixel input-gradient -> (1 - plane parity)
-    int win0 = 0;
-    if (TAPS == 4) {
-      int oy = ph_y, ox = ph_x;
-      if (sp_bwd) {
-        const int cls = c / k.sp_ncc;
-        oy = 1 - (cls >> 1);
-        ox = 1 - (cls & 1);
-      }
-      win0 = (oy * HW_ + ox) * PITCH;
+  // ---- bf16x3 3x3 / sub-pixel: weights by LDS-direct DMA -----------------------------
+  // The packed weights are an image of the LDS tile, so a lane's 16 bytes go global -> LDS
+  // with global_load_lds_dwordx4: no staging registers, no ds_write, no index math.  The
+  // tile is split by taps into two halves whose item counts are multiples of 256 (every wave
+  // issues the same number of DMA instructions, so fixed vmcnt immediates are valid): half 0
+  // of chunk c+1 is fetched while the taps of half 1 of chunk c are still being multiplied,
+  // half 1 at the end of the chunk while the activation tile is split and written; each DMA
+  // has at least half a chunk of MFMAs to land.  Only the activation tile still goes through
+  // registers (it has to be split into bf16 pieces).
+  constexpr bool DMA_B = BF3 && kDmaWeights && (TAPS == 9 || (TAPS == 4 && NT == 2));
+  if constexpr (DMA_B) {
+    constexpr int T0 = (TAPS == 9) ? 4 : 2;            // taps in half 0
+    constexpr int NU = TAPS * NT, U0 = T0 * NT;        // MFMA units (tap-major), units in half 0
+    constexpr int SL = (TAPS == 4) ? 16 : TAPS;        // slabs per (chunk, 32-channel tile)
+    constexpr int H0 = U0 * 192;                       // 16-byte items in half 0
+    static_assert(H0 % 256 == 0, "half 0 must be whole DMA instructions");
+    constexpr int NH1_MIN = (B_ITEMS - H0) / 256;      // half-1 DMA instructions every wave issues
+    constexpr int NA_LD = A_ITERS + ((PRO != P2L_PRO_NONE) ? 2 * S_ITERS : 0);
+    // LDS order of the weight tile: [tap][n-tile j][32 rows] (= MFMA unit order)
+    int b_goff[B_ITERS];
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int jj = tid + 256 * it;
+      const int u = jj / 192, within = jj - u * 192;
+      const int tap = u / NT, j = u - tap * NT;
+      b_goff[it] = ((j * SL + tap) * 32) * 24 + within * 4;
     }
-    if constexpr (BF3) {
-      // Fragment software pipeline.  Unit u = (tap, n-tile j): 6 MFMAs (192 issue cycles)
-      // on acc[j].  While unit u issues, the 3 weight fragments of unit u+1 (and, at a tap
-      // boundary, the 3 activation fragments of the next tap) are already in flight into the
-      // other register set, so the only LDS wait per unit has a whole unit of MFMAs in front
-      // of it.  (hipcc's own schedule of the straightforward loop reads each fragment right
-      // before its first use: 5-6 exposed LDS round trips per tap, MFMA pipe 47 % busy.)
-      constexpr int NU = TAPS * NT;
+    auto geom = [&](int c, int& cc, int& wslab, int& a_extra) {
+      cc = c; wslab = 0; a_extra = 0;
+      if (TAPS == 4) {
+        if (sp_bwd) {
+          const int cls = c / k.sp_ncc;
+          cc = c - cls * k.sp_ncc;
+          wslab = cls * 4;
+          a_extra = ((cls >> 1) * k.ibW + (cls & 1)) * k.x_ld;
+        } else {
+          wslab = (ph_y * 2 + ph_x) * 4;
+        }
+      }
+    };
+    auto dma_b = [&](int c, auto half_c) {
+      constexpr int half = decltype(half_c)::value;
+      int cc, wslab, a_extra;
+      geom(c, cc, wslab, a_extra);
+      const float* base = k.w + ((((size_t)cc * (k.Cout >> 5) + (n0 >> 5)) * SL + wslab) * 32) * 24;
+#pragma unroll
+      for (int it = 0; it < B_ITERS; ++it) {
+        if ((half == 0 && 256 * it >= H0) || (half == 1 && 256 * (it + 1) <= H0)) continue;
+        const int jj = tid + 256 * it;
+        if (jj < B_ITEMS) {
+          // inline asm on purpose: through the builtin hipcc treats the DMA as an LDS write
+          // that may alias everything and puts s_waitcnt vmcnt(0) in front of the next
+          // ds_read / ds_write, i.e. right after the issue.  The waits are placed by hand
+          // below (P2L_WAIT); the compiler's own vmcnt arithmetic for the activation loads
+          // ignores these instructions and therefore only ever over-waits.
+          const float* src = base + b_goff[it];
+          const unsigned lds_wave_base = __builtin_amdgcn_readfirstlane(
+              (unsigned)(size_t)(__attribute__((address_space(3))) float*)(Bs + (size_t)(jj - lane) * 4));
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       :: "v"(src), "s"(lds_wave_base) : "memory");
+        }
+      }
+    };
+    auto load_a = [&](int c) {
+      int cc, wslab, a_extra;
+      geom(c, cc, wslab, a_extra);
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)(a_goff[it] + a_extra) + cc * KC);
+        if (PRO != P2L_PRO_NONE && it < S_ITERS) {
+          const int so = S_UNI ? s_uni : a_soff[it];
+          sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + so + cc * KC);
+          tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + so + cc * KC);
+        }
+      }
+    };
+    auto write_a = [&]() {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        if (a_loff[it] >= 0) {
+          f32x4 v = xr[it];
+          if (PRO != P2L_PRO_NONE) {
+            v = v * sr[S_UNI ? 0 : it] + tr[S_UNI ? 0 : it];
+            if (PRO == P2L_PRO_AFFINE_RELU) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+              v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+          }
+          if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int row = a_loff[it] / 24, q4 = (a_loff[it] - row * 24) >> 2;
+          bf16x4 ph, pm, pl;
+          split3(v, ph, pm, pl);
+          char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 0, row) * 16) = ph;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 2, row) * 16) = pm;
+          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 4, row) * 16) = pl;
+        }
+      }
+    };
+    // s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
+#define P2L_WAIT(VM, LGKM) __builtin_amdgcn_s_waitcnt(((VM) & 15) | (7 << 4) | ((LGKM) << 8) | (((VM) >> 4) << 14))
+    using H0c = std::integral_constant<int, 0>;
+    using H1c = std::integral_constant<int, 1>;
+    // The activation loads of chunk c+2 are issued right after write_a() has consumed those
+    // of chunk c+1 (NOT at the loop top: hipcc re-uses the destination registers for the
+    // addresses and would put a vmcnt(0) there, which also waits for the DMAs in flight).
+    if (c_begin < c_end) {
+      dma_b(c_begin, H0c{});
+      dma_b(c_begin, H1c{});
+      load_a(c_begin);
+      write_a();
+      __builtin_amdgcn_sched_barrier(0);
+      if (c_begin + 1 < c_end) load_a(c_begin + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    P2L_WAIT(NA_LD, 0);                   // everything but the loads just issued
+    __builtin_amdgcn_s_barrier();
+
+    for (int c = c_begin; c < c_end; ++c) {
+      const bool more = (c + 1 < c_end);
+      int win_row = 0;
+      if (TAPS == 4) {
+        int oy = ph_y, ox = ph_x;
+        if (sp_bwd) {
+          const int cls = c / k.sp_ncc;
+          oy = 1 - (cls >> 1);
+          ox = 1 - (cls & 1);
+        }
+        win_row = oy * HW_ + ox;
+      }
       bf16x8 af[2][3], bq[2][3];
       auto lda = [&](int tap, bf16x8 (&a)[3]) {
         const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
         const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
-        const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+        const int arow = a_row0 + win_row + dy * HW_ + dx;
         const float* ar = As + arow * 24;
         a[0] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
         a[1] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
         a[2] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
       };
-      auto ldb = [&](int tap, int j, bf16x8 (&b)[3]) {
-        const float* br = Bs + ((j * TAPS + tap) * 32 + l31) * 24;     // [n-tile][tap][row]
+      auto ldb = [&](int u, bf16x8 (&b)[3]) {
+        const float* br = Bs + (u * 32 + l31) * 24;
         b[0] = *reinterpret_cast<const bf16x8*>(br + b_c1);
         b[1] = *reinterpret_cast<const bf16x8*>(br + b_c2);
         b[2] = *reinterpret_cast<const bf16x8*>(br + b_c3);
       };
       lda(0, af[0]);
-      ldb(0, 0, bq[0]);
+      ldb(0, bq[0]);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int tap = u / NT, j = u - tap * NT;
-        if (u + 1 < NU) {
+        if (u == U0) {
+          // half 1 of THIS chunk (DMA'd at the end of the previous one, the youngest VMEM op)
+          // must have landed in every wave, and every wave must be done reading half 0
+          // before it is refilled
+          P2L_WAIT(0, 0);
+          __builtin_amdgcn_s_barrier();
+          if (more) dma_b(c + 1, H0c{});
+          if (j == 0) lda(tap, af[tap & 1]);
+          ldb(u, bq[u & 1]);
+        }
+        if (u + 1 < NU && u + 1 != U0) {
           const int tn = (u + 1) / NT, jn = (u + 1) - tn * NT;
           if (jn == 0) lda(tn, af[tn & 1]);
-          ldb(tn, jn, bq[(u + 1) & 1]);
+          ldb(u + 1, bq[(u + 1) & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 (&a)[3] = af[tap & 1];
         const bf16x8 (&b)[3] = bq[u & 1];
-        // smallest terms first
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[j], 0, 0, 0);
@@ -545,61 +656,151 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
-      const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
-      if (BF3) {
-        const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
-        const float* ar = As + arow * 24;
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
-        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
-        bf16x8 b1[NT], b2[NT], b3[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float* br = Bs + (tap * BN + j * 32 + l31) * 24;
-          b1[j] = *reinterpret_cast<const bf16x8*>(br + b_c1);
-          b2[j] = *reinterpret_cast<const bf16x8*>(br + b_c2);
-          b3[j] = *reinterpret_cast<const bf16x8*>(br + b_c3);
-        }
-        // smallest terms first; the NT accumulators alternate so that consecutive MFMAs
-        // never depend on each other
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[j], acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[j], acc[j], 0, 0, 0);
-        continue;
+      P2L_WAIT(63, 0);                      // my LDS reads are done
+      __builtin_amdgcn_s_barrier();         // everybody is done with half 1 and the A tile
+      if (more) {
+        write_a();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more2 = (c + 2 < c_end);
+        if (more2) load_a(c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_b(c + 1, H1c{});
+        __builtin_amdgcn_sched_barrier(0);
+        // A tile written (lgkmcnt 0) and half 0 of c+1 landed; the ops issued after it - the
+        // activation loads of c+2 (if any) and the half-1 DMAs - may still be in flight
+        if (more2) P2L_WAIT(NA_LD + NH1_MIN, 0); else P2L_WAIT(NH1_MIN, 0);
+      } else {
+        P2L_WAIT(63, 0);
       }
-      const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
-#pragma unroll
-      for (int kk = 0; kk < KC / 8; ++kk) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(
-              b_frag + (tap * BN + j * 32) * PITCH + kk * 8);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc[j], 0, 0, 0);
-        }
-      }
+      __builtin_amdgcn_s_barrier();
     }
-    }  // !BF3
+#undef P2L_WAIT
+  } else {
+  if (c_begin < c_end) {
+      load_regs(c_begin);
+      write_lds();
+    }
     __syncthreads();
-    if (more) write_lds();
-    __syncthreads();
-  }
+  
+    for (int c = c_begin; c < c_end; ++c) {
+      const bool more = (c + 1 < c_end);
+      if (more) load_regs(c + 1);
+  
+      // window origin inside the halo: 3x3 -> (0,0); sub-pixel forward -> the output
+      // phase; sub-pixel input-gradient -> (1 - plane parity)
+      int win0 = 0;
+      if (TAPS == 4) {
+        int oy = ph_y, ox = ph_x;
+        if (sp_bwd) {
+          const int cls = c / k.sp_ncc;
+          oy = 1 - (cls >> 1);
+          ox = 1 - (cls & 1);
+        }
+        win0 = (oy * HW_ + ox) * PITCH;
+      }
+      if constexpr (BF3) {
+        // Fragment software pipeline.  Unit u = (tap, n-tile j): 6 MFMAs (192 issue cycles)
+        // on acc[j].  While unit u issues, the 3 weight fragments of unit u+1 (and, at a tap
+        // boundary, the 3 activation fragments of the next tap) are already in flight into the
+        // other register set, so the only LDS wait per unit has a whole unit of MFMAs in front
+        // of it.  (hipcc's own schedule of the straightforward loop reads each fragment right
+        // before its first use: 5-6 exposed LDS round trips per tap, MFMA pipe 47 % busy.)
+        constexpr int NU = TAPS * NT;
+        bf16x8 af[2][3], bq[2][3];
+        auto lda = [&](int tap, bf16x8 (&a)[3]) {
+          const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
+          const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
+          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+          const float* ar = As + arow * 24;
+          a[0] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
+          a[1] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
+          a[2] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+        };
+        auto ldb = [&](int tap, int j, bf16x8 (&b)[3]) {
+          const float* br = Bs + ((j * TAPS + tap) * 32 + l31) * 24;     // [n-tile][tap][row]
+          b[0] = *reinterpret_cast<const bf16x8*>(br + b_c1);
+          b[1] = *reinterpret_cast<const bf16x8*>(br + b_c2);
+          b[2] = *reinterpret_cast<const bf16x8*>(br + b_c3);
+        };
+        lda(0, af[0]);
+        ldb(0, 0, bq[0]);
+  #pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int tap = u / NT, j = u - tap * NT;
+          if (u + 1 < NU) {
+            const int tn = (u + 1) / NT, jn = (u + 1) - tn * NT;
+            if (jn == 0) lda(tn, af[tn & 1]);
+            ldb(tn, jn, bq[(u + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 (&a)[3] = af[tap & 1];
+          const bf16x8 (&b)[3] = bq[u & 1];
+          // smallest terms first
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+  #pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
+        const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
+        if (BF3) {
+          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+          const float* ar = As + arow * 24;
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
+          const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+          bf16x8 b1[NT], b2[NT], b3[NT];
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float* br = Bs + (tap * BN + j * 32 + l31) * 24;
+            b1[j] = *reinterpret_cast<const bf16x8*>(br + b_c1);
+            b2[j] = *reinterpret_cast<const bf16x8*>(br + b_c2);
+            b3[j] = *reinterpret_cast<const bf16x8*>(br + b_c3);
+          }
+          // smallest terms first; the NT accumulators alternate so that consecutive MFMAs
+          // never depend on each other
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[j], acc[j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[j], acc[j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[j], acc[j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[j], acc[j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[j], acc[j], 0, 0, 0);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[j], acc[j], 0, 0, 0);
+          continue;
+        }
+        const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
+  #pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
+  #pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(
+                b_frag + (tap * BN + j * 32) * PITCH + kk * 8);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc[j], 0, 0, 0);
+          }
+        }
+      }
+      }  // !BF3
+      __syncthreads();
+      if (more) write_lds();
+      __syncthreads();
+    }
+  
+  }   // !DMA_B
 
   // ---- epilogue -----------------------------------------------------------
   // lane owns column n of 4 quads (g): Q = wave*8 + 2g + lhi, 4 sub-pixels each
