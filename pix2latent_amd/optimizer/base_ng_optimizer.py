@@ -73,7 +73,8 @@ class _BaseNevergradOptimizer():
 
         for (var_type, var_name), ng_opt in self.ng_optimizers.items():
             ng_data = [ng_opt.ask() for _ in range(num_samples)]
-            _ng_data = np.concatenate([x.args[0] for x in ng_data])
+            # every args is a 1-tuple (array,): stacks to [num_samples, *shape] (reference :107)
+            _ng_data = np.concatenate([x.args for x in ng_data])
             shard = getattr(self, 'shard', None)
             if shard is not None and shard.enabled:
                 _ng_data = shard.broadcast_numpy(_ng_data, src=0)

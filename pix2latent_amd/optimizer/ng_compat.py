@@ -27,9 +27,13 @@ class Array(object):
 
 
 class Candidate(object):
+    """nevergrad's candidate for a p.Array parametrisation: `args` is a 1-tuple holding the
+    array in the shape of `init` (the reference stacks them with
+    np.concatenate([x.args for x in asked]), base_ng_optimizer.py:107)."""
+
     def __init__(self, value, uid):
         self.value = value
-        self.args = (value.reshape(1, -1) if value.ndim == 1 else value[None],)
+        self.args = (value,)
         self.kwargs = {}
         self.uid = uid
 
@@ -48,7 +52,8 @@ class _Base(object):
     def _new(self, z):
         self._uid += 1
         self.num_ask += 1
-        c = Candidate(self.p.init.reshape(-1) + self.p.sigma * z, self._uid)
+        c = Candidate((self.p.init.reshape(-1) + self.p.sigma * z).reshape(self.p.init.shape),
+                      self._uid)
         c._z = z
         return c
 

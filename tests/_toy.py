@@ -57,3 +57,55 @@ class FakeCMAES(object):
         self.mean = np.array(x[int(np.argmin(y))], dtype=np.float64)
 
 
+
+
+class FakeNGOpt(object):
+    """recording stand-in for a nevergrad optimizer (API used by the reference,
+    base_ng_optimizer.py:81-83,107,169): ask() -> candidate whose .args is the 1-tuple
+    (array of init's shape,), tell(candidate, loss).  ask = mean + seeded normal; tell records
+    and moves the mean to the best candidate told so far."""
+    log = []          # (kind, payload) in call order, shared across instances
+    instances = []
+
+    class Cand(object):
+        def __init__(self, value, uid):
+            self.args = (value,)
+            self.kwargs = {}
+            self.uid = uid
+
+    def __init__(self, parametrization=None, budget=None, num_workers=1, **kw):
+        self.init = np.array(parametrization.init, dtype=np.float64)
+        self.budget = budget
+        self.mean = self.init.copy()
+        self.best = np.inf
+        self.rng = np.random.RandomState(4321)
+        self.n_ask = 0
+        FakeNGOpt.instances.append(self)
+
+    def ask(self):
+        self.n_ask += 1
+        c = FakeNGOpt.Cand(self.mean + self.rng.randn(*self.init.shape), self.n_ask)
+        FakeNGOpt.log.append(('ask', c.uid))
+        return c
+
+    def tell(self, cand, loss):
+        loss = float(loss)
+        FakeNGOpt.log.append(('tell', (cand.uid, np.array(cand.args[0]).copy(), loss)))
+        if loss < self.best:
+            self.best, self.mean = loss, np.array(cand.args[0], dtype=np.float64)
+
+
+class _FakeNGArray(object):
+    def __init__(self, init=None, shape=None):
+        self.init = np.zeros(shape) if init is None else np.array(init, dtype=np.float64)
+
+    def set_mutation(self, sigma=1.0):
+        return self
+
+
+def fake_nevergrad():
+    """module-like object with the attributes the reference touches"""
+    ng = types.SimpleNamespace()
+    ng.optimizers = types.SimpleNamespace(registry={'CMA': FakeNGOpt, 'DE': FakeNGOpt})
+    ng.p = types.SimpleNamespace(Array=_FakeNGArray)
+    return ng

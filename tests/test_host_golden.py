@@ -236,3 +236,67 @@ def test_cma_control_flow_golden(monkeypatch):
     assert np.allclose(np.array(closses[-1][1]['loss']), g['final_loss'], atol=1e-6)
     assert closses[-1][0] == int(g['total_steps'])
     assert [c[0] for c in model.calls] == [int(c[0]) for c in g['model_calls']]
+
+
+def _patch_ng(monkeypatch):
+    from _toy import FakeNGOpt, fake_nevergrad
+    import pix2latent_amd.optimizer.base_ng_optimizer as B
+    FakeNGOpt.log, FakeNGOpt.instances = [], []
+    monkeypatch.setattr(B, 'ng', fake_nevergrad())
+    return FakeNGOpt
+
+
+def _check_ng_trace(F, g, variables, losses, model):
+    kinds = np.array([0 if k == 'ask' else 1 for k, _ in F.log])
+    tells = [p for k, p in F.log if k == 'tell']
+    assert np.array_equal(kinds, g['kinds']), 'ask / tell call order'
+    assert np.array_equal(np.array([t[0] for t in tells]), g['tell_uid']), 'which candidate is told'
+    assert np.allclose(np.stack([t[1] for t in tells]), g['tell_x'], atol=1e-12)
+    assert np.allclose(np.array([t[2] for t in tells]), g['tell_y'], atol=1e-6)
+    assert F.instances[-1].budget == int(g['budget'])
+    assert np.allclose(torch.stack(list(variables.input.z.data)).detach().numpy(), g['final_z'], atol=1e-6)
+    assert np.allclose(torch.stack(list(variables.input.c.data)).detach().numpy(), g['final_c'], atol=1e-6)
+    assert np.allclose(np.array(losses[-1][1]['loss']), g['final_loss'], atol=1e-6)
+    assert losses[-1][0] == int(g['total_steps'])
+    assert [c[0] for c in model.calls] == [int(c[0]) for c in g['model_calls']]
+
+
+def test_nevergrad_control_flow_golden(monkeypatch):
+    """NevergradOptimizer (reference ng_optimizer.py:22-91) with the recording fake
+    nevergrad of the golden run: num_samples asks per round, forward-only scoring, every
+    asked candidate told its loss, budget = meta_steps, Adam fine-tuning of the last draw."""
+    from pix2latent_amd.optimizer import NevergradOptimizer
+    g = gold('nevergrad')
+    F = _patch_ng(monkeypatch)
+    model = ToyGenerator()
+    torch.manual_seed(45)
+    nopt = NevergradOptimizer('CMA', model, make_vm(), toy_loss, max_batch_size=3)
+    nvars, nouts, nlosses = nopt.optimize(num_samples=4, meta_steps=3, grad_steps=2)
+    _check_ng_trace(F, g, nvars, nlosses, model)
+
+
+def test_hybrid_nevergrad_control_flow_golden(monkeypatch):
+    """HybridNevergradOptimizer (reference hybrid_ng_optimizer.py:23-81, BASELINE config 4):
+    ask -> grad_steps of Adam -> re-score -> tell the ASKED candidates the REFINED losses;
+    budget = meta_steps * grad_steps; last draw refined for last_grad_steps."""
+    from pix2latent_amd.optimizer import HybridNevergradOptimizer
+    g = gold('hybrid_nevergrad')
+    F = _patch_ng(monkeypatch)
+    model = ToyGenerator()
+    torch.manual_seed(46)
+    hopt = HybridNevergradOptimizer('CMA', model, make_vm(), toy_loss, max_batch_size=3)
+    hvars, houts, hlosses = hopt.optimize(num_samples=4, meta_steps=2, grad_steps=2, last_grad_steps=3)
+    _check_ng_trace(F, g, hvars, hlosses, model)
+
+
+def test_ng_compat_facade_conventions():
+    """our nevergrad replacement keeps the API shape the reference relies on"""
+    from pix2latent_amd.optimizer import ng_compat as ng
+    for method in ('CMA', 'DE', 'OnePlusOne', 'RandomSearch'):
+        opt = ng.optimizers.registry[method](parametrization=ng.p.Array(init=np.zeros(6)), budget=20, seed=3)
+        asked = [opt.ask() for _ in range(5)]
+        stacked = np.concatenate([x.args for x in asked])       # reference base_ng_optimizer.py:107
+        assert stacked.shape == (5, 6) and np.isfinite(stacked).all()
+        for c in asked:
+            opt.tell(c, float(np.sum(c.args[0] ** 2)))
+        assert opt.num_ask == 5 and opt.num_tell == 5

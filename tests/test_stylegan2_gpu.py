@@ -193,3 +193,37 @@ def test_basincma_generation_on_stylegan2(sg, dev):
     assert l1.mean() < l0.mean()
     assert np.array_equal(l1, l2), 're-score must be bit-reproducible'
     opt.cma_update(variables, loss=l1)
+
+
+def test_hybrid_nevergrad_on_stylegan2(sg, dev):
+    """BASELINE config 4 flow (examples/invert_stylegan2_cars_hybrid_ng.py:103-114) at SIZE:
+    HybridNevergradOptimizer('CMA'), z in R^512, num_samples not a multiple of the chunk size
+    (chunks 3,3,2), ask -> Adam steps -> tell; finite, improving, asked == told."""
+    from pix2latent_amd import VariableManager
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.optimizer import HybridNevergradOptimizer
+    import pix2latent_amd.loss_functions as LF
+    target = S.synthetic_target(SIZE, 1)
+    weight = torch.ones(3, SIZE, SIZE)
+    loss_mask = torch.zeros(3, SIZE, SIZE)
+    loss_mask[:, SIZE // 8:-SIZE // 8, :] += 1.0
+    model = _FixedNoise(lambda z, n: sg['model'].forward_z(z, noises=n), [n.to(dev) for n in sg['noises']])
+    vm = VariableManager(device=dev)
+    _register(vm, target, weight, loss_mask)
+    opt = HybridNevergradOptimizer('CMA', model, vm,
+                                   LF.ProjectionLoss(lpips_net='vgg', weights=S.lpips_vgg_weights(1), device=dev),
+                                   max_batch_size=3)
+    opt.ng_seed = 0
+    variables, outs, losses = opt.optimize(num_samples=8, meta_steps=2, grad_steps=3, last_grad_steps=4)
+    ng_opt = list(opt.ng_optimizers.values())[0]
+    assert ng_opt.num_ask == 8 * 3 and ng_opt.num_tell == 8 * 2
+    assert ng_opt.budget == 2 * 3
+    final = np.array(losses[-1][1]['loss'])
+    assert final.shape == (8,) and np.isfinite(final).all()
+    assert losses[-1][0] == 2 * 3 + 4
+    assert outs[0].shape[-2] >= SIZE          # collage of the final samples
+    # Adam refinement lowers the loss of what was asked
+    z0 = torch.stack([torch.as_tensor(c.args[0], dtype=torch.float32) for c in opt._sampled[('input', 'z')]])
+    with torch.no_grad():
+        l_asked = opt.loss_fn(model(z=z0.to(dev)), target.to(dev), weight.to(dev), loss_mask.to(dev)).cpu().numpy()
+    assert final.mean() < l_asked.mean()

@@ -56,7 +56,9 @@ def install_stubs():
         return x  # the collage is not pinned
     tv.utils = mod('torchvision.utils', make_grid=make_grid)
     mod('lpips')
-    mod('nevergrad')
+    from _toy import fake_nevergrad
+    _ng = fake_nevergrad()
+    mod('nevergrad', optimizers=_ng.optimizers, p=_ng.p)
     mod('pytorch_pretrained_biggan')
     from _toy import FakeCMAES
     mod('cma', CMAEvolutionStrategy=FakeCMAES)
@@ -210,6 +212,41 @@ def main():
              final_z=torch.stack(cvars.input.z.data).detach().numpy(),
              final_loss=np.array(closses[-1][1]['loss']), total_steps=closses[-1][0],
              model_calls=np.array(model4.calls))
+    # (5b) Nevergrad / HybridNevergrad control flow with the recording fake nevergrad
+    from _toy import FakeNGOpt
+    from pix2latent.optimizer.ng_optimizer import NevergradOptimizer
+    from pix2latent.optimizer.hybrid_ng_optimizer import HybridNevergradOptimizer
+
+    def ng_trace():
+        kinds = np.array([0 if k == 'ask' else 1 for k, _ in FakeNGOpt.log])
+        tells = [p_ for k, p_ in FakeNGOpt.log if k == 'tell']
+        return dict(kinds=kinds, tell_uid=np.array([t_[0] for t_ in tells]),
+                    tell_x=np.stack([t_[1] for t_ in tells]),
+                    tell_y=np.array([t_[2] for t_ in tells]),
+                    budget=FakeNGOpt.instances[-1].budget)
+
+    FakeNGOpt.log, FakeNGOpt.instances = [], []
+    model5 = ToyGenerator()
+    torch.manual_seed(45)
+    nopt = NevergradOptimizer('CMA', model5, make_vm(), toy_loss, max_batch_size=3)
+    nvars, nouts, nlosses = nopt.optimize(num_samples=4, meta_steps=3, grad_steps=2)
+    np.savez(os.path.join(OUT, 'nevergrad.npz'),
+             final_z=torch.stack(nvars.input.z.data).detach().numpy(),
+             final_c=torch.stack(nvars.input.c.data).detach().numpy(),
+             final_loss=np.array(nlosses[-1][1]['loss']), total_steps=nlosses[-1][0],
+             model_calls=np.array(model5.calls), **ng_trace())
+
+    FakeNGOpt.log, FakeNGOpt.instances = [], []
+    model6 = ToyGenerator()
+    torch.manual_seed(46)
+    hopt = HybridNevergradOptimizer('CMA', model6, make_vm(), toy_loss, max_batch_size=3)
+    hvars, houts, hlosses = hopt.optimize(num_samples=4, meta_steps=2, grad_steps=2, last_grad_steps=3)
+    np.savez(os.path.join(OUT, 'hybrid_nevergrad.npz'),
+             final_z=torch.stack(hvars.input.z.data).detach().numpy(),
+             final_c=torch.stack(hvars.input.c.data).detach().numpy(),
+             final_loss=np.array(hlosses[-1][1]['loss']), total_steps=hlosses[-1][0],
+             model_calls=np.array(model6.calls), **ng_trace())
+
     # (6) SpatialTransform / pre-alignment / TransformBasinCMAOptimizer
     import warnings
     warnings.simplefilter('ignore')
