@@ -104,10 +104,16 @@ class _BaseOptimizer():
 
     # -- the step --------------------------------------------------------------
     def _grad_scale(self, n, lo, hi, device):
-        """1 / (size of the REFERENCE chunk each candidate would sit in)"""
-        mbs = self.max_batch_size
-        sizes = [min(mbs, n - (i // mbs) * mbs) for i in range(lo, hi)]
-        return torch.tensor([1.0 / s for s in sizes], dtype=torch.float32, device=device)
+        """1 / (size of the REFERENCE chunk each candidate would sit in).  Cached: building
+        it with torch.tensor(list, device=...) is a pageable H2D copy that synchronises the
+        stream, i.e. one full GPU drain per step (cost 2.5 ms of idle GPU per 26 ms step)."""
+        key = (n, lo, hi, str(device), self.max_batch_size)
+        cache = self.__dict__.setdefault('_gs_cache', {})
+        if key not in cache:
+            mbs = self.max_batch_size
+            sizes = [min(mbs, n - (i // mbs) * mbs) for i in range(lo, hi)]
+            cache[key] = torch.tensor([1.0 / s for s in sizes], dtype=torch.float32, device=device)
+        return cache[key]
 
     def step(self, variables, optimize=True, transform=False):
         if len(self.transform_fns) > 0 and transform:
