@@ -1,11 +1,16 @@
-// 3x3 / 1x1 convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+// 3x3 / 1x1 convolution as an implicit GEMM on the gfx950 matrix cores.
 //
 // Replaces nn.Conv2d forward and input-gradient on the pix2latent hot path
-// (BigGAN-deep GenBlock convs, SelfAttn 1x1s, VGG16 features; reached from
-// pix2latent/model/biggan.py:58 and pix2latent/loss_functions.py:142 in the
-// reference).  Numerics: exact fp32 FMA chains (the f32-input MFMA is bitwise a
-// k-ordered fmaf chain), so results differ from the CPU oracle only by
-// summation order.
+// (BigGAN-deep GenBlock convs, SelfAttn 1x1s, VGG16 features, StyleGAN2 modulated
+// convs; reached from pix2latent/model/biggan.py:58, model/stylegan2.py:116-125 and
+// pix2latent/loss_functions.py:142 in the reference).  Two arithmetic formats:
+//   * P2L_WFMT_F32: v_mfma_f32_32x32x2_f32, exact fp32 FMA chains (bitwise a k-ordered
+//     fmaf chain): results differ from the CPU oracle only by summation order.  Used by
+//     all 1x1 convs and, on request, the 3x3 convs.
+//   * P2L_WFMT_BF16X3 (default for 3x3 / sub-pixel): every fp32 operand split into three
+//     bf16 pieces, six v_mfma_f32_32x32x16_bf16 cross products accumulated in fp32 -
+//     fp32-level accuracy at 2.67x fewer matrix cycles (template flag BF3 below; weights
+//     pre-split and streamed global -> LDS by global_load_lds_dwordx4).
 //
 // Design (MI355X-first, not a translation of a warp-32 tiling):
 //   * NHWC activations; GEMM M = output pixels, N = Cout, K = taps*Cin.
@@ -26,9 +31,11 @@
 //   * The CBN/BN affine + ReLU of the producer and the nearest x2 upsample are
 //     applied while staging (prologue), bias/residual/activation/mask/pool in
 //     the epilogue: no standalone elementwise pass over the activations.
-//   * Global->LDS goes through registers (prologue math + padded rows), loads
-//     for chunk c+1 are issued before the MFMAs of chunk c; two blocks per CU
-//     (<= 69 KB LDS each) overlap one block's barrier with the other's MFMAs.
+//   * fp32 format: global->LDS goes through registers (prologue math + padded rows), loads
+//     for chunk c+1 are issued before the MFMAs of chunk c.  bf16x3 format: only the
+//     activation tile goes through registers (prologue + split); the weight tile is an
+//     LDS-direct DMA in two tap halves.  Two blocks per CU (<= 73 KB LDS each) overlap one
+//     block's barriers with the other's MFMAs.
 //   * Small-M layers (4x4..16x16) split K over blockIdx.y and finish with a
 //     deterministic reduce+epilogue kernel (no float atomics: CMA ranking must
 //     be reproducible).
