@@ -172,7 +172,11 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 cross terms (dropped terms
  *     <= 2^-23 relative).  gfx950 runs bf16 MFMA at 16x the fp32-MFMA rate, so this costs
  *     2.67x fewer matrix cycles.  Weights are pre-split by the *_bf3 pack functions into
- *     buffers of 1.5 x the fp32 packed size; activations are split inside the kernel.   */
+ *     buffers of 1.5 x the fp32 packed size; activations are split inside the kernel.
+ *     Packed layout (an image of the kernel's LDS weight tile, streamed by LDS-direct DMA):
+ *       [K_pad/16 chunks][N_pad/32 tiles][slabs: 9 taps | 16 = phase*4+tap][32 rows][96 B],
+ *       row = [x1 k0-7 | x1 k8-15 | x2 k0-7 | x2 k8-15 | x3 k0-7 | x3 k8-15] as bf16, the
+ *       16-byte chunk index XOR-ed with bit 3 of the row.  N_pad must equal P2LConv.Cout. */
 enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1 };
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
                              int K_pad, int transpose_flip, float* w_packed, void* stream);
