@@ -4,12 +4,17 @@ The candidates of a CMA / Nevergrad generation are independent until the
 rank-based `tell`, so the population dimension is block-partitioned across
 ranks (one process per GPU, torch.distributed backend 'nccl' = RCCL over xGMI
 on the MI355X node, 'gloo' in the CPU tests).  Generator / VGG weights are
-replicated once at start-up.  Per generation the only traffic is
+replicated once at start-up.  The only traffic is
 
-  * rank 0's asked population, broadcast ([pop, N] float64, a few KB), and
-  * one all-gather of the per-candidate scalar losses (<= 3 floats per rank),
+  * per generation: rank 0's asked population, broadcast ([pop, N] float64, a few KB);
+  * per step: one all-gather of the per-candidate scalar losses (<= 3 floats per rank),
+    so that `optimizer.loss` holds the whole population on every rank like the
+    single-process optimizer (kept eager on purpose: a lazy gather would deadlock when only
+    one rank reads the losses);
+  * at the end: one all-gather of the final latents / images.
 
-both latency-bound; there is no collective on the data path of a step.  This
+All of it is latency-bound scalars / small vectors: no activation, gradient or weight ever
+crosses xGMI.  This
 replaces the reference's only multi-GPU mechanism, nn.DataParallel over the
 StyleGAN2 wrapper (examples/invert_stylegan2_cars_*.py:51-53), which
 re-broadcasts all generator weights on every forward.
