@@ -844,14 +844,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   }
 }
 
-// Deterministic split-K finish: one thread per (quad, channel).
+// Deterministic split-K finish.  Item = (quad, channel); ZP = 4 lanes share an item, lane z
+// sums slabs z, z+4, ... (independent loads in flight instead of one serial chain of
+// splitk x 4 dependent adds), the four partial sums are combined in a FIXED shuffle order
+// ((z0 + z1) + (z2 + z3)) and the z = 0 lane runs the epilogue.  Lanes 0-15 of a wave are 16
+// consecutive items (channels: coalesced), the four lanes of an item are l, l^16, l^32, l^48.
 __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
   const int Hh = k.H >> 1, Wh = k.W >> 1;
   const size_t total = (size_t)k.B * Hh * Wh * k.n_store;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int n = (int)(idx % k.n_store);
-  size_t q = idx / k.n_store;
+  // wave = 16 items x 4 z-parts; item index of this lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int zp = lane >> 4;
+  const size_t idx = ((size_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const bool live = idx < total;
+  const size_t id2 = live ? idx : 0;
+  const int n = (int)(id2 % k.n_store);
+  size_t q = id2 / k.n_store;
   const int qx = (int)(q % Wh);
   q /= Wh;
   const int qy = (int)(q % Hh);
@@ -862,12 +870,16 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
   for (int s = 0; s < 4; ++s) {
     const size_t pix = ((size_t)b * k.H + 2 * qy + (s >> 1)) * k.W + 2 * qx + (s & 1);
     float acc = 0.f;
-    for (int zz = 0; zz < k.splitk; ++zz)
+    for (int zz = zp; zz < k.splitk; zz += 4)
       acc += k.ws[((size_t)zz * mtot + pix) * k.Cout + n];
+    // fixed-order combine of the 4 z-parts (lanes l, l^16 | l^32, l^48)
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
     a[s] = acc;
   }
-  epilogue_quad<false>(k, a, (b * k.H + 2 * qy) * k.W + 2 * qx, b, 2 * qy, 2 * qx, n,
-                       k.bias ? k.bias[n] : 0.f);
+  if (live && zp == 0)
+    epilogue_quad<false>(k, a, (b * k.H + 2 * qy) * k.W + 2 * qx, b, 2 * qy, 2 * qx, n,
+                         k.bias ? k.bias[n] : 0.f);
 }
 
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
@@ -1283,7 +1295,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (rc) return rc;
   if (k.splitk > 1) {
     const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
-    hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0,
                        st, k);
     rc = p2l_check_launch();
   }
