@@ -156,9 +156,13 @@ def main():
     from pix2latent_amd import _native as N
     torch.manual_seed(0)
     opt, vm, problem = build_problem(dev, exec_batch_size=args.exec_batch, lpips_net=args.lpips_net)
-    opt.setup_cma(vm)
-    assert opt.num_samples == POP
-    variables = opt.cma_init(vm)
+    # stdout carries exactly ONE JSON line: the optimizers' informational prints
+    # ("(cma-es) number of samples: 18", reference base_cma_optimizer.py:56) go to stderr
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        opt.setup_cma(vm)
+        assert opt.num_samples == POP
+        variables = opt.cma_init(vm)
 
     def sync():
         torch.cuda.synchronize()
