@@ -42,6 +42,8 @@
 #include "p2l_conv_k.h"
 
 #include <cstdlib>
+#include <array>
+#include <cstdio>
 #include <vector>
 
 using namespace p2lconv;
@@ -62,6 +64,7 @@ struct ConvProf {
   std::vector<double> flops;
   std::vector<double> bytes;
   std::vector<int> kind;
+  std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
 } g_prof;
 
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
@@ -1166,6 +1169,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
         ? d->algo_flops
         : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
+    g_prof.shape[prof_slot] = {d->taps, d->B, d->H, d->W, d->Cin, d->Cout, d->ups, d->pro,
+                               arb ? (arb->skip ? 2 : 1) : 0, d->splitk};
     {
       // algorithmic bytes: every operand tensor once (input at ITS resolution, outputs,
       // residual / mask, the fused activation-backward operands) + the packed weights
@@ -1391,6 +1396,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
   g_prof.flops.assign(max_launches, 0.0);
   g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
+  g_prof.shape.assign(max_launches, {});
   g_prof.n = 0;
   g_prof.on = true;
   return P2L_OK;
@@ -1405,6 +1411,9 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
   count[0] = count[1] = 0;
   if (bytes) bytes[0] = bytes[1] = 0.0;
+  // P2L_PROF_DUMP=<file>: one line per launch (tools/prof_layers.py reads it)
+  const char* dump_path = getenv("P2L_PROF_DUMP");
+  FILE* dump = dump_path ? fopen(dump_path, "w") : nullptr;
   for (int i = 0; i < g_prof.n; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return P2L_ELAUNCH;
     float t = 0.f;
@@ -1415,7 +1424,13 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
     if (bytes) bytes[k] += g_prof.bytes[i];
     ms[k] += t;
     count[k] += 1;
+    if (dump) {
+      const auto& sh = g_prof.shape[i];
+      fprintf(dump, "%d %d %d %d %d %d %d %d %d %d %.6e %.6e %.6f\n", sh[0], sh[1], sh[2], sh[3],
+              sh[4], sh[5], sh[6], sh[7], sh[8], sh[9], g_prof.flops[i], g_prof.bytes[i], t);
+    }
   }
+  if (dump) fclose(dump);
   g_prof.n = 0;
   return P2L_OK;
 }
