@@ -13,26 +13,40 @@ DUMP = os.environ.setdefault('P2L_PROF_DUMP', '/tmp/p2l_layers.txt')
 
 
 def main():
-    import bench
+    import time
+    import warnings
+    warnings.simplefilter('ignore')
     from pix2latent_amd import _native as N
-    pop = 18
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import synthetic as S, function_hooks as hook
+    from pix2latent_amd.model.biggan import BigGAN
+    from pix2latent_amd.optimizer import GradientOptimizer
+    import pix2latent_amd.loss_functions as LF
+    pop = int(os.environ.get('P2L_POP', '18'))     # candidates on this rank (18 | 9 | 5 | 3 | 2)
     dev = torch.device('cuda:0')
-    assert pop == bench.POP
-    torch.manual_seed(0)
-    opt, vm, _ = bench.build_problem(dev, exec_batch_size=pop)
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
-        opt.setup_cma(vm)
-        variables = opt.cma_init(vm)
+    model = BigGAN(weights=S.biggan_weights(0), device=dev)
+    loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=S.lpips_vgg_weights(1), device=dev)
+    vm = VariableManager(device=dev)
+    vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook.Clamp(2.0))
+    vm.register('c', (128,), 'input', default=0.05 * torch.randn(128), learning_rate=0.01)
+    vm.register('target', (3, 256, 256), 'output', requires_grad=False,
+                default=S.synthetic_target(256, 1))
+    vm.register('weight', (3, 256, 256), 'output', requires_grad=False,
+                default=S.synthetic_weight_mask(256))
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, exec_batch_size=pop)
+    variables = vm.initialize(num_samples=pop)
     for i in range(2):
         opt.step(variables, optimize=True, transform=(i == 0))
     torch.cuda.synchronize()
     lib = N.lib()
     N.check(lib.p2l_prof_begin(4096), 'prof_begin')
     steps = 3
+    t0 = time.perf_counter()
     for _ in range(steps):
         opt.step(variables, optimize=True)
     torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / steps * 1e3
     f, m, c, b = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)()
     N.check(lib.p2l_prof_end2(f, m, c, b), 'prof_end2')
     rows = collections.OrderedDict()
@@ -43,6 +57,7 @@ def main():
         r = rows.setdefault(key, [0, 0.0, 0.0, 0.0])
         r[0] += 1; r[1] += fl; r[2] += by; r[3] += ms
     tot = sum(r[3] for r in rows.values())
+    print('candidates %d: %.2f ms/step, conv launches %.2f ms/step' % (pop, step_ms, tot / steps))
     print('taps   B    H    W   Cin  Cout ups pro arb sk | n/step  ms/step   TFLOP/s    GB/s  share')
     for key, r in sorted(rows.items(), key=lambda kv: -kv[1][3]):
         print('%4d %3d %4d %4d %5d %5d %3d %3d %3d %2d | %5.1f %8.3f %9.1f %8.0f %5.1f%%' % (
