@@ -119,12 +119,41 @@ def cpu_baseline(problem, max_seconds=40.0):
                       'L1+10*LPIPS-VGG16, torch-CPU fp32, dgrad only)' % (reps, n)}
 
 
+def exact_fp32_leg(dev, args):
+    """evals/s of the same inner step with P2L_CONV_WFMT=f32 (outside the timed K steps)."""
+    import contextlib
+    prev = os.environ.get('P2L_CONV_WFMT')
+    os.environ['P2L_CONV_WFMT'] = 'f32'
+    try:
+        torch.manual_seed(0)
+        opt, vm, _ = build_problem(dev, exec_batch_size=args.exec_batch, lpips_net=args.lpips_net)
+        with contextlib.redirect_stdout(sys.stderr):
+            opt.setup_cma(vm)
+            variables = opt.cma_init(vm)
+        for i in range(2):
+            opt.step(variables, optimize=True, transform=(i == 0))
+        torch.cuda.synchronize()
+        n = max(2, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.step(variables, optimize=True)
+        torch.cuda.synchronize()
+        return POP * n / (time.perf_counter() - t0)
+    finally:
+        if prev is None:
+            os.environ.pop('P2L_CONV_WFMT', None)
+        else:
+            os.environ['P2L_CONV_WFMT'] = prev
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-leg', action='store_true',
+                    help='skip the extra exact-fp32-MFMA measurement reported in config')
     ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex'],
                     help="LPIPS network: 'vgg' = BASELINE.json's metric (default); 'alex' = the "
                          "reference's ProjectionLoss() default, reported as a side configuration")
@@ -277,6 +306,10 @@ def main():
                             'time_share_of_step': round(ms[1] * 1e-3 / elapsed, 4)},
             },
         }
+        if world == 1 and bf3 and not args.no_fp32_leg:
+            # the same steps with every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
+            # reported beside `value` so the arithmetic choice is visible in one line
+            rec['config']['exact_fp32_mfma_evals_per_s'] = round(exact_fp32_leg(dev, args), 1)
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(problem)
         print(json.dumps(rec), flush=True)

@@ -2,10 +2,10 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python bench.py --lpips-net alex --no-cpu-baseline > gpurun_out/bench_alex.json 2> gpurun_out/bench_alex.err
+python bench.py --lpips-net alex --no-cpu-baseline --no-fp32-leg > gpurun_out/bench_alex.json 2> gpurun_out/bench_alex.err
 grep -v cma-es gpurun_out/bench_alex.json; tail -3 gpurun_out/bench_alex.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_alex -o ax -- python $R/bench.py --lpips-net alex --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof_alex.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_alex -o ax -- python $R/bench.py --lpips-net alex --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg > /dev/null 2> $R/gpurun_out/prof_alex.err
 cd $R
 rm -f gpurun_out/prof_alex/*kernel_trace.csv
 python - <<'PY'

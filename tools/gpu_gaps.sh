@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps -o g -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/gaps.err
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps -o g -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-leg > /dev/null 2> $R/gpurun_out/gaps.err
 cd $R
 python - <<'PY'
 import csv, glob

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null > gpurun_out/shard1.json
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-leg 2>/dev/null > gpurun_out/shard1.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo 2> gpurun_out/shard2.err > gpurun_out/shard2.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 4 --steps 3 --warmup 1 --backend gloo 2> gpurun_out/shard4.err > gpurun_out/shard4.json
 tail -3 gpurun_out/shard2.err
