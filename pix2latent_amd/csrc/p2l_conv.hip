@@ -441,9 +441,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           bf16x4 ph, pm, pl;
           split3(v, ph, pm, pl);
           char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 0, row) * 16) = ph;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 2, row) * 16) = pm;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 4, row) * 16) = pl;
+          // (c ^ s) with c = {0,2,4} + (q4 >> 1) and s in {0,1}: only the low bit moves,
+          // so the three pieces are one address + 0 / 32 / 64 bytes
+          char* rq = rb + bf3_chunk(q4 >> 1, row) * 16;
+          *reinterpret_cast<bf16x4*>(rq) = ph;
+          *reinterpret_cast<bf16x4*>(rq + 32) = pm;
+          *reinterpret_cast<bf16x4*>(rq + 64) = pl;
         } else {
           *reinterpret_cast<f32x4*>(As + a_loff[it]) = v;
         }
@@ -480,8 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
   const float* a_frag = As + a_row0 * PITCH + lhi * 4;
   const float* b_frag = Bs + l31 * PITCH + lhi * 4;
   // BF3: B rows are (j*TAPS + tap)*32 + l31 (multiples of 32 + l31): swizzle bit from l31 only
-  const int b_c1 = bf3_chunk(0 + lhi, l31) * 4, b_c2 = bf3_chunk(2 + lhi, l31) * 4,
-            b_c3 = bf3_chunk(4 + lhi, l31) * 4;
+  const int b_c1 = bf3_chunk(lhi, l31) * 4, b_c2 = b_c1 + 8, b_c3 = b_c1 + 16;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -582,9 +584,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           bf16x4 ph, pm, pl;
           split3(v, ph, pm, pl);
           char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 0, row) * 16) = ph;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 2, row) * 16) = pm;
-          *reinterpret_cast<bf16x4*>(rb + bf3_chunk((q4 >> 1) + 4, row) * 16) = pl;
+          // (c ^ s) with c = {0,2,4} + (q4 >> 1) and s in {0,1}: only the low bit moves,
+          // so the three pieces are one address + 0 / 32 / 64 bytes
+          char* rq = rb + bf3_chunk(q4 >> 1, row) * 16;
+          *reinterpret_cast<bf16x4*>(rq) = ph;
+          *reinterpret_cast<bf16x4*>(rq + 32) = pm;
+          *reinterpret_cast<bf16x4*>(rq + 64) = pl;
         }
       }
     };
@@ -625,9 +630,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
         const int arow = a_row0 + win_row + dy * HW_ + dx;
         const float* ar = As + arow * 24;
-        a[0] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
-        a[1] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
-        a[2] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+        const float* aq = ar + bf3_chunk(lhi, arow) * 4;      // pieces at +0 / +32 / +64 bytes
+        a[0] = *reinterpret_cast<const bf16x8*>(aq);
+        a[1] = *reinterpret_cast<const bf16x8*>(aq + 8);
+        a[2] = *reinterpret_cast<const bf16x8*>(aq + 16);
       };
       auto ldb = [&](int u, bf16x8 (&b)[3]) {
         const float* br = Bs + (u * 32 + l31) * 24;
@@ -722,9 +728,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
           const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
           const float* ar = As + arow * 24;
-          a[0] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
-          a[1] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
-          a[2] = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+          const float* aq = ar + bf3_chunk(lhi, arow) * 4;
+          a[0] = *reinterpret_cast<const bf16x8*>(aq);
+          a[1] = *reinterpret_cast<const bf16x8*>(aq + 8);
+          a[2] = *reinterpret_cast<const bf16x8*>(aq + 16);
         };
         auto ldb = [&](int tap, int j, bf16x8 (&b)[3]) {
           const float* br = Bs + ((j * TAPS + tap) * 32 + l31) * 24;     // [n-tile][tap][row]
@@ -762,9 +769,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         if (BF3) {
           const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
           const float* ar = As + arow * 24;
-          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(0 + lhi, arow) * 4);
-          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(2 + lhi, arow) * 4);
-          const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + bf3_chunk(4 + lhi, arow) * 4);
+          const float* aq = ar + bf3_chunk(lhi, arow) * 4;
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 8);
+          const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(aq + 16);
           bf16x8 b1[NT], b2[NT], b3[NT];
   #pragma unroll
           for (int j = 0; j < NT; ++j) {
