@@ -122,6 +122,15 @@ int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
                        const float* w, float* dx, void* stream);
 int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk, int C,
                    int out_bstride, void* stream);
+/* Deferred form of the finish (per host thread): between _begin and _flush every
+ * p2l_arb_finish - including the ones p2l_conv_dgrad_arb / p2l_affine_relu_bwd issue - is
+ * only recorded, and _flush reduces all of them in ONE launch (the backward pass of a
+ * generator has ~50 of them and needs ds/dt only at its end).  The caller must give every
+ * deferred layer its own `partial` buffer and keep it untouched until _flush.  _cancel
+ * drops what was recorded (error paths). */
+void p2l_arb_defer_begin(void);
+int p2l_arb_defer_flush(void* stream);
+void p2l_arb_defer_cancel(void);
 
 /* Select the 3x3 kernel for eligible layers: -1 = v1 (default); 0 / 1 = the
  * persistent LDS-double-buffered v2 with 256- / 128-pixel tiles (experimental,
@@ -201,6 +210,13 @@ typedef struct P2LGemm {
 } P2LGemm;
 int p2l_gemm(const P2LGemm* d, const float* A, const float* B, float* C,
              void* stream);
+/* same, splitting K over extra blocks when the product is deep (K >= 1024) and has fewer
+ * than 192 output tiles; the K slices are summed in a fixed order (no atomics).  `ws` needs
+ * p2l_gemm_ws_bytes(d) bytes (0 = this product is never split); without it the call is
+ * p2l_gemm. */
+size_t p2l_gemm_ws_bytes(const P2LGemm* d);
+int p2l_gemm_ws(const P2LGemm* d, const float* A, const float* B, float* C, void* ws,
+                size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Small dense layers on the conditioning vector (gen_z, CBN gain/bias).     */

@@ -137,7 +137,7 @@ EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
-    'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_linear_fwd', 'p2l_linear_bwd',
+    'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',
@@ -154,7 +154,8 @@ EXPORTS = [
     'p2l_sg2_clamp16_fwd', 'p2l_sg2_clamp16_bwd', 'p2l_broadcast_rows', 'p2l_add_inplace',
     'p2l_sg2_ws_bytes', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
     'p2l_sg2_mapping_bwd', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
-    'p2l_conv_dgrad_arb', 'p2l_arb_finish',
+    'p2l_conv_dgrad_arb', 'p2l_arb_finish', 'p2l_arb_defer_begin', 'p2l_arb_defer_flush',
+    'p2l_arb_defer_cancel',
     'p2l_gconv_fwd', 'p2l_maxpool3s2_fwd', 'p2l_maxpool3s2_bwd', 'p2l_conv1_dgrad',
     'p2l_alex_cache_floats', 'p2l_alexloss_ws_bytes', 'p2l_alexloss_prepare', 'p2l_alexloss_fwd',
     'p2l_alexloss_bwd',
@@ -177,9 +178,11 @@ def lib():
                 '(no CPU fallback). Run __graft_entry__.build().' % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
         _lib.p2l_strerror.restype = C.c_char_p
+        _lib.p2l_arb_defer_begin.restype = None
+        _lib.p2l_arb_defer_cancel.restype = None
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
-                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats'):
+                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

@@ -20,6 +20,11 @@ struct GemmK {
   float alpha;
   int accumulate;
   int n_ntiles;
+  // split-K (deep-K products with few output tiles): slice z = blockIdx.z multiplies
+  // K range [z*kper, (z+1)*kper) and dumps its raw accumulators to ws[z][batch][M][N];
+  // gemm_splitk_finish adds the slices in a fixed order
+  float* ws;
+  int ksplit, kper;
 };
 
 template <int BN, bool AKM, bool BKM>
@@ -109,12 +114,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  load_regs(0);
+  const int k_begin = (int)blockIdx.z * g.kper;
+  const int k_end = min(g.K, k_begin + g.kper);
+  load_regs(k_begin);
   write_lds();
   __syncthreads();
 
-  for (int kc = 0; kc < g.K; kc += KC) {
-    const bool more = kc + KC < g.K;
+  for (int kc = k_begin; kc < k_end; kc += KC) {
+    const bool more = kc + KC < k_end;
     if (more) load_regs(kc + KC);
 #pragma unroll
     for (int kk = 0; kk < KC / 8; ++kk) {
@@ -145,6 +152,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK g) {
     __syncthreads();
   }
 
+  if (g.ksplit > 1) {
+    float* S = g.ws + ((size_t)blockIdx.z * gridDim.y + batch) * ((size_t)g.M * g.N);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        S[(size_t)m * g.N + n] = acc[j][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 32 + l31;
@@ -159,9 +179,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmK g) {
   }
 }
 
+// C = alpha * (ws[0] + ws[1] + ... in this order) (+ C): one float4 of C per thread
+__global__ __launch_bounds__(256) void gemm_splitk_finish(const GemmK g, int batch) {
+  const size_t mn4 = (size_t)g.M * g.N / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn4 * batch) return;
+  const size_t b = i / mn4, r = i - b * mn4;
+  const size_t m = r / (g.N / 4), n = (r - m * (g.N / 4)) * 4;
+  const size_t slab = (size_t)batch * g.M * g.N;
+  const float* p = g.ws + b * ((size_t)g.M * g.N) + m * g.N + n;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  for (int z = 1; z < g.ksplit; ++z) v += *reinterpret_cast<const f32x4*>(p + z * slab);
+  float* cp = g.C + b * g.sc + m * g.ldc + n;
+  v = v * g.alpha;
+  if (g.accumulate) { cp[0] += v.x; cp[1] += v.y; cp[2] += v.z; cp[3] += v.w; }
+  else { cp[0] = v.x; cp[1] = v.y; cp[2] = v.z; cp[3] = v.w; }
+}
+
 template <int BN>
 int launch_gemm(const GemmK& g, int akm, int bkm, int batch, hipStream_t st) {
-  dim3 grid((g.M / 128) * g.n_ntiles, batch), block(256);
+  dim3 grid((g.M / 128) * g.n_ntiles, batch, g.ksplit), block(256);
   if (!akm && !bkm) hipLaunchKernelGGL((gemm_mfma_kernel<BN, false, false>), grid, block, 0, st, g);
   else if (!akm && bkm) hipLaunchKernelGGL((gemm_mfma_kernel<BN, false, true>), grid, block, 0, st, g);
   else if (akm && !bkm) hipLaunchKernelGGL((gemm_mfma_kernel<BN, true, false>), grid, block, 0, st, g);
@@ -171,8 +208,38 @@ int launch_gemm(const GemmK& g, int akm, int bkm, int batch, hipStream_t st) {
 
 }  // namespace
 
+// split-K only pays for deep-K products that leave most CUs without a tile
+static int gemm_suggest_split(const P2LGemm* d) {
+  if (!d || d->M % 128 || d->N % 32 || d->K < 1024) return 1;
+  const int bn = (d->N % 64 == 0) ? 64 : 32;
+  const int blocks = (d->M / 128) * (d->N / bn) * d->batch;
+  if (blocks >= 192) return 1;
+  int s = cdiv(512, blocks);
+  if (s > d->K / 256) s = d->K / 256;      // >= 16 chunks per slice
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t p2l_gemm_ws_bytes(const P2LGemm* d) {
+  const int s = gemm_suggest_split(d);
+  return s > 1 ? (size_t)s * d->batch * d->M * d->N * sizeof(float) : 0;
+}
+
+static int gemm_impl(const P2LGemm* d, const float* A, const float* B, float* C, void* ws,
+                     size_t ws_bytes, void* stream);
+
 extern "C" int p2l_gemm(const P2LGemm* d, const float* A, const float* B,
                         float* C, void* stream) {
+  return gemm_impl(d, A, B, C, nullptr, 0, stream);
+}
+
+extern "C" int p2l_gemm_ws(const P2LGemm* d, const float* A, const float* B, float* C,
+                           void* ws, size_t ws_bytes, void* stream) {
+  return gemm_impl(d, A, B, C, ws, ws_bytes, stream);
+}
+
+static int gemm_impl(const P2LGemm* d, const float* A, const float* B, float* C, void* ws,
+                     size_t ws_bytes, void* stream) {
   if (!d || !A || !B || !C) return P2L_EINVAL;
   if (d->M % 128 || d->N % 32 || d->K % 16 || d->batch < 1) return P2L_EINVAL;
   if (d->lda % 4 || d->ldb % 4) return P2L_EINVAL;
@@ -185,6 +252,19 @@ extern "C" int p2l_gemm(const P2LGemm* d, const float* A, const float* B,
   const int bn = (d->N % 64 == 0) ? 64 : 32;
   g.n_ntiles = d->N / bn;
   hipStream_t st = (hipStream_t)stream;
-  return bn == 64 ? launch_gemm<64>(g, d->a_kmajor, d->b_kmajor, d->batch, st)
-                  : launch_gemm<32>(g, d->a_kmajor, d->b_kmajor, d->batch, st);
+  g.ksplit = 1; g.kper = d->K; g.ws = nullptr;
+  const int s = gemm_suggest_split(d);
+  if (s > 1 && ws && ws_bytes >= p2l_gemm_ws_bytes(d) && d->ldc % 4 == 0) {
+    g.ksplit = s;
+    g.kper = cdiv(cdiv(d->K, s), 16) * 16;
+    g.ksplit = cdiv(d->K, g.kper);
+    g.ws = (float*)ws;
+  }
+  const int rc = bn == 64 ? launch_gemm<64>(g, d->a_kmajor, d->b_kmajor, d->batch, st)
+                          : launch_gemm<32>(g, d->a_kmajor, d->b_kmajor, d->batch, st);
+  if (rc || g.ksplit == 1) return rc;
+  const size_t items = (size_t)d->batch * d->M * d->N / 4;
+  hipLaunchKernelGGL(gemm_splitk_finish, dim3((unsigned)cdiv(items, (size_t)256)), dim3(256), 0, st,
+                     g, d->batch);
+  return p2l_check_launch();
 }

@@ -239,6 +239,42 @@ __global__ __launch_bounds__(256) void arb_finish_kernel(const float* partial, f
   }
 }
 
+// the same reduction for up to ARB_GROUP_MAX recorded layers in one launch:
+// grid (max channel groups, B, layers)
+constexpr int ARB_GROUP_MAX = 56;
+struct ArbFin { const float* partial; float* ds; float* dt; int nblk, C, bstride, pad; };
+struct ArbFinGroup { ArbFin e[ARB_GROUP_MAX]; int n, Bn; };
+__global__ __launch_bounds__(256) void arb_finish_group_kernel(const ArbFinGroup g) {
+  __shared__ f32x4 red_s[256], red_t[256];
+  const ArbFin& e = g.e[blockIdx.z];
+  const int C = e.C, nblk = e.nblk;
+  if ((int)blockIdx.x * 64 >= C) return;
+  const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
+  const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
+  const size_t half = (size_t)g.Bn * nblk * C;
+  f32x4 a = {0, 0, 0, 0}, t = {0, 0, 0, 0};
+  const bool live = c < C;
+  for (int j = seg; live && j < nblk; j += 16) {
+    const size_t o = ((size_t)b * nblk + j) * C + c;
+    a += *reinterpret_cast<const f32x4*>(e.partial + o);
+    t += *reinterpret_cast<const f32x4*>(e.partial + half + o);
+  }
+  red_s[tid] = a;
+  red_t[tid] = t;
+  __syncthreads();
+  if (seg == 0 && live) {
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      a += red_s[j * 16 + cl];
+      t += red_t[j * 16 + cl];
+    }
+    *reinterpret_cast<f32x4*>(e.ds + (size_t)b * e.bstride + c) = a;
+    *reinterpret_cast<f32x4*>(e.dt + (size_t)b * e.bstride + c) = t;
+  }
+}
+thread_local bool g_arb_defer = false;
+thread_local ArbFinGroup g_arb_group;
+
 // ---------------------------------------------------------------------------
 // softmax over rows of `cols` (multiple of 256, <= 2048): one wave per row
 // ---------------------------------------------------------------------------
@@ -798,14 +834,47 @@ extern "C" int p2l_affine_relu_bwd(const float* da, int da_ld, const float* x,
   k.nblk = cdiv(k.P, ARB_SLAB);
   hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, C / 64, Bn), dim3(256), 0,
                      ST(stream), k);
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(C / 64, Bn), dim3(256), 0,
-                     ST(stream), partial, ds, dt, Bn, k.nblk, C, dsdt_bstride);
+  const int rc = p2l_check_launch();
+  if (rc) return rc;
+  return p2l_arb_finish(partial, ds, dt, Bn, k.nblk, C, dsdt_bstride, stream);
+}
+
+extern "C" void p2l_arb_defer_begin(void) {
+  g_arb_defer = true;
+  g_arb_group.n = 0;
+}
+extern "C" void p2l_arb_defer_cancel(void) {
+  g_arb_defer = false;
+  g_arb_group.n = 0;
+}
+static int arb_group_launch(void* stream) {
+  ArbFinGroup& g = g_arb_group;
+  if (g.n == 0) return P2L_OK;
+  int cmax = 0;
+  for (int i = 0; i < g.n; ++i) cmax = g.e[i].C > cmax ? g.e[i].C : cmax;
+  hipLaunchKernelGGL(arb_finish_group_kernel, dim3(cdiv(cmax, 64), g.Bn, g.n), dim3(256), 0,
+                     ST(stream), g);
+  g.n = 0;
   return p2l_check_launch();
+}
+extern "C" int p2l_arb_defer_flush(void* stream) {
+  g_arb_defer = false;
+  return arb_group_launch(stream);
 }
 
 extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk,
                               int C, int out_bstride, void* stream) {
   if (C % 32 || out_bstride % 4) return P2L_EINVAL;
+  if (g_arb_defer) {
+    ArbFinGroup& g = g_arb_group;
+    if (g.n == ARB_GROUP_MAX || (g.n > 0 && g.Bn != Bn)) {
+      const int rc = arb_group_launch(stream);
+      if (rc) return rc;
+    }
+    g.Bn = Bn;
+    g.e[g.n++] = ArbFin{partial, ds, dt, nblk, C, out_bstride, 0};
+    return P2L_OK;
+  }
   hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream),
                      partial, ds, dt, Bn, nblk, C, out_bstride);
   return p2l_check_launch();

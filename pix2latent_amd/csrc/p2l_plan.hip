@@ -119,6 +119,7 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
 // ---------------------------------------------------------------------------
 struct BGBlockOff {
   size_t h1, h2, h3, y;
+  size_t pf;  // floats of one activation-backward partial buffer of this block
   int H, Ho;  // input / output resolution
 };
 struct BGLayout {
@@ -130,7 +131,7 @@ struct BGLayout {
   int att_H;
   // backward temporaries
   size_t g_a, g_b, g_c, g_d;  // gradient scratch buffers (max activation size)
-  size_t arb_partial;
+  size_t arb_partial, tail_pf;
   size_t d_theta, d_phi_p, d_phi, d_g_p, d_g, d_ag;
   size_t skws; size_t skws_floats;
   size_t total;
@@ -152,7 +153,9 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   int H = 4;
   L.x0 = a.take((size_t)B * H * H * 16 * m->ch);
   size_t max_act = (size_t)B * H * H * 16 * m->ch;
-  size_t max_partial = 0, max_sk = 0;
+  // every activation-backward of the backward pass gets its own partial-sum buffer: their
+  // second reduction stage is deferred and runs as one launch (p2l_arb_defer_*)
+  size_t sum_partial = 0, max_sk = 0;
   auto upd_sk = [&](int Hc, int Cin, int Cout, int taps) {
     ConvCall c = mk_conv(B, Hc, Hc, Cin, Cout, taps);
     const size_t f = conv_ws_floats(c);
@@ -178,6 +181,17 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
       L.d_g = a.take(B * P * (C / 2));
       L.d_ag = a.take(B * P * (C / 2));
       if (B * P * (P / 4) > max_act) max_act = B * P * (P / 4);  // dP temp
+      {
+        // the two K = P products of the backward pass (d g_p, d phi_p) split K when B is small
+        P2LGemm q{};
+        q.batch = B; q.M = (int)P / 4; q.K = (int)P;
+        q.N = C / 2;
+        size_t f = p2l_gemm_ws_bytes(&q) / sizeof(float);
+        if (f > max_sk) max_sk = f;
+        q.N = C / 8;
+        f = p2l_gemm_ws_bytes(&q) / sizeof(float);
+        if (f > max_sk) max_sk = f;
+      }
     }
     const P2LGenBlock& g = m->blocks[i];
     const int mid = g.cin / 4;
@@ -193,8 +207,8 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
     for (size_t v : acts) if (v > max_act) max_act = v;
     const int nblk = cdiv(Ho * Ho, 128);   // fused epilogue: one partial per 128-pixel tile
     const size_t cmax = (size_t)(g.cin > mid ? g.cin : mid);
-    const size_t pf = 2 * (size_t)B * nblk * cmax;
-    if (pf > max_partial) max_partial = pf;
+    o.pf = 2 * (size_t)B * nblk * cmax;
+    sum_partial += 4 * o.pf;
     // split-K workspace for fwd and dgrad convs of this block
     upd_sk(H, g.cin, mid, 1);  upd_sk(Ho, mid, mid, 9);  upd_sk(Ho, mid, g.cout, 1);
     upd_sk(Ho, g.cout, mid, 1);  upd_sk(H, mid, g.cin, 1);
@@ -203,15 +217,15 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   L.out_res = H;
   {
     const int nblk = cdiv(H * H, 128);
-    const size_t pf = 2 * (size_t)B * nblk * m->ch;
-    if (pf > max_partial) max_partial = pf;
+    L.tail_pf = 2 * (size_t)B * nblk * m->ch;
+    sum_partial += L.tail_pf;
     if ((size_t)B * H * H * m->ch > max_act) max_act = (size_t)B * H * H * m->ch;
   }
   L.g_a = a.take(max_act);
   L.g_b = a.take(max_act);
   L.g_c = a.take(max_act);
   L.g_d = a.take(max_act);
-  L.arb_partial = a.take(max_partial);
+  L.arb_partial = a.take(sum_partial);
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
   L.total = a.off;
@@ -321,7 +335,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
       g1.stride_a = (int64_t)P * (C / 8); g1.stride_b = (int64_t)(P / 4) * (C / 8);
       g1.stride_c = (int64_t)P * (P / 4);
       g1.a_kmajor = 0; g1.b_kmajor = 0; g1.alpha = 1.f; g1.accumulate = 0;
-      RET_IF(p2l_gemm(&g1, W + L.att_theta, W + L.att_phi_p, W + L.att_P, st));
+      RET_IF(p2l_gemm_ws(&g1, W + L.att_theta, W + L.att_phi_p, W + L.att_P, skws, L.skws_floats * sizeof(float), st));
       RET_IF(p2l_softmax_fwd(W + L.att_P, W + L.att_P, (int64_t)B * P, P / 4, st));
       // attn_g[p, :] = sum_k P[p,k] g[k, :]
       P2LGemm g2{};
@@ -330,7 +344,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
       g2.stride_a = (int64_t)P * (P / 4); g2.stride_b = (int64_t)(P / 4) * (C / 2);
       g2.stride_c = (int64_t)P * (C / 2);
       g2.a_kmajor = 0; g2.b_kmajor = 1; g2.alpha = 1.f; g2.accumulate = 0;
-      RET_IF(p2l_gemm(&g2, W + L.att_P, W + L.att_g_p, W + L.att_ag, st));
+      RET_IF(p2l_gemm_ws(&g2, W + L.att_P, W + L.att_g_p, W + L.att_ag, skws, L.skws_floats * sizeof(float), st));
       ConvCall oc = mk_conv(B, H, H, C / 2, C, 1);
       oc.x = W + L.att_ag; oc.w = m->att_w[3]; oc.y = W + L.att_y;
       oc.d.alpha = m->gamma; oc.res = x; oc.d.res_ld = C;
@@ -392,6 +406,12 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
   const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
   float* skws = W + L.skws;
   float* part = W + L.arb_partial;
+  // ds / dt of the ~50 activation-backwards are only needed by the conditioning gradient at
+  // the very end: record their second reduction stage and run it as ONE launch
+  struct ArbDefer {
+    ArbDefer() { p2l_arb_defer_begin(); }
+    ~ArbDefer() { p2l_arb_defer_cancel(); }      // no-op after a flush; cleans up error paths
+  } arb_defer;
   float* ga = W + L.g_a;   // gradient w.r.t. the current layer's output
   float* gb = W + L.g_b;   // scratch
   float* gc = W + L.g_c;   // scratch
@@ -409,6 +429,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     ArbArgs a{xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr, 0, 0, 0, W + L.draw,
               W + L.draw + (size_t)B * m->ch, m->ch};
     RET_IF(run_dgrad_arb(c, a, ga, gd, part, skws, L.skws_floats, st));
+    part += L.tail_pf;
   }
   for (int i = m->n_blocks - 1; i >= 0; --i) {
     const P2LGenBlock& g = m->blocks[i];
@@ -426,12 +447,14 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     ArbArgs a3{W + o.h3, mid, W + L.s + g.cbn_off[3], W + L.t + g.cbn_off[3], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[3], W + L.dt + g.cbn_off[3], CT};
     RET_IF(run_dgrad_arb(d3, a3, gb, gd, part, skws, L.skws_floats, st));
+    part += o.pf;
     // conv_2
     ConvCall d2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     d2.x = gb; d2.w = g.wt[2];
     ArbArgs a2{W + o.h2, mid, W + L.s + g.cbn_off[2], W + L.t + g.cbn_off[2], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[2], W + L.dt + g.cbn_off[2], CT};
     RET_IF(run_dgrad_arb(d2, a2, gc, gd, part, skws, L.skws_floats, st));
+    part += o.pf;
     // conv_1 (+ nearest-x2 backward = 2x2 sum pool fused in the epilogue)
     ConvCall d1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     d1.x = gc; d1.w = g.wt[1];
@@ -440,6 +463,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     ArbArgs a1{W + o.h1, mid, W + L.s + g.cbn_off[1], W + L.t + g.cbn_off[1], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT};
     RET_IF(run_dgrad_arb(d1, a1, gb, gd, part, skws, L.skws_floats, st));
+    part += o.pf;
     // conv_0, + relu(cbn_0) backward + shortcut gradient from dy (= ga)
     ConvCall d0 = mk_conv(B, o.H, o.H, mid, g.cin, 1);
     d0.x = gb; d0.w = g.wt[0];
@@ -447,6 +471,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     ArbArgs a0{xin, g.cin, W + L.s + g.cbn_off[0], W + L.t + g.cbn_off[0], CT, ga, g.cout,
                skipC, g.up, W + L.ds + g.cbn_off[0], W + L.dt + g.cbn_off[0], CT};
     RET_IF(run_dgrad_arb(d0, a0, gc, gd, part, skws, L.skws_floats, st));
+    part += o.pf;
     { float* tmp = ga; ga = gc; gc = tmp; }
 
     if (i == m->attn_before) {
@@ -465,7 +490,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       q1.stride_a = (int64_t)P * (C / 2); q1.stride_b = (int64_t)(P / 4) * (C / 2);
       q1.stride_c = (int64_t)P * (P / 4);
       q1.alpha = 1.f;
-      RET_IF(p2l_gemm(&q1, W + L.d_ag, W + L.att_g_p, gb, st));
+      RET_IF(p2l_gemm_ws(&q1, W + L.d_ag, W + L.att_g_p, gb, skws, L.skws_floats * sizeof(float), st));
       // d g_p[k,c] = sum_p P[p,k] d_ag[p,c]
       P2LGemm q2{};
       q2.batch = B; q2.M = P / 4; q2.N = C / 2; q2.K = P;
@@ -473,7 +498,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       q2.stride_a = (int64_t)P * (P / 4); q2.stride_b = (int64_t)P * (C / 2);
       q2.stride_c = (int64_t)(P / 4) * (C / 2);
       q2.a_kmajor = 1; q2.b_kmajor = 1; q2.alpha = 1.f;
-      RET_IF(p2l_gemm(&q2, W + L.att_P, W + L.d_ag, W + L.d_g_p, st));
+      RET_IF(p2l_gemm_ws(&q2, W + L.att_P, W + L.d_ag, W + L.d_g_p, skws, L.skws_floats * sizeof(float), st));
       // dS = softmax backward (in place in gb)
       RET_IF(p2l_softmax_bwd(W + L.att_P, gb, gb, (int64_t)B * P, P / 4, st));
       // d theta[p,d] = sum_k dS[p,k] phi_p[k,d]
@@ -483,7 +508,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       q3.stride_a = (int64_t)P * (P / 4); q3.stride_b = (int64_t)(P / 4) * (C / 8);
       q3.stride_c = (int64_t)P * (C / 8);
       q3.b_kmajor = 1; q3.alpha = 1.f;
-      RET_IF(p2l_gemm(&q3, gb, W + L.att_phi_p, W + L.d_theta, st));
+      RET_IF(p2l_gemm_ws(&q3, gb, W + L.att_phi_p, W + L.d_theta, skws, L.skws_floats * sizeof(float), st));
       // d phi_p[k,d] = sum_p dS[p,k] theta[p,d]
       P2LGemm q4{};
       q4.batch = B; q4.M = P / 4; q4.N = C / 8; q4.K = P;
@@ -491,7 +516,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       q4.stride_a = (int64_t)P * (P / 4); q4.stride_b = (int64_t)P * (C / 8);
       q4.stride_c = (int64_t)(P / 4) * (C / 8);
       q4.a_kmajor = 1; q4.b_kmajor = 1; q4.alpha = 1.f;
-      RET_IF(p2l_gemm(&q4, gb, W + L.att_theta, W + L.d_phi_p, st));
+      RET_IF(p2l_gemm_ws(&q4, gb, W + L.att_theta, W + L.d_phi_p, skws, L.skws_floats * sizeof(float), st));
       // max-pool backward for phi and g
       RET_IF(p2l_maxpool2_bwd(W + L.att_phi, C / 8, W + L.d_phi_p, C / 8, nullptr, 0,
                               W + L.d_phi, C / 8, B, H, H, C / 8, 0, st));
@@ -511,6 +536,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
   }
   // ga = d gen_z output [B, 16*16*ch]; conditioning gradients
   RET_IF(p2l_linear_bwd(ga, m->genz_w, W + L.dcond, B, cond, 16 * 16 * m->ch, 0, st));
+  RET_IF(p2l_arb_defer_flush(st));
   RET_IF(p2l_cbn_fold_bwd(W + L.ds, W + L.dt, m->cbn_mean, m->cbn_rstd, W + L.draw,
                           W + L.draw + CT, B, CT, 2 * CT, st));
   RET_IF(p2l_linear_bwd(W + L.draw, m->cbn_w, W + L.dcond, B, cond, 2 * CT, 1, st));

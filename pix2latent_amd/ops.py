@@ -103,7 +103,10 @@ def gemm(A, B, batch, M, Nn, K, a_kmajor=False, b_kmajor=False, alpha=1.0, Cacc=
     d.alpha = alpha
     d.accumulate = int(Cacc is not None)
     Cm = Cacc if Cacc is not None else torch.empty(batch, M, Nn, device=A.device)
-    N.check(_lib().p2l_gemm(C.byref(d), N.ptr(A), N.ptr(B), N.ptr(Cm), N.stream()), 'gemm')
+    wsb = _lib().p2l_gemm_ws_bytes(C.byref(d))      # > 0: deep-K product, split over K
+    ws = torch.empty(max(wsb // 4, 1), device=A.device)
+    N.check(_lib().p2l_gemm_ws(C.byref(d), N.ptr(A), N.ptr(B), N.ptr(Cm), N.ptr(ws),
+                               C.c_size_t(wsb), N.stream()), 'gemm')
     return Cm
 
 

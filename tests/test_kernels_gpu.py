@@ -278,6 +278,31 @@ def test_gemm_layouts(dev, O, akm, bkm):
     assert relerr(C2.cpu(), 2 * ref) < 2e-5
 
 
+@pytest.mark.parametrize('akm,bkm', [(False, False), (True, True)])
+def test_gemm_splitk(dev, O, akm, bkm):
+    # deep K, few output tiles: the K range is split over blocks and summed in a fixed order
+    from pix2latent_amd import _native as N
+    import ctypes as C
+    g = torch.Generator().manual_seed(5)
+    batch, M, Nn, K = 2, 256, 64, 2048
+    d = N.P2LGemm()
+    d.batch, d.M, d.N, d.K = batch, M, Nn, K
+    assert N.lib().p2l_gemm_ws_bytes(C.byref(d)) > 0
+    A = torch.randn(batch, M, K, generator=g)
+    Bm = torch.randn(batch, Nn, K, generator=g)
+    ref = torch.bmm(A.double(), Bm.double().transpose(1, 2)) * 0.5
+    Ad = (A.transpose(1, 2) if akm else A).contiguous().to(dev)
+    Bd = (Bm.transpose(1, 2) if bkm else Bm).contiguous().to(dev)
+    Cm = O.gemm(Ad, Bd, batch, M, Nn, K, a_kmajor=akm, b_kmajor=bkm, alpha=0.5)
+    C1 = O.gemm(Ad, Bd, batch, M, Nn, K, a_kmajor=akm, b_kmajor=bkm, alpha=0.5)
+    torch.cuda.synchronize()
+    assert relerr(Cm.cpu().double(), ref) < 2e-5
+    assert torch.equal(Cm, C1)                         # deterministic
+    C2 = O.gemm(Ad, Bd, batch, M, Nn, K, a_kmajor=akm, b_kmajor=bkm, alpha=0.5, Cacc=Cm.clone())
+    torch.cuda.synchronize()
+    assert relerr(C2.cpu().double(), 2 * ref) < 2e-5
+
+
 @pytest.mark.parametrize('Bn', [1, 9, 18])
 def test_linear_fwd_bwd(dev, O, Bn):
     g = torch.Generator().manual_seed(4)
