@@ -145,6 +145,13 @@ int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
 /* same, plus the algorithmic bytes of the timed launches (each operand tensor once +
  * packed weights); index 0 = 3x3 launches, 1 = 1x1 launches */
 int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]);
+/* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
+ * of a 26 ms step), so a caller that times a whole step loop can ask for only every
+ * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;
+ * launch number n of that step is timed iff n % period == i % period, so after `period`
+ * steps every launch of the step has been timed once.  Without the call every launch is
+ * timed. */
+int p2l_prof_step(int step, int period);
 
 /* Extra epilogue terms of the StyleGAN2 styled conv (p2l_conv_fwd_ex):
  *   v = acc * oscale[b][n] + noise_w * noise[b][pixel] + bias[n] ; act            */

@@ -65,6 +65,7 @@ struct ConvProf {
   std::vector<double> bytes;
   std::vector<int> kind;
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
+  int seq = 0, period = 1, phase = 0;       // sampling (p2l_prof_step)
 } g_prof;
 
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
@@ -1171,7 +1172,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   hipStream_t st = (hipStream_t)stream;
 
   int prof_slot = -1;
-  if (g_prof.on && g_prof.n < (int)g_prof.flops.size()) {
+  if (g_prof.on && g_prof.n < (int)g_prof.flops.size() &&
+      (g_prof.seq++ % g_prof.period) == g_prof.phase) {
     prof_slot = g_prof.n++;
     g_prof.flops[prof_slot] = d->algo_flops > 0.0
         ? d->algo_flops
@@ -1406,7 +1408,16 @@ extern "C" int p2l_prof_begin(int max_launches) {
   g_prof.kind.assign(max_launches, 0);
   g_prof.shape.assign(max_launches, {});
   g_prof.n = 0;
+  g_prof.seq = 0; g_prof.period = 1; g_prof.phase = 0;
   g_prof.on = true;
+  return P2L_OK;
+}
+
+extern "C" int p2l_prof_step(int step, int period) {
+  if (step < 0 || period < 1) return P2L_EINVAL;
+  g_prof.seq = 0;
+  g_prof.period = period;
+  g_prof.phase = step % period;
   return P2L_OK;
 }
 

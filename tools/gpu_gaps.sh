@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/gaps -o g -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-leg > /dev/null 2> $R/gpurun_out/gaps.err
 cd $R
+python tools/underfilled.py $(ls gpurun_out/gaps/*kernel_trace.csv | head -1) > gpurun_out/underfilled.txt 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/gaps/*kernel_trace.csv')[0]
