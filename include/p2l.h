@@ -120,6 +120,14 @@ int p2l_conv_arb_fusable(const P2LConv* d);
 int p2l_conv_arb_nblk(const P2LConv* d);
 int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
                        const float* w, float* dx, void* stream);
+/* Split-K form (d->splitk > 1, small launches): the K slices go to `workspace`
+ * (p2l_conv_workspace_bytes) and the deterministic finish kernel applies the activation
+ * backward; `partial` then needs 2*B*p2l_conv_arb_nblk_ws(d)*Cout floats (one partial per
+ * 2x2 quad).  Falls back to p2l_conv_dgrad_arb when d->splitk resolves to 1. */
+int p2l_conv_arb_split_fusable(const P2LConv* d);
+int p2l_conv_arb_nblk_ws(const P2LConv* d);
+int p2l_conv_dgrad_arb_ws(const P2LConv* d, const P2LArb* arb, const float* dy, const float* w,
+                          float* dx, void* workspace, size_t ws_bytes, void* stream);
 int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn, int nblk, int C,
                    int out_bstride, void* stream);
 /* Deferred form of the finish (per host thread): between _begin and _flush every

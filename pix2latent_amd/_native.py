@@ -154,7 +154,8 @@ EXPORTS = [
     'p2l_sg2_clamp16_fwd', 'p2l_sg2_clamp16_bwd', 'p2l_broadcast_rows', 'p2l_add_inplace',
     'p2l_sg2_ws_bytes', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
     'p2l_sg2_mapping_bwd', 'p2l_set_conv_variant', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
-    'p2l_conv_dgrad_arb', 'p2l_arb_finish', 'p2l_arb_defer_begin', 'p2l_arb_defer_flush',
+    'p2l_conv_dgrad_arb', 'p2l_conv_arb_split_fusable', 'p2l_conv_arb_nblk_ws',
+    'p2l_conv_dgrad_arb_ws', 'p2l_arb_finish', 'p2l_arb_defer_begin', 'p2l_arb_defer_flush',
     'p2l_arb_defer_cancel',
     'p2l_gconv_fwd', 'p2l_maxpool3s2_fwd', 'p2l_maxpool3s2_bwd', 'p2l_conv1_dgrad',
     'p2l_alex_cache_floats', 'p2l_alexloss_ws_bytes', 'p2l_alexloss_prepare', 'p2l_alexloss_fwd',

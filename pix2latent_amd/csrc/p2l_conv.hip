@@ -889,9 +889,55 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
     acc += __shfl_xor(acc, 32, 64);
     a[s] = acc;
   }
-  if (live && zp == 0)
+  if (!(live && zp == 0)) return;
+  if (k.arb_x == nullptr) {
     epilogue_quad<false>(k, a, (b * k.H + 2 * qy) * k.W + 2 * qx, b, 2 * qy, 2 * qx, n,
                          k.bias ? k.bias[n] : 0.f);
+    return;
+  }
+  // fused backward of relu(x*s+t) on the finished input gradient (same arithmetic as the
+  // ARB branch of epilogue_vec, one channel per lane); the per-(sample, channel) sums are
+  // written per QUAD (arb_nblk = quads per image) and reduced by p2l_arb_finish
+  const float sc = k.arb_s[(size_t)b * k.arb_bstride + n];
+  const float tc = k.arb_t[(size_t)b * k.arb_bstride + n];
+  const bool pool_sum = k.pool == P2L_POOL_SUM;
+  const bool has_skip = k.arb_skip && n < k.arb_skip_C;
+  float v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) v[s] = k.alpha * a[s];
+  if (pool_sum) v[0] = (v[0] + v[1]) + (v[2] + v[3]);
+  float* dst = pool_sum ? k.yp : k.y;
+  const unsigned dld = (unsigned)(pool_sum ? k.yp_ld : k.y_ld);
+  const int Wo = pool_sum ? Wh : k.W, Ho = pool_sum ? Hh : k.H;
+  float sgx = 0.f, sg = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s < (pool_sum ? 1 : 4)) {
+      const int yy = pool_sum ? qy : 2 * qy + (s >> 1), xx = pool_sum ? qx : 2 * qx + (s & 1);
+      const unsigned pix = (unsigned)((b * Ho + yy) * Wo + xx);
+      const float xv = k.arb_x[(size_t)pix * k.arb_x_ld + n];
+      const float pre = xv * sc + tc;
+      const float g = (k.arb_nomask || pre > 0.f) ? v[s] : 0.f;
+      float o = g * sc;
+      if (has_skip) {
+        const unsigned ld = (unsigned)k.arb_skip_ld;
+        if (k.arb_skip_ups) {
+          const unsigned W2 = 2u * (unsigned)Wo;
+          const unsigned cq = ((unsigned)(b * 2 * Ho + 2 * yy)) * W2 + 2u * (unsigned)xx;
+          o += (k.arb_skip[(size_t)cq * ld + n] + k.arb_skip[(size_t)(cq + 1) * ld + n]) +
+               (k.arb_skip[(size_t)(cq + W2) * ld + n] + k.arb_skip[(size_t)(cq + W2 + 1) * ld + n]);
+        } else {
+          o += k.arb_skip[(size_t)pix * ld + n];
+        }
+      }
+      dst[(size_t)pix * dld + n] = o;
+      sgx += g * xv;
+      sg += g;
+    }
+  }
+  const size_t po = ((size_t)b * k.arb_nblk + (size_t)qy * Wh + qx) * k.Cout + n;
+  k.arb_partial[po] = sgx;
+  k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + po] = sg;
 }
 
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
@@ -1033,6 +1079,7 @@ int choose_bn(const P2LConv* d, int n_mtiles) {
   if (d->Cout % 64) return 32;
   const int ph = (d->ups == 2) ? 4 : 1;      // sub-pixel forward: 4 phases per tile
   const int n64 = n_mtiles * (d->Cout / 64) * ph, n32 = n_mtiles * (d->Cout / 32) * ph;
+  if (n64 < 256 && d->ups >= 2) return 32;   // sub-pixel forms never split K: more blocks
   if (n64 < 256) return 64;               // split-K regime: keep the fatter tile
   const double t64 = (double)cdiv(n64, 256) * 64.0;
   const double t32 = (double)cdiv(n32, 256) * 32.0 * 1.06;   // thinner tile: less reuse
@@ -1085,7 +1132,7 @@ extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nblk = k.n_mtiles * (d->Cout / bn);
   const int nchunks = d->Cin / kc;
-  if (nblk >= 192) return 1;
+  if (nblk >= 192) return 1;   // (splitting the 192...255-block launches too measured slower)
   int s = cdiv(512, nblk);
   // keep >= 2 chunks of work per split for 3x3 (18 tap-chunks), >= 4 for 1x1
   const int min_chunks = (d->taps == 9) ? 2 : 4;
@@ -1098,6 +1145,16 @@ extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
   if (d->splitk <= 1) return 0;
   return (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
+}
+
+// the split-K factor conv_launch_impl ends up with for d->splitk
+static int effective_splitk(const P2LConv* d) {
+  if (d->splitk <= 1 || d->ups >= 2) return 1;
+  const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
+  const int nchunks = d->Cin / kc;
+  int sk = d->splitk > nchunks ? nchunks : d->splitk;
+  const int per = cdiv(nchunks, sk);
+  return cdiv(nchunks, per);
 }
 
 static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvExtra* ex,
@@ -1149,7 +1206,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   if (k.partial && (arb || d->pool != P2L_POOL_NONE || d->splitk > 1)) return P2L_EUNSUP;
   if (arb) {
-    if (k.tb_log != 0 || d->splitk > 1 || res || mask || d->act != P2L_ACT_NONE ||
+    // one image per tile for the in-kernel form; with split-K the finish kernel does it
+    if ((k.tb_log != 0 && effective_splitk(d) <= 1) || res || mask || d->act != P2L_ACT_NONE ||
         d->pool == P2L_POOL_MAX || !arb->x || !arb->s || !arb->t || !arb->partial)
       return P2L_EUNSUP;
     k.arb_x = arb->x; k.arb_s = arb->s; k.arb_t = arb->t; k.arb_skip = arb->skip;
@@ -1168,6 +1226,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (k.splitk > 1) {
     const size_t need = (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
     if (!workspace || ws_bytes < need) return P2L_EWS;
+    if (arb) k.arb_nblk = (d->H >> 1) * (d->W >> 1);    // finish kernel: one partial per quad
   }
   hipStream_t st = (hipStream_t)stream;
 
@@ -1346,6 +1405,33 @@ extern "C" int p2l_conv_arb_nblk(const P2LConv* d) {
   ConvK k{};
   if (!d || choose_tile(d, k) != P2L_OK) return 0;
   return k.n_mtiles / d->B;
+}
+
+extern "C" int p2l_conv_arb_split_fusable(const P2LConv* d) {
+  ConvK k{};
+  if (!d || choose_tile(d, k) != P2L_OK || k.partial) return 0;
+  return effective_splitk(d) > 1 && d->pool != P2L_POOL_MAX;
+}
+
+extern "C" int p2l_conv_arb_nblk_ws(const P2LConv* d) {
+  if (!d) return 0;
+  return effective_splitk(d) > 1 ? (d->H >> 1) * (d->W >> 1) : p2l_conv_arb_nblk(d);
+}
+
+extern "C" int p2l_conv_dgrad_arb_ws(const P2LConv* d, const P2LArb* arb, const float* dy,
+                                     const float* w, float* dx, void* workspace, size_t ws_bytes,
+                                     void* stream) {
+  if (!d || !arb || !dx) return P2L_EINVAL;
+  P2LConv dd = *d;
+  if (dd.ups == 3) dd.pool = P2L_POOL_NONE;
+  if (effective_splitk(&dd) <= 1) return p2l_conv_dgrad_arb(d, arb, dy, w, dx, stream);
+  const bool pooled = dd.pool == P2L_POOL_SUM;
+  int rc = conv_launch_impl(&dd, arb, nullptr, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
+                            pooled ? nullptr : dx, pooled ? dx : nullptr, workspace, ws_bytes,
+                            stream);
+  if (rc) return rc;
+  return p2l_arb_finish(arb->partial, arb->ds, arb->dt, dd.B, p2l_conv_arb_nblk_ws(&dd), dd.Cout,
+                        arb->dsdt_bstride, stream);
 }
 
 extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,

@@ -100,12 +100,14 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
   const bool pooled = c.d.pool == P2L_POOL_SUM;
   const bool half = pooled || c.d.ups == 3;          // result lives at half resolution
   const int Ho = half ? c.d.H / 2 : c.d.H, Wo = half ? c.d.W / 2 : c.d.W;
-  if (c.d.splitk == 1 && p2l_conv_arb_fusable(&c.d)) {
+  const bool split_fused = c.d.splitk > 1 && p2l_conv_arb_split_fusable(&c.d) &&
+                           p2l_conv_workspace_bytes(&c.d) <= skws_floats * sizeof(float);
+  if (split_fused || (c.d.splitk == 1 && p2l_conv_arb_fusable(&c.d))) {
     P2LArb arb{};
     arb.x = a.x; arb.x_ld = a.x_ld; arb.s = a.s; arb.t = a.t; arb.st_bstride = a.st_bstride;
     arb.skip = a.skip; arb.skip_ld = a.skip_ld; arb.skip_C = a.skip_C; arb.skip_ups = a.skip_ups;
     arb.ds = a.ds; arb.dt = a.dt; arb.dsdt_bstride = a.dsdt_bstride; arb.partial = part;
-    return p2l_conv_dgrad_arb(&c.d, &arb, c.x, c.w, dx, st);
+    return p2l_conv_dgrad_arb_ws(&c.d, &arb, c.x, c.w, dx, skws, skws_floats * sizeof(float), st);
   }
   if (pooled) { c.yp = tmp; c.y = nullptr; } else { c.y = tmp; c.yp = nullptr; }
   RET_IF(run_conv(c, skws, skws_floats, st));
@@ -205,9 +207,27 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
     const size_t acts[] = {(size_t)B * H * H * g.cin, (size_t)B * Ho * Ho * mid,
                            (size_t)B * Ho * Ho * g.cout};
     for (size_t v : acts) if (v > max_act) max_act = v;
-    const int nblk = cdiv(Ho * Ho, 128);   // fused epilogue: one partial per 128-pixel tile
-    const size_t cmax = (size_t)(g.cin > mid ? g.cin : mid);
-    o.pf = 2 * (size_t)B * nblk * cmax;
+    {
+      // partial sums per (sample, tile | quad, channel) of the four activation-backwards of
+      // this block: one per 128-pixel tile in the conv epilogue, one per 2x2 quad when the
+      // input-gradient conv splits K (small batches) and its finish kernel does the work
+      auto pf_of = [&](int Hc, int Cin, int Cout, int taps, int pool) {
+        ConvCall c = mk_conv(B, Hc, Hc, Cin, Cout, taps);
+        c.d.pool = pool;
+        c.d.splitk = p2l_conv_suggest_splitk(&c.d);
+        int nb = p2l_conv_arb_nblk_ws(&c.d);
+        const int tiles = cdiv(Hc * Hc, 128);
+        if (tiles > nb) nb = tiles;
+        return 2 * (size_t)B * nb * Cout;
+      };
+      o.pf = pf_of(Ho, g.cout, mid, 1, P2L_POOL_NONE);
+      size_t f = pf_of(Ho, mid, mid, 9, P2L_POOL_NONE);
+      if (f > o.pf) o.pf = f;
+      f = pf_of(Ho, mid, mid, 9, g.up ? P2L_POOL_SUM : P2L_POOL_NONE);
+      if (f > o.pf) o.pf = f;
+      f = pf_of(H, mid, g.cin, 1, P2L_POOL_NONE);
+      if (f > o.pf) o.pf = f;
+    }
     sum_partial += 4 * o.pf;
     // split-K workspace for fwd and dgrad convs of this block
     upd_sk(H, g.cin, mid, 1);  upd_sk(Ho, mid, mid, 9);  upd_sk(Ho, mid, g.cout, 1);

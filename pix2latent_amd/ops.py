@@ -216,9 +216,11 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
 
 
 def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
-                   skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32):
+                   skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32, splitk=1):
     """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
-    H, W = resolution of dy; Cin = channels of dy, Cout = channels of x."""
+    H, W = resolution of dy; Cin = channels of dy, Cout = channels of x.
+    splitk > 1: the split-K form, activation backward in the finish kernel
+    (p2l_conv_dgrad_arb_ws)."""
     d = N.P2LConv()
     d.wfmt = wfmt
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
@@ -227,9 +229,13 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
     d.pool = N.POOL_SUM if (pool_sum and not subpix) else N.POOL_NONE
     d.ups = 3 if subpix else 0
     d.y_ld = d.yp_ld = d.n_store = Cout
-    d.splitk = 1
-    assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1
-    nblk = _lib().p2l_conv_arb_nblk(C.byref(d))
+    d.splitk = splitk
+    if splitk > 1:
+        assert _lib().p2l_conv_arb_split_fusable(C.byref(d)) == 1
+        nblk = _lib().p2l_conv_arb_nblk_ws(C.byref(d))
+    else:
+        assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1
+        nblk = _lib().p2l_conv_arb_nblk(C.byref(d))
     part = torch.empty(2 * B * nblk * Cout, device=dy.device)
     Ho, Wo = (H // 2, W // 2) if (pool_sum or subpix) else (H, W)
     dx = torch.empty(B, Ho, Wo, Cout, device=dy.device)
@@ -242,8 +248,15 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
         a.skip, a.skip_ld, a.skip_C, a.skip_ups = skip.data_ptr(), skip.shape[-1], skip_C, int(skip_ups)
     a.ds, a.dt, a.dsdt_bstride = ds.data_ptr(), dt.data_ptr(), Cout
     a.partial = part.data_ptr()
-    N.check(_lib().p2l_conv_dgrad_arb(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
-                                      N.ptr(dx), N.stream()), 'conv_dgrad_arb')
+    if splitk > 1:
+        wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
+        ws = torch.empty(max(wsb // 4, 1), device=dy.device)
+        N.check(_lib().p2l_conv_dgrad_arb_ws(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
+                                             N.ptr(dx), N.ptr(ws), C.c_size_t(wsb), N.stream()),
+                'conv_dgrad_arb_ws')
+    else:
+        N.check(_lib().p2l_conv_dgrad_arb(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
+                                          N.ptr(dx), N.stream()), 'conv_dgrad_arb')
     return dx, ds, dt
 
 

@@ -220,12 +220,14 @@ def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
     assert relerr(nchw(dx)[:, :Cin], x.grad) < 2e-5
 
 
+@pytest.mark.parametrize('splitk', [1, 4], ids=['epilogue', 'splitk-finish'])
 @pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('taps,ups,skip', [(9, False, None), (9, True, None), (1, False, 'same'),
                                            (1, False, 'ups')])
-def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt):
+def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk):
     """dgrad conv with the consumer's CBN+ReLU backward (and GenBlock shortcut gradient)
-    fused into its epilogue, vs autograd through relu(x*s+t) -> (nearest x2) -> conv."""
+    fused into its epilogue - or, split over K, into the deterministic finish kernel - vs
+    autograd through relu(x*s+t) -> (nearest x2) -> conv."""
     g = torch.Generator().manual_seed(12)
     B, C, Co, H = 3, 64, 128, 16           # x: [B,C,H,H] ; y: [B,Co,Ho,Ho]
     k = 3 if taps == 9 else 1
@@ -254,7 +256,7 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt):
     wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True, wfmt=wfmt)
     dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, Ho, Ho, Co, C, taps, nhwc(x.detach(), dev),
                                   s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups, wfmt=wfmt,
-                                  skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'))
+                                  skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'), splitk=splitk)
     torch.cuda.synchronize()
     assert relerr(nchw(dx), exp_dx) < 2e-5
     assert relerr(ds.cpu(), s.grad) < 5e-5
