@@ -37,7 +37,8 @@ class _BaseOptimizer():
                 whole population fits, so the chunk size that DEFINES the
                 semantics (gradient factor 1/b_chunk, reference closure.py:58) is
                 kept while the execution batch may be larger.  None = the
-                reference behaviour (execute chunk by chunk).
+                reference behaviour (execute chunk by chunk); 'all' = the whole
+                (rank-local) population in one pass.
         """
         self.max_batch_size = max_batch_size
         self.exec_batch_size = exec_batch_size
@@ -123,8 +124,10 @@ class _BaseOptimizer():
         if self.track_variables:
             self.track(variables)
 
+        ebs = self.exec_batch_size
+        if ebs == 'all':
+            ebs = variables.num_samples
         if not self.shard.enabled:
-            ebs = self.exec_batch_size
             if ebs is not None and ebs > self.max_batch_size and \
                     variables.num_samples > self.max_batch_size:
                 n = variables.num_samples
@@ -147,9 +150,10 @@ class _BaseOptimizer():
         if hi > lo:
             local = slice_vars(variables, lo, hi)
             gs = self._grad_scale(n, lo, hi, first.device)
+            mbs = self.max_batch_size if ebs is None else max(self.max_batch_size, ebs)
             out, loss, self.other = step(self.model, local, loss_fn=self.loss_fn,
                                          optimize=optimize,
-                                         max_batch_size=self.max_batch_size, grad_scale=gs)
+                                         max_batch_size=mbs, grad_scale=gs)
             loss_t = loss.tensor() if isinstance(loss, LazyLosses) else \
                 torch.tensor(np.asarray(loss), dtype=torch.float32, device=first.device)
         else:

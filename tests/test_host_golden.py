@@ -175,14 +175,15 @@ def test_gradient_optimizer_trajectory_golden():
     assert [c[0] for c in model2.calls[-3:]] == [int(c[0]) for c in g['rescore_model_calls']]
 
 
-def test_exec_batch_size_keeps_reference_trajectory():
+@pytest.mark.parametrize('ebs', [5, 'all'])
+def test_exec_batch_size_keeps_reference_trajectory(ebs):
     """executing the whole population in one pass (exec_batch_size) with the
     reference chunk's gradient scale reproduces the chunked golden trajectory."""
     from pix2latent_amd.optimizer import GradientOptimizer
     g = gold('gradient_optimizer')
     model = ToyGenerator()
     torch.manual_seed(42)
-    opt = GradientOptimizer(model, make_vm(), toy_loss, max_batch_size=2, exec_batch_size=5)
+    opt = GradientOptimizer(model, make_vm(), toy_loss, max_batch_size=2, exec_batch_size=ebs)
     variables, outs, losses = opt.optimize(num_samples=5, grad_steps=3)
     assert [c[0] for c in model.calls] == [5, 5, 5]
     assert np.allclose(np.array(losses[-1][1]['loss']), g['final_loss'], atol=1e-6)

@@ -21,7 +21,9 @@ for name, size, n, mb in (('cars', 512, 32, 9), ('cars', 512, 9, 9), ('ffhq', 10
                 hook_fn=hook.Compose(hook.NormalPerturb(sigma=0.05), hook.Clamp(2.0)), grad_free=True)
     for nm, t in (('target', target), ('weight', weight), ('loss_mask', loss_mask)):
         vm.register(nm, (3, size, size), 'output', requires_grad=False, default=t)
-    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=mb)
+    ebs = os.environ.get('P2L_EXEC') or None        # candidates per device pass: int | 'all'
+    ebs = int(ebs) if ebs and ebs != 'all' else ebs
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=mb, exec_batch_size=ebs)
     variables = vm.initialize(num_samples=n)
     for i in range(2):
         opt.step(variables, optimize=True, transform=(i == 0))
