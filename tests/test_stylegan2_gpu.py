@@ -125,9 +125,11 @@ def _register(vm, target, weight, loss_mask, lr=0.05):
         vm.register(name, (3, SIZE, SIZE), 'output', requires_grad=False, default=t)
 
 
-def test_gradient_optimizer_stylegan2_vs_cpu_oracle(sg, dev):
+@pytest.mark.parametrize('ebs', [None, 'all'], ids=['chunked', 'one-pass'])
+def test_gradient_optimizer_stylegan2_vs_cpu_oracle(sg, dev, ebs):
     """examples/invert_stylegan2_cars_adam.py reduced to SIZE, 3 candidates x 3 Adam steps,
-    with weight AND loss_mask, driven on the native engine and on the CPU oracle."""
+    with weight AND loss_mask, driven on the native engine (in the reference's chunks of 2,
+    or all 3 in one device pass with the chunk's gradient scale) and on the CPU oracle."""
     from pix2latent_amd import VariableManager
     from pix2latent_amd.utils import synthetic as S
     from pix2latent_amd.optimizer import GradientOptimizer
@@ -140,11 +142,12 @@ def test_gradient_optimizer_stylegan2_vs_cpu_oracle(sg, dev):
     loss_mask = torch.zeros(3, SIZE, SIZE)
     loss_mask[:, SIZE // 8:-SIZE // 8, :] += 1.0
 
-    def run(device, model, loss_fn):
+    def run(device, model, loss_fn, exec_batch_size=None):
         vm = VariableManager(device=device)
         _register(vm, target, weight, loss_mask)
         torch.manual_seed(5)
-        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=2)
+        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=2,
+                                exec_batch_size=exec_batch_size)
         variables = vm.initialize(num_samples=3)
         losses = []
         for i in range(3):
@@ -155,7 +158,7 @@ def test_gradient_optimizer_stylegan2_vs_cpu_oracle(sg, dev):
 
     l_gpu, z_gpu = run(dev, _FixedNoise(lambda z, n: sg['model'].forward_z(z, noises=n),
                                         [n.to(dev) for n in sg['noises']]),
-                       LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev))
+                       LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev), ebs)
     l_cpu, z_cpu = run('cpu', _FixedNoise(lambda z, n: R.forward_z(W, z, n, SIZE), sg['noises']),
                        lambda out, target, weight, loss_mask:
                        L.projection_loss(Wv, out, target, weight, loss_mask))
