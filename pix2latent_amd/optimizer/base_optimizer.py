@@ -10,6 +10,8 @@ track :100-107, log_result :123-141) with three MI355X-first changes:
   * `apply_transform` writes into the contiguous variable buffers in place, which
     also invalidates the loss' cached target features.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -41,6 +43,11 @@ class _BaseOptimizer():
                 (rank-local) population in one pass.
         """
         self.max_batch_size = max_batch_size
+        if exec_batch_size is None:
+            # unmodified example scripts can opt in from the environment
+            env = os.environ.get('P2L_EXEC_BATCH', '').strip().lower()
+            if env:
+                exec_batch_size = 'all' if env == 'all' else int(env)
         self.exec_batch_size = exec_batch_size
         self.model = model.eval() if hasattr(model, 'eval') else model
         self.var_manager = var_manager

@@ -191,6 +191,20 @@ def test_exec_batch_size_keeps_reference_trajectory(ebs):
     assert np.allclose(torch.stack(list(variables.input.c.data)).detach().numpy(), g['final_c'], atol=1e-6)
 
 
+def test_exec_batch_from_environment(monkeypatch):
+    """P2L_EXEC_BATCH lets an unmodified example script run the population in one pass"""
+    from pix2latent_amd.optimizer import GradientOptimizer
+    g = gold('gradient_optimizer')
+    monkeypatch.setenv('P2L_EXEC_BATCH', 'all')
+    model = ToyGenerator()
+    torch.manual_seed(42)
+    opt = GradientOptimizer(model, make_vm(), toy_loss, max_batch_size=2)
+    assert opt.exec_batch_size == 'all'
+    variables, outs, losses = opt.optimize(num_samples=5, grad_steps=3)
+    assert [c[0] for c in model.calls] == [5, 5, 5]
+    assert np.allclose(np.array(losses[-1][1]['loss']), g['final_loss'], atol=1e-6)
+
+
 def _patch_cma(monkeypatch):
     import pix2latent_amd.optimizer.base_cma_optimizer as B
     FakeCMAES.log = []
