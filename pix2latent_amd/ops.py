@@ -216,11 +216,13 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
 
 
 def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
-                   skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32, splitk=1):
+                   skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32, splitk=1,
+                   keep=None):
     """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
     H, W = resolution of dy; Cin = channels of dy, Cout = channels of x.
     splitk > 1: the split-K form, activation backward in the finish kernel
-    (p2l_conv_dgrad_arb_ws)."""
+    (p2l_conv_dgrad_arb_ws).  keep: list that receives the partial-sum buffer (it must stay
+    alive until p2l_arb_defer_flush when the finish is deferred)."""
     d = N.P2LConv()
     d.wfmt = wfmt
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
@@ -237,6 +239,8 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
         assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1
         nblk = _lib().p2l_conv_arb_nblk(C.byref(d))
     part = torch.empty(2 * B * nblk * Cout, device=dy.device)
+    if keep is not None:
+        keep.append(part)
     Ho, Wo = (H // 2, W // 2) if (pool_sum or subpix) else (H, W)
     dx = torch.empty(B, Ho, Wo, Cout, device=dy.device)
     ds = torch.empty(B, Cout, device=dy.device)

@@ -263,6 +263,61 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk)
     assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
+def test_arb_finish_deferred_group(dev, O):
+    """p2l_arb_defer_begin/flush: the second reduction stage of several activation-backwards
+    in ONE launch gives exactly what the per-layer launches give."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(21)
+    B, H = 2, 16
+    cases = []
+    for C, Co, taps in ((64, 128, 9), (128, 64, 1), (96, 64, 1)):
+        k = 3 if taps == 9 else 1
+        x = torch.randn(B, H, H, C, generator=g).to(dev)
+        s = (0.5 + torch.rand(B, C, generator=g)).to(dev)
+        t = (0.3 * torch.randn(B, C, generator=g)).to(dev)
+        w = torch.randn(Co, C, k, k, generator=g) / math.sqrt(C * k * k)
+        dy = torch.randn(B, H, H, Co, generator=g).to(dev)
+        wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True)
+        cases.append((dy, wt, Co, C, taps, x, s, t))
+
+    keep = []                      # partial buffers must outlive the deferred flush
+
+    def run_all():
+        return [O.conv_dgrad_arb(dy, wt, B, H, H, Co, C, taps, x, s, t, C, keep=keep)
+                for dy, wt, Co, C, taps, x, s, t in cases]
+
+    ref = run_all()
+    torch.cuda.synchronize()
+    N.lib().p2l_arb_defer_begin()
+    try:
+        got = run_all()            # ds / dt are not written yet
+        N.check(N.lib().p2l_arb_defer_flush(N.stream()), 'arb_defer_flush')
+    finally:
+        N.lib().p2l_arb_defer_cancel()
+    torch.cuda.synchronize()
+    for (dx0, ds0, dt0), (dx1, ds1, dt1) in zip(ref, got):
+        assert torch.equal(dx0, dx1) and torch.equal(ds0, ds1) and torch.equal(dt0, dt1)
+
+
+def test_conv_profiler_sampling(dev, O):
+    """p2l_prof_step(i, period): launch n of step i is timed iff n % period == i % period"""
+    import ctypes as C
+    from pix2latent_amd import _native as N
+    lib = N.lib()
+    x = torch.randn(1, 16, 16, 32, device=dev)
+    w = O.pack_conv_weight(torch.randn(32, 32, 1, 1, device=dev), 1, 32, 32)
+    N.check(lib.p2l_prof_begin(64), 'prof_begin')
+    for step in range(4):
+        N.check(lib.p2l_prof_step(step, 4), 'prof_step')
+        for _ in range(8):
+            O.conv(x, w, 1, 16, 16, 32, 32, 1)
+    torch.cuda.synchronize()
+    f, m, c = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
+    N.check(lib.p2l_prof_end(f, m, c), 'prof_end')
+    assert c[1] == 8 and c[0] == 0          # 4 steps x 8 launches, every 4th timed
+    assert m[1] > 0 and f[1] == 8 * 2.0 * 16 * 16 * 32 * 32
+
+
 @pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_layouts(dev, O, akm, bkm):
     g = torch.Generator().manual_seed(3)
