@@ -15,13 +15,14 @@ import os
 import numpy as np
 import torch
 
-from .closure import step, LazyLosses
-from ..parallel import PopulationShard
+from .closure import step, apply_hooks, LazyLosses
+from .search_loop import SearchLoopMixin
+from ..parallel import PopulationShard, ShardedLosses
 from ..utils.image import to_image, to_grid, binarize, resize_area
 from ..variable_manager import slice_vars
 
 
-class _BaseOptimizer():
+class _BaseOptimizer(SearchLoopMixin):
     """ Base template for gradient optimization """
 
     def __init__(self, model, var_manager, loss_fn, max_batch_size=9,
@@ -102,12 +103,17 @@ class _BaseOptimizer():
         src_type = self.var_manager.variable_info[src_name]['var_type']
         dst_type = self.var_manager.variable_info[dst_name]['var_type']
 
-        src_data = torch.stack(list(variables[src_type][src_name].data))
-        dst_data = torch.stack(list(variables[dst_type][dst_name].data))
+        # a rank only ever looks at its own block of candidates: warp just those rows
+        n = variables.num_samples
+        lo, hi = self.shard.bounds(n) if self.shard.enabled else (0, n)
+        if hi == lo:
+            return
+        src_data = torch.stack(list(variables[src_type][src_name].data[lo:hi]))
+        dst_data = torch.stack(list(variables[dst_type][dst_name].data[lo:hi]))
 
         new_dst_data = t_fn(dst_data, src_data)
         for i in range(len(new_dst_data)):
-            variables[dst_type][dst_name].data[i].copy_(new_dst_data[i])
+            variables[dst_type][dst_name].data[lo + i].copy_(new_dst_data[i])
         return
 
     # -- the step --------------------------------------------------------------
@@ -124,6 +130,8 @@ class _BaseOptimizer():
         return cache[key]
 
     def step(self, variables, optimize=True, transform=False):
+        """one pass over the population: (transform on request) -> track -> closure.step on
+        this rank's block of candidates, executed `exec_batch_size` at a time"""
         if len(self.transform_fns) > 0 and transform:
             for _, transform_dict in self.transform_fns.items():
                 self.apply_transform(variables, transform_dict)
@@ -131,45 +139,47 @@ class _BaseOptimizer():
         if self.track_variables:
             self.track(variables)
 
-        ebs = self.exec_batch_size
-        if ebs == 'all':
-            ebs = variables.num_samples
-        if not self.shard.enabled:
-            if ebs is not None and ebs > self.max_batch_size and \
-                    variables.num_samples > self.max_batch_size:
-                n = variables.num_samples
-                first = next(iter(variables.input.values())).data[0]
-                self.out, self.loss, self.other = step(
-                    self.model, variables, loss_fn=self.loss_fn, optimize=optimize,
-                    max_batch_size=ebs, grad_scale=self._grad_scale(n, 0, n, first.device))
-            else:
-                self.out, self.loss, self.other = step(
-                    self.model, variables,
-                    loss_fn=self.loss_fn,
-                    optimize=optimize,
-                    max_batch_size=self.max_batch_size
-                )
+        n = variables.num_samples
+        mbs = self.max_batch_size
+        ebs = n if self.exec_batch_size == 'all' else self.exec_batch_size
+        sharded = self.shard.enabled
+        lo, hi = self.shard.bounds(n) if sharded else (0, n)
+        first = next(iter(variables.input.values())).data[0]
+
+        if not sharded and (ebs is None or ebs <= mbs or n <= mbs):
+            # the reference's own execution: chunk by chunk, gradient factor 1/b_chunk implied
+            self.out, self.loss, self.other = step(self.model, variables, loss_fn=self.loss_fn,
+                                                   optimize=optimize, max_batch_size=mbs)
             return self.out, self.loss, self.other
 
-        n = variables.num_samples
-        lo, hi = self.shard.bounds(n)
-        first = next(iter(variables.input.values())).data[0]
-        if hi > lo:
-            local = slice_vars(variables, lo, hi)
-            gs = self._grad_scale(n, lo, hi, first.device)
-            mbs = self.max_batch_size if ebs is None else max(self.max_batch_size, ebs)
-            out, loss, self.other = step(self.model, local, loss_fn=self.loss_fn,
-                                         optimize=optimize,
-                                         max_batch_size=mbs, grad_scale=gs)
-            loss_t = loss.tensor() if isinstance(loss, LazyLosses) else \
-                torch.tensor(np.asarray(loss), dtype=torch.float32, device=first.device)
-        else:
+        if hi == lo:                      # a rank without candidates (population < world)
+            self._idle_hooks(variables, n)
             out, self.other = None, {}
             loss_t = torch.zeros(0, dtype=torch.float32, device=first.device)
-        self.out_local = out
-        self.loss = LazyLosses(self.shard.all_gather_losses(loss_t, n))
-        self.out = out
+        else:
+            block = slice_vars(variables, lo, hi) if sharded else variables
+            out, loss, self.other = step(
+                self.model, block, loss_fn=self.loss_fn, optimize=optimize,
+                max_batch_size=mbs if ebs is None else max(mbs, ebs),
+                grad_scale=self._grad_scale(n, lo, hi, first.device), population=(lo, n, mbs))
+            if not sharded:
+                self.out, self.loss = out, loss
+                return self.out, self.loss, self.other
+            loss_t = loss.tensor() if isinstance(loss, LazyLosses) else \
+                torch.tensor(np.asarray(loss), dtype=torch.float32, device=first.device)
+
+        self.out_local = self.out = out
+        # ONE all-gather per generation, not per step: `ShardedLosses` gathers
+        # when it is read -- re-score before tell, log_result, end of optimize() -- points
+        # every rank reaches in the same order.  Re-scores and log=True read it right away.
+        self.loss = ShardedLosses(loss_t, self.shard, n)
+        if self.log or not optimize:
+            self.loss.gather()
         return self.out, self.loss, self.other
+
+    def _idle_hooks(self, variables, n):
+        """keep an idle rank's random stream and hook clocks in step with the others"""
+        apply_hooks(slice_vars(variables, 0, 0), (0, n), self.max_batch_size)
 
     def gather_population(self, variables):
         """after sharded optimisation: make every rank's `variables` and
@@ -178,6 +188,8 @@ class _BaseOptimizer():
             return
         n = variables.num_samples
         lo, hi = self.shard.bounds(n)
+        if isinstance(self.loss, ShardedLosses):
+            self.loss.gather()
         with torch.no_grad():
             for _, v in variables.input.items():
                 full = self.shard.all_gather_rows(torch.stack(list(v.data[lo:hi])) if hi > lo

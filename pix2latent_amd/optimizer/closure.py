@@ -25,39 +25,8 @@ import numpy as np
 import torch
 
 from ..variable_manager import split_vars, FusedAdam
-
-
-class LazyLosses(object):
-    """per-sample losses that stay on the device until they are looked at;
-    behaves like the reference's list of np.float32."""
-
-    def __init__(self, t):
-        self._t = t
-        self._np = None
-
-    def tensor(self):
-        return self._t
-
-    def _get(self):
-        if self._np is None:
-            self._np = self._t.detach().float().cpu().numpy()
-        return self._np
-
-    def __array__(self, dtype=None, copy=None):
-        a = self._get()
-        return a.astype(dtype) if dtype is not None else a
-
-    def __len__(self):
-        return int(self._t.numel())
-
-    def __iter__(self):
-        return iter(self._get())
-
-    def __getitem__(self, i):
-        return self._get()[i]
-
-    def __repr__(self):
-        return 'LazyLosses(%r)' % (self._get(),)
+from ..utils.lazy_losses import LazyLosses  # noqa: F401  (re-exported)
+from ..utils.function_hooks import HookSpan
 
 
 def _in_sync(var):
@@ -81,25 +50,45 @@ def _gather(var):
     return torch.stack(list(var.data))
 
 
-def _run_hook(var):
-    if var.hook_fn is None:
+def apply_hooks(vars, population=None, chunk=None):
+    """Runs the hooks of one step: in-place mutation of the latents before the forward pass,
+    also on forward-only passes (reference closure.py:42-44).
+
+    The reference calls every hook once per chunk of `max_batch_size` samples, inside that
+    chunk's closure.  Here all those calls are made up-front, reference chunk by reference
+    chunk over the WHOLE population and for every hooked variable of a chunk in turn -- the
+    same call sequence, hence the same random stream, whatever the execution batch size or
+    the number of ranks is.  (Safe to hoist: a chunk's hooks touch only that chunk's rows,
+    and so does the Adam update the reference interleaves with them.)
+
+    `vars` holds rows [lo, lo + num_samples) of a population of n; population = (lo, n).
+    Rows of a chunk held by another rank are passed as absent (utils/function_hooks.py)."""
+    lo, n = population if population is not None else (0, vars.num_samples)
+    hi = lo + vars.num_samples
+    hooked = [v for v in vars.input.values() if v.hook_fn is not None]
+    if not hooked:
         return
-    if hasattr(var.hook_fn, 'apply_batched') and _in_sync(var):
-        with torch.no_grad():
-            var.hook_fn.apply_batched(var.buf)
-    else:
-        var.hook_fn(var.data)
+    with torch.no_grad():
+        for c0 in range(0, n, chunk):
+            c1 = min(c0 + chunk, n)
+            s, e = max(c0, lo), min(c1, hi)
+            if s >= e:
+                s = e = c0                                 # nothing of this chunk lives here
+            for var in hooked:
+                if hasattr(var.hook_fn, 'apply_batched') and _in_sync(var):
+                    var.hook_fn.apply_batched(var.buf[s - lo:e - lo] if e > s else var.buf[0:0],
+                                              HookSpan(s, e, c0, c1))
+                elif e > s:
+                    var.hook_fn(var.data[s - lo:e - lo])
 
 
-def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
+def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, population):
     outs, losses = [], []
     for ci, _vars in enumerate(split_vars(vars, size=max_batch_size)):
         b_sz = _vars.num_samples
         gs = None if grad_scale is None else \
             grad_scale[ci * max_batch_size: ci * max_batch_size + b_sz]
         target_args = {k: _gather(v) for k, v in _vars.output.items()}
-        for _, var in _vars.input.items():
-            _run_hook(var)
         leaves, input_args = {}, {}
         for k, var in _vars.input.items():
             x = _gather(var)
@@ -129,7 +118,7 @@ def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
     return torch.cat(outs), LazyLosses(torch.cat(losses)), {}
 
 
-def _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
+def _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale, population):
     outs, indiv_losses = [], []
     for ci, _vars in enumerate(split_vars(vars, size=max_batch_size)):
         box = {}
@@ -141,10 +130,7 @@ def _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
             target_args = {k: torch.stack(list(v.data)) for k, v in _vars.output.items()}
             if optimize:
                 _vars.opt.zero_grad()
-            # (1) hooks mutate the leaves in place
-            for _, var in _vars.input.items():
-                if var.hook_fn is not None:
-                    var.hook_fn(var.data)
+            # (1) hooks: already applied for the whole step (apply_hooks)
             # (2) forward
             input_args = {k: torch.stack(list(v.data)) for k, v in _vars.input.items()}
             out = model(**input_args)
@@ -170,7 +156,8 @@ def _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale):
     return torch.stack(outs), indiv_losses, {}
 
 
-def step(model, vars, loss_fn, optimize=True, max_batch_size=9, grad_scale=None):
+def step(model, vars, loss_fn, optimize=True, max_batch_size=9, grad_scale=None,
+         population=None):
     """
     The step function for model evaluation.
 
@@ -184,10 +171,16 @@ def step(model, vars, loss_fn, optimize=True, max_batch_size=9, grad_scale=None)
             1/b_chunk of `loss.mean()`; population sharding passes the
             REFERENCE chunk size here so that trajectories do not depend on the
             number of GPUs.
+        population: (first row, population size, reference chunk size) when `vars` is a
+            block of a larger population and / or `max_batch_size` is an execution batch
+            larger than the reference chunk; tells the hooks where their rows sit.
 
     Returns:
         outs, indiv_losses (list-like of np.float32), misc_return ({})
     """
+    apply_hooks(vars, None if population is None else population[:2],
+                max_batch_size if population is None else population[2])
     if isinstance(vars.opt, FusedAdam):
-        return _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale)
-    return _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale)
+        return _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale,
+                           population)
+    return _step_generic(model, vars, loss_fn, optimize, max_batch_size, grad_scale, population)

@@ -1,19 +1,12 @@
-"""GradientOptimizer (reference pix2latent/optimizer/gradient_optimizer.py:11-56)."""
-import time
+"""GradientOptimizer: `num_samples` candidates refined by `grad_steps` Adam updates.
 
+API of reference pix2latent/optimizer/gradient_optimizer.py:11-56; the loop itself is the
+shared driver (search_loop.py) with a one-generation plan and no sampler."""
 from .base_optimizer import _BaseOptimizer
-from ..utils.misc import progress_print
+from .search_loop import Generation, StepTicker
 
 
 class GradientOptimizer(_BaseOptimizer):
-    """
-    Basic gradient optimizer: `num_samples` candidates, `grad_steps` updates with
-    the optimizer defined in the variable manager (Adam by default).
-    """
-
-    def __init__(self, *args, **kwargs):
-        _BaseOptimizer.__init__(self, *args, **kwargs)
-        return
 
     def optimize(self, num_samples, grad_steps, pbar=None):
         """
@@ -21,31 +14,15 @@ class GradientOptimizer(_BaseOptimizer):
             num_samples (int): number of samples to optimize over
             grad_steps (int): number of gradient descent updates.
             pbar: progress bar such as tqdm or st.progress [Default: None]
+        Returns
+            (variables, [image grid], [[grad_steps, {'loss': per-sample losses}]]), or the
+            logged lists when constructed with log=True
         """
         self.losses, self.outs = [], []
-
-        variables = self.var_manager.initialize(num_samples=num_samples)
-
-        t_st = time.time()
-
-        for i in range(grad_steps):
-            self.step(variables, optimize=True, transform=(i == 0))
-
-            if pbar is not None:
-                pbar.progress(i / grad_steps)
-
-            if self.log:
-                if ((i + 1) % self.log_iter == 0) or (i + 1 == grad_steps):
-                    self.log_result(variables, i + 1)
-
-            if (i + 1) % self.show_iter == 0:
-                t_avg = (time.time() - t_st) / self.show_iter
-                progress_print('optimize', i + 1, grad_steps, 'c', t_avg)
-                t_st = time.time()
-
-        self.gather_population(variables)
-
-        if self.log:
-            return variables, self.outs, self.losses
-
-        return variables, [self._final_grid()], [[grad_steps, {'loss': self.loss}]]
+        # step labels are 1-based counts; the last step is always logged; the pbar is fed
+        # the 0-based index and the console line is printed even next to a pbar
+        ticker = StepTicker(self, grad_steps, pbar, mark=grad_steps, pbar_lag=1,
+                            always_print=True)
+        plan = [Generation(steps=grad_steps, refine=True, report=False, shift=0)]
+        variables = self.run_generations(plan, None, ticker, num_samples)
+        return self.finish(variables, grad_steps)

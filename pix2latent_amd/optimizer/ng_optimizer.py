@@ -1,10 +1,10 @@
-"""NevergradOptimizer: forward-only ask/tell search + Adam fine-tuning
-(reference pix2latent/optimizer/ng_optimizer.py:12-91)."""
-import time
+"""NevergradOptimizer: forward-only ask/tell search with a free number of candidates per
+round, then Adam fine-tuning of a last draw.
 
+API of reference pix2latent/optimizer/ng_optimizer.py:12-91; budget = meta_steps."""
 from .base_optimizer import _BaseOptimizer
 from .base_ng_optimizer import _BaseNevergradOptimizer
-from ..utils.misc import progress_print
+from .search_loop import Generation, StepTicker
 
 
 class NevergradOptimizer(_BaseOptimizer, _BaseNevergradOptimizer):
@@ -12,61 +12,21 @@ class NevergradOptimizer(_BaseOptimizer, _BaseNevergradOptimizer):
     def __init__(self, method, *args, **kwargs):
         _BaseOptimizer.__init__(self, *args, **kwargs)
         _BaseNevergradOptimizer.__init__(self, method=method)
-        return
 
     def optimize(self, num_samples, meta_steps, grad_steps=0, pbar=None):
         """
         Args
-            num_samples (int): number of samples per ask/tell round
-            meta_steps (int): number of ask/tell updates
-            grad_steps (int): gradient updates applied after the search
+            num_samples (int): candidates per ask/tell round
+            meta_steps (int): number of ask/tell rounds
+            grad_steps (int): gradient updates applied after the search [Default: 0]
+            pbar: progress bar such as tqdm or st.progress
         """
-        self.losses, self.outs, i = [], [], 0
+        self.losses, self.outs = [], []
         total_steps = meta_steps + grad_steps
         self.setup_ng(self.var_manager, budget=meta_steps)
-
-        t_st = time.time()
-
-        for _ in range(meta_steps):
-            variables = self.ng_init(self.var_manager, num_samples)
-            self.step(variables, optimize=False, transform=False)
-            i += 1
-
-            if self.log:
-                if (i % self.log_iter == 0) or (i == grad_steps):
-                    self.log_result(variables, i)
-
-            self.ng_update(variables, inverted_loss=True)
-
-            if pbar is not None:
-                pbar.progress(i / total_steps)
-            else:
-                if i % self.show_iter == 0:
-                    t_avg = (time.time() - t_st) / self.show_iter
-                    progress_print('optimize', i, total_steps, 'c', t_avg)
-                    t_st = time.time()
-
-        variables = self.ng_init(self.var_manager, num_samples)
-
-        for j in range(grad_steps):
-            self.step(variables, optimize=True, transform=(j == 0))
-            i += 1
-
-            if self.log:
-                if ((i + 1) % self.log_iter == 0) or (i + 1 == grad_steps):
-                    self.log_result(variables, i + 1)
-
-            if pbar is not None:
-                pbar.progress(i / total_steps)
-            else:
-                if (i + 1) % self.show_iter == 0:
-                    t_avg = (time.time() - t_st) / self.show_iter
-                    progress_print('optimize', i + 1, total_steps, 'c', t_avg)
-                    t_st = time.time()
-
-        self.gather_population(variables)
-
-        if self.log:
-            return variables, self.outs, self.losses
-
-        return variables, [self._final_grid()], [[total_steps, {'loss': self.loss}]]
+        ticker = StepTicker(self, total_steps, pbar, mark=grad_steps)
+        plan = [Generation(1, False, True, 0)] * meta_steps + \
+               [Generation(grad_steps, True, False, 1)]
+        variables = self.run_generations(plan, self.sampler, ticker,
+                                         self._population(num_samples))
+        return self.finish(variables, total_steps)

@@ -7,10 +7,11 @@ on the MI355X node, 'gloo' in the CPU tests).  Generator / VGG weights are
 replicated once at start-up.  The only traffic is
 
   * per generation: rank 0's asked population, broadcast ([pop, N] float64, a few KB);
-  * per step: one all-gather of the per-candidate scalar losses (<= 3 floats per rank),
-    so that `optimizer.loss` holds the whole population on every rank like the
-    single-process optimizer (kept eager on purpose: a lazy gather would deadlock when only
-    one rank reads the losses);
+  * per generation: one all-gather of the per-candidate scalar losses (<= 3 floats per
+    rank) before `tell`; `optimizer.loss` is a `ShardedLosses` that gathers on first read.
+    Reads happen at points every rank reaches in the same order (re-score, log_result with
+    log=True, end of optimize()); user code that looks at `opt.loss` must do so on every
+    rank, like any collective;
   * at the end: one all-gather of the final latents / images.
 
 All of it is latency-bound scalars / small vectors: no activation, gradient or weight ever
@@ -22,6 +23,9 @@ re-broadcasts all generator weights on every forward.
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+from .utils.lazy_losses import LazyLosses
 
 
 def partition(n, world):
@@ -72,6 +76,17 @@ class PopulationShard(object):
         dist.broadcast(t, src=src, group=self.group)
         return t.cpu().numpy()
 
+    def broadcast_tensor(self, t, src=0):
+        """rank `src`'s tensor to every rank (same shape / dtype everywhere); gloo needs a
+        host buffer, RCCL a device one"""
+        if not self.enabled:
+            return t
+        nccl = dist.get_backend(self.group) == 'nccl'
+        buf = t.detach().contiguous().clone() if (t.is_cuda == nccl) else \
+            t.detach().to('cuda' if nccl else 'cpu').contiguous()
+        dist.broadcast(buf, src=src, group=self.group)
+        return buf.to(t.device)
+
     def all_gather_rows(self, local, n):
         """gather per-candidate rows (final latents / images) in population order."""
         if not self.enabled:
@@ -84,3 +99,28 @@ class PopulationShard(object):
         bufs = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(bufs, pad.contiguous(), group=self.group)
         return torch.cat([bufs[r][:hi - lo] for r, (lo, hi) in enumerate(parts)], dim=0)
+
+
+class ShardedLosses(LazyLosses):
+    """Per-candidate losses of a sharded step.  Holds the rank-local values; the population
+    vector is assembled by ONE padded all-gather the first time it is read (`gather()` is
+    idempotent and a collective: every rank must reach it)."""
+
+    def __init__(self, local, shard, n):
+        LazyLosses.__init__(self, None)
+        self.local, self._shard, self._n = local, shard, n
+
+    def gather(self):
+        if self._t is None:
+            self._t = self._shard.all_gather_losses(self.local, self._n)
+        return self._t
+
+    def tensor(self):
+        return self.gather()
+
+    def _get(self):
+        self.gather()
+        return LazyLosses._get(self)
+
+    def __len__(self):
+        return self._n

@@ -16,7 +16,11 @@ from .base_transform import TransformTemplate
 def _warp(ims, theta):
     """ims [B,C,H,W], theta [B,2,3] -> F.grid_sample(ims, F.affine_grid(theta, ims.size()))"""
     theta = theta.type_as(ims)
-    if ims.is_cuda:
+    assert theta.size(0) == ims.size(0), \
+        'one transformation per image expected but got {} for {} images'.format(
+            theta.size(0), ims.size(0))
+    needs_grad = torch.is_grad_enabled() and (ims.requires_grad or theta.requires_grad)
+    if ims.is_cuda and not needs_grad:
         from .. import _native as N
         src = ims.contiguous().float()
         th = theta.contiguous().float().view(-1, 6)
@@ -25,6 +29,8 @@ def _warp(ims, theta):
         N.check(N.lib().p2l_affine_grid_sample(N.ptr(src), N.ptr(th), N.ptr(dst), B, C, H, W,
                                                N.stream()), 'p2l_affine_grid_sample')
         return dst
+    # CPU tensors, and differentiable uses on the device (invertibility_loss, gradient-based
+    # search of t): the two torch ops the reference calls, so autograd sees ims AND theta
     return F.grid_sample(ims, F.affine_grid(theta, list(ims.size()), align_corners=False),
                          align_corners=False)
 
@@ -49,7 +55,7 @@ class SpatialTransform(TransformTemplate):
             sensitivity (float): t = default_t + (sensitivity * delta_t)
         """
         self.identity_t = np.array(identity_t, dtype=np.float32)
-        self.is_spatial = True
+        self.is_spatial = True       # __call__ (default + sensitivity * delta) is the base class'
         self.sensitivity = sensitivity
 
         self.t = t
@@ -58,12 +64,6 @@ class SpatialTransform(TransformTemplate):
 
         self._t = torch.Tensor(self.t)
         return
-
-    def __call__(self, ims, delta_t, invert=False):
-        t = self._t.type_as(ims) + (self.sensitivity * delta_t)
-        if invert:
-            return self.invert_transform(ims, t)
-        return self.transform(ims, t)
 
     def get_default_param(self, as_tensor=True):
         if as_tensor:

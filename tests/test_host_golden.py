@@ -315,3 +315,75 @@ def test_ng_compat_facade_conventions():
         for c in asked:
             opt.tell(c, float(np.sum(c.args[0] ** 2)))
         assert opt.num_ask == 5 and opt.num_tell == 5
+
+
+def test_random_hooks_row_form_is_the_reference_stream():
+    """apply_batched draws one randn per row in population order: bit-identical to the
+    reference's per-sample loop (golden `perturb` / `compose`), for any execution chunking"""
+    from pix2latent_amd.utils import function_hooks as hook
+    g = gold('hooks')
+    src = torch.from_numpy(g['src'])
+    n = src.size(0)
+    torch.manual_seed(32)
+    b = src.clone(); hook.NormalPerturb(0.05).apply_batched(b)
+    assert np.array_equal(b.numpy(), g['perturb'])
+    torch.manual_seed(33)
+    b = src.clone(); hook.Compose(hook.NormalPerturb(0.05), hook.Clamp(2.0)).apply_batched(b)
+    # (Compose applies NormalPerturb to ALL rows, then Clamp: same order as the reference)
+    assert np.array_equal(b.numpy(), g['compose'])
+    # a rank holding rows [1,3) of the chunk draws-and-discards the others: same numbers on
+    # its rows, and the generator ends where a single process would
+    torch.manual_seed(32)
+    b = src.clone(); hook.NormalPerturb(0.05).apply_batched(b[1:3], hook.HookSpan(1, 3, 0, n))
+    assert np.array_equal(b[1:3].numpy(), g['perturb'][1:3])
+    assert np.array_equal(b[0].numpy(), g['src'][0])
+    after = torch.rand(1)
+    torch.manual_seed(32)
+    hook.NormalPerturb(0.05).apply_batched(src.clone())
+    assert torch.equal(after, torch.rand(1))
+    # ... and so does a rank holding nothing of the chunk
+    torch.manual_seed(32)
+    hook.NormalPerturb(0.05).apply_batched(src[0:0].clone(), hook.HookSpan(0, 0, 0, n))
+    assert torch.equal(after, torch.rand(1))
+
+
+def test_hooks_of_a_step_follow_the_reference_call_sequence():
+    """closure.apply_hooks: one hook call per reference chunk and hooked variable, in the
+    reference's order, for any execution batch: ScheduledNormalPerturb's clock and the
+    interleaving of two random hooks match the chunk-by-chunk per-sample loop"""
+    from pix2latent_amd import VariableManager
+    from pix2latent_amd.optimizer.closure import apply_hooks
+    from pix2latent_amd.variable_manager import slice_vars
+    from pix2latent_amd.utils import function_hooks as hook
+
+    def make():
+        vm = VariableManager(device='cpu')
+        vm.register('a', (4,), 'input', default=torch.zeros(4),
+                    hook_fn=hook.Compose(hook.NormalPerturb(0.1), hook.Clamp(0.15)))
+        vm.register('b', (3,), 'input', default=torch.zeros(3),
+                    hook_fn=hook.ScheduledNormalPerturb(0.5, max_step=9))
+        return vm.initialize(5)
+    # reference order: for chunk in chunks of 2: for var in (a, b): hook(chunk's samples)
+    ref = make()
+    torch.manual_seed(5)
+    for step in range(2):
+        for lo in (0, 2, 4):
+            for name in ('a', 'b'):
+                ref.input[name].hook_fn(ref.input[name].data[lo:lo + 2])
+    assert ref.input.b.hook_fn.t == 6
+    # one pass over the whole population
+    one = make()
+    torch.manual_seed(5)
+    for step in range(2):
+        apply_hooks(one, (0, 5), 2)
+    assert one.input.b.hook_fn.t == 6
+    for name in ('a', 'b'):
+        assert torch.equal(one.input[name].buf, torch.stack(list(ref.input[name].data)))
+    # a block [1,4) of the population (a rank of a sharded run)
+    part = make()
+    torch.manual_seed(5)
+    for step in range(2):
+        apply_hooks(slice_vars(part, 1, 4), (1, 5), 2)
+    for name in ('a', 'b'):
+        assert torch.equal(part.input[name].buf[1:4], torch.stack(list(ref.input[name].data))[1:4])
+        assert torch.count_nonzero(part.input[name].buf[0]) == 0

@@ -151,3 +151,130 @@ def test_sharded_hybrid_nevergrad_matches_single_process():
         assert np.allclose(z, g['final_z'], atol=1e-5)
         assert np.allclose(loss, g['final_loss'], atol=1e-6)
     assert np.array_equal(res[0][1], res[1][1])
+
+
+# ---------------------------------------------------------------------------------------
+# sharding + transformation search (BASELINE config 5's optimizer) and sharding + random hooks
+# (config 4's Compose(NormalPerturb, Clamp)): both must not depend on the number of ranks
+# ---------------------------------------------------------------------------------------
+def _run_transform_basincma():
+    from _toy import ToyGenerator, toy_target, toy_weight, FakeCMAES
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.transform import SpatialTransform, TransformBasinCMAOptimizer
+    import pix2latent_amd.optimizer.base_cma_optimizer as B
+    from oracle.lpips_ref import reconstruction_loss
+    B.CMAEvolutionStrategy = FakeCMAES
+    FakeCMAES.log = []
+    vm = VariableManager(device='cpu')
+    vm.register('z', (6,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook.Clamp(1.5))
+    vm.register('c', (4,), 'input', default=torch.linspace(-0.2, 0.2, 4), learning_rate=0.01)
+    vm.register('target', (3, 4, 4), 'output', requires_grad=False, default=toy_target())
+    vm.register('weight', (3, 4, 4), 'output', requires_grad=False, default=toy_weight())
+    vm.register('t', (3,), 'transform', requires_grad=False, grad_free=True)
+    torch.manual_seed(45)
+    topt = TransformBasinCMAOptimizer(ToyGenerator(), vm,
+                                      lambda o, target, weight: reconstruction_loss(o, target, weight),
+                                      max_batch_size=4)
+    topt.register_transform(SpatialTransform(), 't', 'target')
+    topt.register_transform(SpatialTransform(), 't', 'weight')
+    topt.set_variable_propagation('z')
+    tvars, (tout, ttarget, tcand), tloss = topt.optimize(meta_steps=3, grad_steps=2)
+    return dict(told=[t[1] for t in FakeCMAES.log],
+                candidate=topt.get_candidate().numpy(), best=float(topt._best_loss),
+                final_z=torch.stack(list(tvars.input.z.data)).detach().numpy(),
+                final_target=torch.stack(list(tvars.output.target.data)).numpy(),
+                final_loss=np.array(tloss), cand_out=tcand.numpy(),
+                vp_mean=topt.vp_means['z'].numpy())
+
+
+def _run_perturbed_basincma():
+    from _toy import ToyGenerator, toy_target, toy_weight, FakeCMAES
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import BasinCMAOptimizer
+    import pix2latent_amd.optimizer.base_cma_optimizer as B
+    from oracle.lpips_ref import reconstruction_loss
+    B.CMAEvolutionStrategy = FakeCMAES
+    FakeCMAES.log = []
+    vm = VariableManager(device='cpu')
+    vm.register('z', (6,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, grad_free=True,
+                hook_fn=hook.Compose(hook.NormalPerturb(0.05), hook.Clamp(1.5)))
+    vm.register('c', (4,), 'input', default=torch.linspace(-0.2, 0.2, 4), learning_rate=0.01,
+                hook_fn=hook.ScheduledNormalPerturb(0.3, max_step=12))
+    vm.register('target', (3, 4, 4), 'output', requires_grad=False, default=toy_target())
+    vm.register('weight', (3, 4, 4), 'output', requires_grad=False, default=toy_weight())
+    torch.manual_seed(47)
+    opt = BasinCMAOptimizer(ToyGenerator(), vm,
+                            lambda o, target, weight: reconstruction_loss(o, target, weight),
+                            max_batch_size=3)
+    variables, _, losses = opt.optimize(meta_steps=2, grad_steps=2, last_grad_steps=2)
+    return dict(told=[t[1] for t in FakeCMAES.log],
+                final_z=torch.stack(list(variables.input.z.data)).detach().numpy(),
+                final_c=torch.stack(list(variables.input.c.data)).detach().numpy(),
+                final_loss=np.array(losses[-1][1]['loss']))
+
+
+_RUNNERS = {'transform': _run_transform_basincma, 'perturb': _run_perturbed_basincma}
+
+
+def _worker_named(rank, world, port, q, which):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _RUNNERS[which]()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(which, world, port):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_named, args=(r, world, port, q, which)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_transform_basincma_matches_reference_trace(world):
+    """TransformBasinCMAOptimizer with register_transform over 2 and 3 ranks (7 candidates:
+    4+3 / 3+2+2): warps of the local rows only, un-warped scoring of the local rows with the
+    local transformation parameters, all-gather before tell, the best candidate's latent
+    fetched from whichever rank owns it, propagation noise drawn once -> the imported
+    reference's single-process trace (tests/golden/transform_basincma.npz)."""
+    g = np.load(os.path.join(HERE, 'golden', 'transform_basincma.npz'))
+    res = _spawn('transform', world, 33500 + (os.getpid() % 2000) + world)
+    for rank, r in res.items():
+        assert np.allclose(r['told'][0], g['tell_y0'], atol=1e-6)
+        assert np.allclose(r['told'][1], g['tell_y1'], atol=1e-6)
+        assert np.allclose(r['candidate'], g['candidate'], atol=1e-6)
+        assert abs(r['best'] - float(g['best_loss'])) < 1e-6
+        assert np.allclose(r['final_z'], g['final_z'], atol=1e-5)
+        assert np.allclose(r['final_target'], g['final_target'], atol=1e-6)
+        assert np.allclose(r['final_loss'], g['final_loss'], atol=1e-6)
+        assert np.allclose(r['cand_out'], g['cand_out'], atol=1e-6)
+        assert np.allclose(r['vp_mean'], g['vp_mean'], atol=1e-5)
+
+
+@pytest.mark.timeout(300)
+def test_random_hooks_do_not_depend_on_the_number_of_ranks():
+    """Compose(NormalPerturb, Clamp) on z and ScheduledNormalPerturb on c (the hook of
+    BASELINE config 4): every rank replays the whole population's random stream and applies
+    its own rows, so 1, 2 and 3 equally seeded ranks follow the same trajectory."""
+    single = _run_perturbed_basincma()
+    for world in (2, 3):
+        res = _spawn('perturb', world, 35500 + (os.getpid() % 2000) + world)
+        for rank, r in res.items():
+            for k in ('final_z', 'final_c', 'final_loss'):
+                assert np.allclose(r[k], single[k], atol=1e-6), (world, rank, k)
+            for a, b in zip(r['told'], single['told']):
+                assert np.allclose(a, b, atol=1e-6)

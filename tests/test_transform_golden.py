@@ -86,3 +86,54 @@ def test_transform_basincma_control_flow_golden(monkeypatch):
     assert np.allclose(tcand.numpy(), g['cand_out'], atol=1e-6)
     assert np.allclose(topt.vp_means['z'].numpy(), g['vp_mean'], atol=1e-5)
     assert [c[0] for c in model.calls] == [int(c[0]) for c in g['model_calls']]
+
+
+def test_compose_transform_golden():
+    """ComposeTransform vs the imported reference (transform_utils.py:122-184): slicing of
+    the shared parameter vector, re-weighting around each default, t broadcast over the
+    batch, inversion order, only_spatial."""
+    from pix2latent_amd.transform import SpatialTransform, ComposeTransform
+    g = gold('compose_transform')
+    ims, t, tb = (torch.from_numpy(g[k]) for k in ('ims', 't', 'tb'))
+    comp = ComposeTransform([(SpatialTransform(), 1.0),
+                             (SpatialTransform(t=[0.9, 0.05, -0.1], sensitivity=0.2), 2.0)])
+    assert np.allclose(np.stack(comp.get_param()), g['param'])
+    assert np.allclose(comp.get_param(as_tensor=True).numpy(), g['param_flat'])
+    assert np.allclose(comp(ims, t).numpy(), g['fwd'], atol=1e-6)
+    assert np.allclose(comp(ims, tb).numpy(), g['fwd_b'], atol=1e-6)
+    assert np.allclose(comp(comp(ims, tb), tb, invert=True).numpy(), g['inv_b'], atol=1e-6)
+    assert np.allclose(comp(ims, tb, only_spatial=True).numpy(), g['spatial_only'], atol=1e-6)
+    assert np.allclose(ComposeTransform([SpatialTransform()])(ims, tb[:, :3]).numpy(), g['single'], atol=1e-6)
+    assert np.allclose(comp.reweight(tb[:, :3], 2.0, torch.tensor([1.0, 0.0, 0.0])).numpy(), g['reweight'])
+    assert comp.get_opt_param().shape == (6,)
+    assert 'ComposeTransform' in str(comp)
+
+
+def test_setup_transform_fn():
+    """setup_transform_fn (transform_utils.py:15-50): nothing requested -> (None, None);
+    spatial search -> one SpatialTransform with the identity start; align -> the start is the
+    mask's pre-alignment (golden value); colour names are refused (out of scope)."""
+    import types
+    from pix2latent_amd.transform import setup_transform_fn, ComposeTransform
+    g = gold('spatial_transform')
+    mask = torch.from_numpy(g['mask'])
+    ns = types.SimpleNamespace
+    assert setup_transform_fn(ns(spatial_transform=False, align=False, color_transform=[]), mask) == (None, None)
+    fn, t = setup_transform_fn(ns(spatial_transform=True, align=False, color_transform=[]), mask)
+    assert isinstance(fn, ComposeTransform) and t.shape == (1, 3)
+    assert np.allclose(t.numpy(), [[1.0, 0.0, 0.0]])
+    fn, t = setup_transform_fn(ns(spatial_transform=False, align=True, color_transform=[]), mask.clone())
+    assert np.allclose(t.numpy()[0], g['pre_align'])
+    with pytest.raises(NotImplementedError):
+        setup_transform_fn(ns(spatial_transform=True, align=False, color_transform=['hue']), mask)
+
+
+def test_spatial_transform_checks_batch_and_is_differentiable():
+    from pix2latent_amd.transform import SpatialTransform
+    st = SpatialTransform()
+    ims = torch.rand(2, 3, 8, 8)
+    with pytest.raises(AssertionError, match='one transformation per image'):
+        st.transform(ims, torch.tensor([[1.0, 0.0, 0.0]] * 3))
+    t = torch.tensor([[0.9, 0.1, 0.0], [1.1, 0.0, -0.1]], requires_grad=True)
+    st.transform(ims, t).sum().backward()
+    assert t.grad is not None and t.grad.abs().sum() > 0

@@ -66,9 +66,37 @@ def install_stubs():
     sys.path.insert(0, REF)
 
 
+def compose_section():
+    """(7) ComposeTransform (reference transform/transform_utils.py:122-184): two spatial
+    transformations with different defaults / weights driven by one 6-vector"""
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent.transform import SpatialTransform
+    from pix2latent.transform.transform_utils import ComposeTransform
+    g = torch.Generator().manual_seed(71)
+    ims = torch.rand(3, 3, 16, 16, generator=g) * 2 - 1
+    a, b = SpatialTransform(), SpatialTransform(t=[0.9, 0.05, -0.1], sensitivity=0.2)
+    comp = ComposeTransform([(a, 1.0), (b, 2.0)])
+    t = torch.tensor([[0.3, -0.5, 1.0, 0.8, 0.2, -0.4]])
+    tb = t.repeat(3, 1) * torch.tensor([[1.0], [0.5], [-1.0]])
+    single = ComposeTransform([SpatialTransform()])
+    np.savez(os.path.join(OUT, 'compose_transform.npz'), ims=ims.numpy(), t=t.numpy(), tb=tb.numpy(),
+             param=np.stack(comp.get_param()), param_flat=comp.get_param(as_tensor=True).numpy(),
+             fwd=comp(ims, t).numpy(), fwd_b=comp(ims, tb).numpy(),
+             inv_b=comp(comp(ims, tb), tb, invert=True).numpy(),
+             spatial_only=comp(ims, tb, only_spatial=True).numpy(),
+             single=single(ims, tb[:, :3]).numpy(),
+             reweight=comp.reweight(tb[:, :3], 2.0, torch.tensor([1.0, 0.0, 0.0])).numpy())
+    print('compose_transform.npz written')
+
+
 def main():
     install_stubs()
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['compose']:
+        import pix2latent  # noqa: F401  (the reference)
+        assert pix2latent.__file__.startswith(REF)
+        return compose_section()
     import pix2latent  # noqa: F401  (the reference)
     from pix2latent import VariableManager, distribution
     from pix2latent.variable_manager import split_vars
@@ -301,6 +329,7 @@ def main():
              final_target=torch.stack(tvars.output.target.data).detach().numpy(),
              final_loss=np.array(tloss), cand_out=tcand.detach().numpy(),
              vp_mean=topt.vp_means['z'].detach().numpy(), model_calls=np.array(model5.calls))
+    compose_section()
     print('golden fixtures written to', OUT)
     for f in sorted(os.listdir(OUT)):
         print('  ', f, os.path.getsize(os.path.join(OUT, f)))
