@@ -84,39 +84,138 @@ def _best_threads():
     return best
 
 
-def cpu_baseline(problem, max_seconds=40.0):
-    """the oracle (CPU restatement, torch-CPU fp32, all host cores) timed on a
-    bounded sample of the same workload: fwd + loss + bwd of a chunk of 2
-    candidates (dgrad only; the reference would also compute weight gradients)."""
+def cpu_baseline(problem, chunk=MAX_BATCH):
+    """The oracle (CPU restatement, torch-CPU fp32, best thread count of the host) timed on a
+    bounded sample of the same workload: ONE reference chunk of `chunk` (= max_batch_size = 9)
+    candidates, fwd + loss + bwd, once with weight gradients enabled -- what the reference
+    does: it never freezes the generator / LPIPS parameters, so loss.backward() also computes
+    the generator's weight gradients (closure.py:58) -- and once with input gradients only
+    (what the native path computes).  `value` is the reference behaviour (wgrad on)."""
     from oracle import biggan_ref as R, lpips_ref as L
     W, Wv, c_default, target, weight = problem
-    n = 2
     g = torch.Generator().manual_seed(2)
     torch.set_num_threads(_best_threads())
 
-    def one():
+    def one(n, wgrad):
+        # nn.Parameters of the reference's modules: every generator weight / bias / BN affine /
+        # gamma (running statistics are buffers); of lpips.LPIPS only the `lin` layers -- its
+        # backbone is built with requires_grad=False (pnet_tune=False) [3P-recall]
+        Wg = {k: (v.detach().clone().requires_grad_(True)
+                  if wgrad and torch.is_floating_point(v) and 'running_' not in k else v)
+              for k, v in W.items()}
+        Wvg = {k: (v.detach().clone().requires_grad_(True)
+                   if wgrad and k.startswith('lpips.lin') else v) for k, v in Wv.items()}
         z = torch.fmod(torch.randn(n, 128, generator=g), 2.0).requires_grad_(True)
         c = c_default.unsqueeze(0).repeat(n, 1).requires_grad_(True)
-        out = R.biggan_forward(W, z, c)
-        loss = L.projection_loss(Wv, out, target.unsqueeze(0).repeat(n, 1, 1, 1),
+        t0 = time.perf_counter()
+        out = R.biggan_forward(Wg, z, c)
+        loss = L.projection_loss(Wvg, out, target.unsqueeze(0).repeat(n, 1, 1, 1),
                                  weight.unsqueeze(0).repeat(n, 1, 1, 1))
         loss.mean().backward()
-        return float(loss.sum())
-    t0 = time.perf_counter()
-    one()                                   # warm-up (thread pools, oneDNN primitives)
-    warm = time.perf_counter() - t0
-    reps = 0
-    t0 = time.perf_counter()
-    while True:
-        one()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el + warm > max_seconds or reps >= 3:
-            break
-    return {'value': round(n * reps / el, 4), 'unit': 'evals/s',
+        return time.perf_counter() - t0
+    one(chunk, False)                       # warm-up at the timed shapes (thread pools, oneDNN primitives)
+    t_off = one(chunk, False)
+    t_on = one(chunk, True)
+    return {'value': round(chunk / t_on, 4), 'unit': 'evals/s',
             'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d x (fwd+loss+bwd of a chunk of %d candidates, BigGAN-deep-256 + '
-                      'L1+10*LPIPS-VGG16, torch-CPU fp32, dgrad only)' % (reps, n)}
+            'wgrad': {'on': round(chunk / t_on, 4), 'off': round(chunk / t_off, 4)},
+            'sample': '1 reference chunk of %d candidates (fwd+loss+bwd, BigGAN-deep-256 + '
+                      'L1+10*LPIPS-VGG16, torch-CPU fp32), timed once with weight gradients '
+                      'enabled (the reference never freezes the networks: value) and once '
+                      'with input gradients only' % chunk}
+
+
+# ---------------------------------------------------------------------------------------
+# the other configurations BASELINE.json / north_star name, measured AFTER the timed region
+# and reported under config.extra (same JSON line)
+# ---------------------------------------------------------------------------------------
+def _time_steps(fn, n_warm, n):
+    for i in range(n_warm):
+        fn(i == 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn(False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def extra_configs(dev, n_steps=3):
+    import contextlib
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import synthetic as S, function_hooks as hook
+    from pix2latent_amd.model.biggan import BigGAN
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    from pix2latent_amd.optimizer import GradientOptimizer
+    import pix2latent_amd.loss_functions as LF
+    out = {}
+    Wv = S.lpips_vgg_weights(1)
+
+    def run(name, model, vm, n, size, note, **kw):
+        loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
+        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=MAX_BATCH, **kw)
+        variables = vm.initialize(num_samples=n)
+        dt = _time_steps(lambda first: opt.step(variables, optimize=True, transform=first), 2, n_steps)
+        losses = [float(x) for x in opt.loss]
+        assert all(l == l for l in losses), name
+        out[name] = {'evals_per_s': round(n / dt, 1), 'ms_per_step': round(1e3 * dt, 2),
+                     'candidates': n, 'resolution': size, 'what': note}
+        del opt, variables, loss_fn
+        torch.cuda.empty_cache()
+
+    with contextlib.redirect_stdout(sys.stderr):
+        # C2: BigGAN-256 GradientOptimizer, num_samples = 8 (one chunk)
+        vm = VariableManager(device=dev)
+        g = torch.Generator().manual_seed(2)
+        vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                    learning_rate=0.05, hook_fn=hook.Clamp(2.0))
+        vm.register('c', (128,), 'input', default=0.05 * torch.randn(128, generator=g),
+                    learning_rate=0.01)
+        vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_target(256, 1))
+        vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_weight_mask(256))
+        run('biggan_gradient_n8', BigGAN(weights=S.biggan_weights(0), device=dev), vm, 8, 256,
+            'BASELINE config 2: GradientOptimizer inner step, 8 samples, L1 + 10*LPIPS-VGG16')
+
+        # C4: StyleGAN2 cars 512^2, 32 samples, Compose(NormalPerturb, Clamp), loss mask
+        gen = StyleGAN2(model='cars', search='z', device=dev)
+        fixed = [torch.randn(1, 1, s_[2], s_[3], generator=g).to(dev) for s_ in gen.noise_shape]
+
+        class FixedNoise(torch.nn.Module):
+            def forward(self, z=None):
+                return gen.forward_z(z, noises=[n_.expand(z.size(0), -1, -1, -1).contiguous()
+                                                for n_ in fixed])
+        vm = VariableManager(device=dev)
+        vm.register('z', (512,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                    learning_rate=0.05,
+                    hook_fn=hook.Compose(hook.NormalPerturb(sigma=0.05), hook.Clamp(2.0)))
+        mask = torch.zeros(3, 512, 512)
+        mask[:, 64:-64, :] += 1.0
+        for nm, t in (('target', S.synthetic_target(512, 1)), ('weight', torch.ones(3, 512, 512)),
+                      ('loss_mask', mask)):
+            vm.register(nm, (3, 512, 512), 'output', requires_grad=False, default=t)
+        run('stylegan2_cars_512_n32', FixedNoise(), vm, 32, 512,
+            'BASELINE config 4 inner step: 32 samples (reference chunks 9,9,9,5 define the '
+            'gradient scale; executed in one device pass), z-space, rows 64:-64 loss mask',
+            exec_batch_size='all')
+        del gen, fixed
+        torch.cuda.empty_cache()
+
+        # C5 shard: StyleGAN2 FFHQ 1024^2 in W+, 3 candidates (pop 22 over 8 ranks), w+ and noises
+        gen = StyleGAN2(model='ffhq', search='w+', device=dev)
+        n_noise = sum(s_[-2] * s_[-1] for s_ in gen.noise_shape)
+        vm = VariableManager(device=dev)
+        vm.register('z', (18, 512), 'input', learning_rate=0.05,
+                    default=gen.latent_mean.cpu().view(1, 512).repeat(18, 1))
+        vm.register('noises', (n_noise,), 'input', learning_rate=0.05,
+                    default=torch.randn(n_noise, generator=g))
+        vm.register('target', (3, 1024, 1024), 'output', requires_grad=False, default=S.synthetic_target(1024, 1))
+        vm.register('weight', (3, 1024, 1024), 'output', requires_grad=False, default=S.synthetic_weight_mask(1024))
+        run('stylegan2_ffhq_1024_shard3_wplus', gen, vm, 3, 1024,
+            'BASELINE config 5, one rank\'s shard: 3 candidates, W+ latents [18,512] and the '
+            '2.8M-element noise vector both optimised')
+    return out
 
 
 def exact_fp32_leg(dev, args):
@@ -157,6 +256,8 @@ def main():
                          '(1 = every launch; costs ~5 %% of the step)')
     ap.add_argument('--no-fp32-leg', action='store_true',
                     help='skip the extra exact-fp32-MFMA measurement reported in config')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the additional configurations reported under config.extra')
     ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex'],
                     help="LPIPS network: 'vgg' = BASELINE.json's metric (default); 'alex' = the "
                          "reference's ProjectionLoss() default, reported as a side configuration")
@@ -222,8 +323,9 @@ def main():
     ms = (C.c_double * 2)()
     cnt = (C.c_int32 * 2)()
     abytes = (C.c_double * 2)()
-    N.check(lib.p2l_prof_end2(flops, ms, cnt, abytes), 'p2l_prof_end2')
-    last_loss = [float(x) for x in opt.loss]
+    xflops = (C.c_double * 2)()
+    N.check(lib.p2l_prof_end3(flops, ms, cnt, abytes, xflops), 'p2l_prof_end3')
+    last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()
     t1 = time.perf_counter()
@@ -243,18 +345,25 @@ def main():
         # generator fwd+dgrad 58.80 GMAC + LPIPS net fwd+dgrad (VGG16 40.08 | AlexNet 1.74 GMAC)
         gflop_eval = GFLOP_PER_EVAL if args.lpips_net == 'vgg' else 2 * (58.80 + 1.737)
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        exec_tflops = xflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
         bf3 = N.default_wfmt() == N.WFMT_BF16X3
         # PMC counters cannot be read from inside the timed process: `traffic` is the
         # committed result of the separate rocprofv3 --pmc passes over this same command
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                             'round1_traffic.json')
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
-            traffic_src = 'profiles/round1_traffic.json'
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+        for name in ('round2_traffic.json', 'round1_traffic.json'):
+            tpath = os.path.join(prof_dir, name)
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_src = {'file': 'profiles/' + name, 'commit': tj.get('commit'),
+                               'box': tj.get('box'), 'command': tj.get('command'),
+                               'note': 'separate rocprofv3 --pmc passes over this bench command '
+                                       '(PMC cannot be read inside the timed process)'}
+                break
         rec = {
             'metric': 'candidate-latent evals/sec (fwd+loss+bwd), BigGAN-256 pop=18',
             'value': round(evals / elapsed, 3),
@@ -281,6 +390,9 @@ def main():
                 'conv3x3_arithmetic': 'bf16x3' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
+                'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                'backend': (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
+                'loss_gather': 'one all-gather per generation (lazy); per step only when log=True',
                 'gflop_per_eval_basis': gflop_eval,
                 'end_to_end_tflops': round(gflop_eval * evals / elapsed / 1e3, 2),
                 'fwd_only_rescore_evals_per_s': round(rescore_rate, 1),
@@ -301,7 +413,14 @@ def main():
                 'frac': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
                                              else FP32_MFMA_PEAK_TFLOPS), 4),
                 'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                'issued_bf16_mfma_tflops': round(6 * conv_tflops, 1) if bf3 else None,
+                # `achieved` is ALGORITHMIC: sub-pixel (upsample-fused) launches are priced at the
+                # 9 taps of upsample-then-convolve on the high-resolution grid and the 3-channel
+                # image convs at 3 channels.  What the matrix pipe EXECUTES for the same launches
+                # (4 phase-taps; channels padded to 16 / 32) is reported next to it:
+                'executed': {'fp32_equiv_tflops': round(exec_tflops, 2),
+                             'bf16_mfma_tflops_issued': round(6 * exec_tflops, 1) if bf3 else None,
+                             'frac_of_peak': round(exec_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
+                                                                  else FP32_MFMA_PEAK_TFLOPS), 4)},
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,
@@ -320,6 +439,11 @@ def main():
             # the same steps with every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
             # reported beside `value` so the arithmetic choice is visible in one line
             rec['config']['exact_fp32_mfma_evals_per_s'] = round(exact_fp32_leg(dev, args), 1)
+        if world == 1 and not args.no_extra:
+            try:
+                rec['config']['extra'] = extra_configs(dev)
+            except Exception as e:          # the headline must not be lost to a side measurement
+                rec['config']['extra'] = {'error': repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(problem)
         print(json.dumps(rec), flush=True)

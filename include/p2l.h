@@ -140,11 +140,6 @@ void p2l_arb_defer_begin(void);
 int p2l_arb_defer_flush(void* stream);
 void p2l_arb_defer_cancel(void);
 
-/* Select the 3x3 kernel for eligible layers: -1 = v1 (default); 0 / 1 = the
- * persistent LDS-double-buffered v2 with 256- / 128-pixel tiles (experimental,
- * see csrc/p2l_conv2.hip).  $P2L_CONV_FORCE overrides the argument. */
-int p2l_set_conv_variant(int variant);
-
 /* Per-launch timing of the conv kernel with HIP events recorded on the launch
  * stream (bench.py roofline leg).  begin() pre-creates the event pool; end()
  * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */
@@ -153,6 +148,11 @@ int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
 /* same, plus the algorithmic bytes of the timed launches (each operand tensor once +
  * packed weights); index 0 = 3x3 launches, 1 = 1x1 launches */
 int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]);
+/* same, plus the FLOPs the matrix pipe actually executed for those launches (padded channel
+ * counts; sub-pixel forms: 4 phase-taps per output pixel where `flops` counts the 9 taps of
+ * the upsample-then-convolve definition) */
+int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                  double exec_flops[2]);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
  * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;
@@ -434,7 +434,9 @@ int p2l_biggan_bwd(const P2LBigGAN* m, int Bn, void* ws, size_t ws_bytes,
 /* debug/test hook: float offset + shape of a saved activation in ws.        */
 /* what: 0 = output of layer L (ModuleList index, SelfAttn included),        */
 /*       1 = gen_z output, 2 = folded CBN s, 3 = folded CBN t,               */
-/*       4 = d s, 5 = d t (after bwd)                                        */
+/*       4 = d s, 5 = d t (after bwd),                                       */
+/*       6 = d loss / d (CBN gains | CBN biases) [B][2*cbn_total] (after bwd):*/
+/*           the per-layer gradients the parity tests compare with the oracle */
 int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int L,
                          size_t* float_off, int32_t shape[4]);
 
@@ -464,7 +466,9 @@ int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
                          const float* weight, const float* loss_mask, int Bn,
                          int H, int W, const P2LLossCache* cache, void* ws,
                          size_t ws_bytes, void* stream);
-/* loss[b] = L1_weighted + beta * LPIPS_weighted; use_lpips=0 -> L1 only       */
+/* loss[b] = L1_weighted + beta * LPIPS_weighted; use_lpips=0 -> L1 only;       *
+ * in the backward entry points use_lpips=2 -> gradient of beta * LPIPS_weighted *
+ * alone (PerceptualLoss, pix2latent/loss_functions.py:140-148)                 */
 int p2l_projloss_fwd(const P2LVggLpips* v, const float* img16,
                      const float* target, const float* weight,
                      const float* loss_mask, const P2LLossCache* cache,

@@ -56,28 +56,35 @@ def _bn_stats(means, vars_, truncation, n_stats=N_STATS):
     return mean, var
 
 
-def cbn(W, prefix, x, cond, truncation):
-    """Conditional BN: (x-mu)/sqrt(var+eps) * (1 + scale(cond)) + offset(cond)."""
+def cbn(W, prefix, x, cond, truncation, taps=None):
+    """Conditional BN: (x-mu)/sqrt(var+eps) * (1 + scale(cond)) + offset(cond).
+    `taps` (dict): records this layer's per-(sample, channel) gain and bias tensors with
+    their gradients retained -- the tests compare d loss / d gain, d loss / d bias of each of
+    the 48 layers, which localises a wrong input-gradient conv to the layer it sits in."""
     mean, var = _bn_stats(W[prefix + '.running_means'], W[prefix + '.running_vars'], truncation)
     mean = mean.view(1, -1, 1, 1)
     var = var.view(1, -1, 1, 1)
     weight = 1 + F.linear(cond, W[prefix + '.scale.weight']).unsqueeze(-1).unsqueeze(-1)
     bias = F.linear(cond, W[prefix + '.offset.weight']).unsqueeze(-1).unsqueeze(-1)
+    if taps is not None and weight.requires_grad:
+        weight.retain_grad()
+        bias.retain_grad()
+        taps[prefix] = (weight, bias)
     return (x - mean) / torch.sqrt(var + BN_EPS) * weight + bias
 
 
-def gen_block(W, p, x, cond, truncation, up, cin, cout):
+def gen_block(W, p, x, cond, truncation, up, cin, cout, taps=None):
     """GenBlock.forward [3P-recall]: bottleneck 1x1 -> 3x3 -> 3x3 -> 1x1 + shortcut."""
     x0 = x
-    x = F.relu(cbn(W, p + '.bn_0', x, cond, truncation))
+    x = F.relu(cbn(W, p + '.bn_0', x, cond, truncation, taps))
     x = F.conv2d(x, W[p + '.conv_0.weight'], W[p + '.conv_0.bias'])
-    x = F.relu(cbn(W, p + '.bn_1', x, cond, truncation))
+    x = F.relu(cbn(W, p + '.bn_1', x, cond, truncation, taps))
     if up:
         x = F.interpolate(x, scale_factor=2, mode='nearest')
     x = F.conv2d(x, W[p + '.conv_1.weight'], W[p + '.conv_1.bias'], padding=1)
-    x = F.relu(cbn(W, p + '.bn_2', x, cond, truncation))
+    x = F.relu(cbn(W, p + '.bn_2', x, cond, truncation, taps))
     x = F.conv2d(x, W[p + '.conv_2.weight'], W[p + '.conv_2.bias'], padding=1)
-    x = F.relu(cbn(W, p + '.bn_3', x, cond, truncation))
+    x = F.relu(cbn(W, p + '.bn_3', x, cond, truncation, taps))
     x = F.conv2d(x, W[p + '.conv_3.weight'], W[p + '.conv_3.bias'])
     if cin != cout:
         x0 = x0[:, :cin // 2]
@@ -99,7 +106,7 @@ def self_attn(W, p, x):
 
 
 def generator_forward(W, cond, truncation=1.0, ch=CH, layers=LAYERS, attn_pos=ATTN_POS,
-                      return_intermediates=False):
+                      return_intermediates=False, cbn_taps=None):
     """Generator.forward [3P-recall]; `cond` = cat(z, class_embedding) [B, 2*z_dim]."""
     inter = {}
     z = F.linear(cond, W['generator.gen_z.weight'], W['generator.gen_z.bias'])
@@ -111,7 +118,7 @@ def generator_forward(W, cond, truncation=1.0, ch=CH, layers=LAYERS, attn_pos=AT
             z = self_attn(W, p, z)
         else:
             _, up, cin, cout = spec
-            z = gen_block(W, p, z, cond, truncation, up, cin, cout)
+            z = gen_block(W, p, z, cond, truncation, up, cin, cout, cbn_taps)
         inter['layer%d' % i] = z
     mean, var = _bn_stats(W['generator.bn.running_means'], W['generator.bn.running_vars'], truncation)
     z = F.batch_norm(z, mean, var, W['generator.bn.weight'], W['generator.bn.bias'],

@@ -50,10 +50,6 @@ using namespace p2lconv;
 
 namespace {
 
-// which 3x3 kernel p2l_conv_fwd uses for eligible layers: -1 = v1 (default),
-// 0 / 1 = persistent double-buffered v2 with 256- / 128-pixel tiles.
-int g_conv_variant = -1;
-
 // Optional per-launch timing of the conv kernel (bench.py's roofline leg):
 // hipEvents from a pre-created pool are recorded on the launch stream around
 // every conv (incl. its split-K finish); nothing is allocated while enabled.
@@ -61,7 +57,8 @@ struct ConvProf {
   bool on = false;
   int n = 0;
   std::vector<hipEvent_t> ev;
-  std::vector<double> flops;
+  std::vector<double> flops;    // algorithmic (direct convolution on the real channels)
+  std::vector<double> xflops;   // executed on the matrix pipe (padded channels, 4 phase-taps)
   std::vector<double> bytes;
   std::vector<int> kind;
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
@@ -1237,6 +1234,10 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     g_prof.flops[prof_slot] = d->algo_flops > 0.0
         ? d->algo_flops
         : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
+    // what the MFMAs actually multiply: padded channel counts, and for the sub-pixel forms 4
+    // phase-taps per high-resolution output pixel instead of 9
+    g_prof.xflops[prof_slot] =
+        2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * (d->ups >= 2 ? 4 : d->taps);
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
     g_prof.shape[prof_slot] = {d->taps, d->B, d->H, d->W, d->Cin, d->Cout, d->ups, d->pro,
                                arb ? (arb->skip ? 2 : 1) : 0, d->splitk};
@@ -1316,24 +1317,6 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
 #undef P2L_LAUNCH_SP
 #undef P2L_LAUNCH_SP2
     rc = p2l_check_launch();
-    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
-    return rc;
-  }
-  // ---- optional v2 kernel (see p2l_conv2.hip; measured equal-or-slower than v1, so
-  //      only used when selected through p2l_set_conv_variant) ----------------------
-  if (!arb && g_conv_variant >= 0 && d->taps == 9 && d->Cout % 64 == 0 && d->W >= 16 &&
-      d->H >= (g_conv_variant == 0 ? 16 : 8) && k.splitk == 1) {
-    ConvK k2 = k;
-    const int th = g_conv_variant == 0 ? 16 : 8;
-    k2.tw_log = 4; k2.th_log = ilog2(th); k2.tb_log = 0;
-    k2.tiles_x_log = ilog2(d->W / 16);
-    k2.tiles_y_log = ilog2(d->H / th);
-    k2.n_mtiles = d->B * (d->W / 16) * (d->H / th);
-    k2.n_ntiles = d->Cout / 64;
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("P2L_ABL"); abl = e ? atoi(e) : 0; }
-    k2.abl = abl;
-    rc = p2l_launch_conv2(k2, d->pro, d->ups, g_conv_variant, st);
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
   }
@@ -1475,12 +1458,6 @@ extern "C" int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I
   return p2l_check_launch();
 }
 
-extern "C" int p2l_set_conv_variant(int variant) {
-  if (variant < -1 || variant > 1) return P2L_EINVAL;
-  const char* e = getenv("P2L_CONV_FORCE");
-  g_conv_variant = e ? atoi(e) : variant;
-  return P2L_OK;
-}
 
 extern "C" int p2l_prof_begin(int max_launches) {
   if (max_launches < 1) return P2L_EINVAL;
@@ -1490,6 +1467,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
     g_prof.ev.push_back(e);
   }
   g_prof.flops.assign(max_launches, 0.0);
+  g_prof.xflops.assign(max_launches, 0.0);
   g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
   g_prof.shape.assign(max_launches, {});
@@ -1512,6 +1490,12 @@ extern "C" int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]) {
 }
 
 extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]) {
+  return p2l_prof_end3(flops, ms, count, bytes, nullptr);
+}
+
+extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                             double exec_flops[2]) {
+  if (exec_flops) exec_flops[0] = exec_flops[1] = 0.0;
   g_prof.on = false;
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
   count[0] = count[1] = 0;
@@ -1526,6 +1510,7 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
       return P2L_ELAUNCH;
     const int k = g_prof.kind[i];
     flops[k] += g_prof.flops[i];
+    if (exec_flops) exec_flops[k] += g_prof.xflops[i];
     if (bytes) bytes[k] += g_prof.bytes[i];
     ms[k] += t;
     count[k] += 1;

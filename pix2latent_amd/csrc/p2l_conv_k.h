@@ -41,7 +41,6 @@ struct ConvK {
   //   1 = forward: low-res input, 4 output phases (blockIdx.y), output stride 2
   //   2 = input-gradient: the 4 phase planes of the high-res dY are 4 K-slices
   int sp_mode, sp_ncc;   // sp_ncc = channel chunks per phase plane (mode 2)
-  int abl;  // ablation bits (diagnostics only, P2L_ABL env): see p2l_conv2.hip
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -101,4 +100,3 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
 }  // namespace p2lconv
 
 // v2 (persistent, LDS double-buffered) 3x3 kernel, defined in p2l_conv2.hip
-int p2l_launch_conv2(const p2lconv::ConvK& k, int pro, int ups, int cfg, hipStream_t st);

@@ -292,6 +292,10 @@ extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Li
     shape[0] = Bn; shape[1] = 1; shape[2] = 1; shape[3] = m->cbn_total;
     return P2L_OK;
   }
+  if (what == 6) {  // after p2l_biggan_bwd: d loss / d (CBN gains | CBN biases), [B][2*cbn_total]
+    *float_off = L.draw; shape[0] = Bn; shape[1] = 1; shape[2] = 1; shape[3] = 2 * m->cbn_total;
+    return P2L_OK;
+  }
   if (what != 0) return P2L_EINVAL;
   // ModuleList index -> block index (SelfAttn occupies index attn_before)
   int idx = 0;
@@ -799,6 +803,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
     c.d.algo_flops = 2.0 * B * H * W * 3.0 * 64 * 9;
     RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
   }
+  if (use_lpips == 2) return P2L_OK;   // PerceptualLoss on its own: no L1 term
   RET_IF(p2l_l1_loss_bwd(img16, target, weight, loss_mask, cache->wsum, gloss, dimg16, B, H,
                          W, 1, st));
   return P2L_OK;

@@ -226,6 +226,7 @@ extern "C" int p2l_alexloss_bwd(const P2LAlexLpips* v, const float* img16, const
     RET_IF(p2l_maxpool3s2_bwd(Wk + L.y[0], gb, gtap, ga, B, L.h[0], L.w[0], 64, st));
   }
   RET_IF(p2l_conv1_dgrad(ga, v->wt[0], dimg16, B, H, W, 64, 11, 4, 2, st));
+  if (use_lpips == 2) return P2L_OK;   // PerceptualLoss on its own: no L1 term
   return p2l_l1_loss_bwd(img16, target, weight, loss_mask, cache->wsum, gloss, dimg16, B, H, W, 1,
                          st);
 }

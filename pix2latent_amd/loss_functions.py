@@ -195,6 +195,7 @@ class _CacheSlot(object):
             self.desc.wt[k] = base + 4 * wt_off[k]
         self.desc.wsum = base + 4 * wsum_off.value
         self.held = None
+        self.B = B
 
 
 class _LossEngine(object):
@@ -229,25 +230,57 @@ class _LossEngine(object):
         self._fwd_ticket = 0
 
     def _alloc(self, B, H, W, dev):
-        if self.shape == (B, H, W):
+        """workspace + image staging sized for the LARGEST chunk seen at this resolution: a
+        ragged last chunk (32 samples = 9,9,9,5) alternates B every step, and re-allocating
+        would also drop the cached target features of every chunk"""
+        if self.shape is not None and self.shape[1:] == (H, W) and B <= self.shape[0]:
             return
+        if self.shape is not None and self.shape[1:] == (H, W):
+            B = max(B, self.shape[0])
+        else:
+            self.slots = {}                          # resolution changed: caches are void
         nbytes = self.f_ws(B, H, W)
         if nbytes == 0:
             raise N.NativeError('loss workspace sizing rejected shape %s' % ((B, H, W),))
         self.ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         self.ws_bytes = nbytes
-        self.img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
-        self.dimg16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
+        self._img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
+        self._dimg16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
         self.shape = (B, H, W)
-        self.slots = {}
+
+    @property
+    def img16(self):
+        return self._img16
+
+    @property
+    def dimg16(self):
+        return self._dimg16
 
     @staticmethod
     def _ident(t):
         return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
 
+    @staticmethod
+    def _conform(name, t, B, like):
+        """the reference multiplies / subtracts these against output [B,3,H,W] with torch
+        broadcasting (loss_functions.py:117-124,143-147): accept [H,W]-matching tensors with
+        1 or 3 channels and 1 or B samples, and say so when they do not fit (the native
+        kernels read 3*H*W floats per sample unconditionally)."""
+        e = t
+        if e.dim() == 3:
+            e = e.unsqueeze(0)
+        H, W = like.shape[2:]
+        if e.dim() != 4 or tuple(e.shape[2:]) != (H, W) or e.size(1) not in (1, 3) or \
+                e.size(0) not in (1, B):
+            raise ValueError('%s of shape %s does not broadcast against the output %s'
+                             % (name, tuple(t.shape), tuple(like.shape)))
+        if e.size(0) != B or e.size(1) != 3:
+            e = e.expand(B, 3, H, W)
+        return e.contiguous().float()
+
     def bind(self, name, t, B, like=None):
-        """[1,3,H,W] / [3,H,W] / None(weight) -> contiguous fp32 [B,3,H,W], memoised on
-        the source tensor's identity so that the target cache key stays stable."""
+        """-> contiguous fp32 [B,3,H,W] (None stays None, except `weight`), memoised on the
+        source tensor's identity so that the target cache key stays stable."""
         if t is None:
             if name != 'weight':
                 return None
@@ -259,17 +292,12 @@ class _LossEngine(object):
                 self._memo[name] = (key, torch.ones(B, 3, like.size(2), like.size(3),
                                                     device=like.device))
             return self._memo[name][1]
-        if t.dim() == 4 and t.size(0) == B and t.is_contiguous() and t.dtype == torch.float32:
+        if t.dim() == 4 and tuple(t.shape) == (B, 3) + tuple(like.shape[2:]) and \
+                t.is_contiguous() and t.dtype == torch.float32 and t.device == like.device:
             return t
         key = (self._ident(t), B)
         if self._memo.get(name, (None, None))[0] != key:
-            e = t
-            if e.dim() == 3:
-                e = e.unsqueeze(0)
-            if e.size(0) == 1 and B > 1:
-                e = e.expand(B, -1, -1, -1)
-            e = e.contiguous().float()
-            self._memo[name] = (key, e, t)
+            self._memo[name] = (key, self._conform(name, t.to(like.device), B, like), t)
         return self._memo[name][1]
 
     def prepare(self, out, target, weight, loss_mask, use_lpips):
@@ -279,8 +307,9 @@ class _LossEngine(object):
         slot = self.slots.pop(key, None)
         if slot is None:
             if len(self.slots) >= self.MAX_SLOTS:
-                slot = self.slots.pop(next(iter(self.slots)))     # recycle the LRU slot
-            else:
+                old = self.slots.pop(next(iter(self.slots)))      # evict the LRU slot ...
+                slot = old if old.B == B else None                # ... and reuse its memory
+            if slot is None:
                 slot = _CacheSlot(self.f_cache, B, H, W, out.device)
             vref = C.byref(self.vgg.desc) if use_lpips else None
             N.check(self.f_prepare(vref, N.ptr(target), N.ptr(weight), N.ptr(loss_mask), B, H, W,
@@ -295,9 +324,10 @@ class _LossEngine(object):
 
 def _apply(eng, output, target, weight, loss_mask, beta, mode):
     B = output.size(0)
-    return _ProjLossFn.apply(output, eng.bind('target', target, B),
+    return _ProjLossFn.apply(output, eng.bind('target', target, B, like=output),
                              eng.bind('weight', weight, B, like=output),
-                             eng.bind('loss_mask', loss_mask, B), eng, float(beta), mode)
+                             eng.bind('loss_mask', loss_mask, B, like=output), eng, float(beta),
+                             mode)
 
 
 class _ProjLossFn(torch.autograd.Function):
@@ -346,9 +376,7 @@ class _ProjLossFn(torch.autograd.Function):
                                 'backward(); use one loss object per in-flight graph')
         g = gloss.contiguous().float()
         if ctx.mode == 2:
-            # LPIPS only: run the combined backward with the L1 term switched off
-            raise N.NativeError('PerceptualLoss backward is only available through '
-                                'ProjectionLoss in this build')
+            use_lpips = 2          # the LPIPS term alone (L1 accumulation switched off)
         N.check(eng.f_bwd(C.byref(eng.vgg.desc) if use_lpips else None,
                           N.ptr(eng.img16), N.ptr(target), N.ptr(weight),
                           N.ptr(loss_mask), C.byref(ctx.slot.desc), N.f32(ctx.beta),
@@ -445,8 +473,7 @@ class ReconstructionLoss(nn.Module):
 
 
 class PerceptualLoss(nn.Module):
-    """ LPIPS loss with spatial weighting (reference loss_functions.py:127-148);
-    forward-only on its own (gradients flow through ProjectionLoss). """
+    """ LPIPS loss with spatial weighting (reference loss_functions.py:127-148) """
 
     def __init__(self, net='vgg', use_gpu=True, weights=None, device='cuda'):
         super(PerceptualLoss, self).__init__()

@@ -254,7 +254,9 @@ class BigGAN(nn.Module):
 
     # -------------------------------------------------------------- execution
     def _workspace(self, B):
-        if self._ws_B != B:
+        # sized for the largest batch seen: a ragged last chunk must not re-allocate GBs
+        # twice per step (the plan lays the arena out from the B of each call)
+        if B > self._ws_B:
             nbytes = self._lib.p2l_biggan_ws_bytes(C.byref(self._desc), B)
             if nbytes == 0:
                 raise N.NativeError('p2l_biggan_ws_bytes rejected batch %d' % B)
@@ -268,6 +270,7 @@ class BigGAN(nn.Module):
     def _run_forward(self, z, c):
         B = z.shape[0]
         ws = self._workspace(B)
+        self._last_B = B
         self._ticket += 1
         N.check(self._lib.p2l_biggan_fwd(C.byref(self._desc), N.ptr(z), N.ptr(c), B,
                                          N.ptr(ws), C.c_size_t(self._ws_bytes),
@@ -293,7 +296,7 @@ class BigGAN(nn.Module):
         """test hook: view of a saved NHWC activation inside the workspace."""
         off = C.c_size_t(0)
         shape = (C.c_int32 * 4)()
-        N.check(self._lib.p2l_biggan_ws_lookup(C.byref(self._desc), self._ws_B, what, layer,
+        N.check(self._lib.p2l_biggan_ws_lookup(C.byref(self._desc), self._last_B, what, layer,
                                                C.byref(off), shape), 'p2l_biggan_ws_lookup')
         n = shape[0] * shape[1] * shape[2] * shape[3]
         return self._ws[off.value:off.value + n].view(*list(shape))

@@ -217,7 +217,8 @@ class StyleGAN2(nn.Module):
         self._noise_sizes = [s[-1] * s[-2] for s in self.noise_shape]
 
     def _ensure_ws(self, B):
-        if self._ws_B != B:
+        # sized for the largest batch seen (32 samples = chunks of 9,9,9,5 alternate B)
+        if B > self._ws_B:
             nbytes = self._lib.p2l_sg2_ws_bytes(C.byref(self._desc), B)
             if nbytes == 0:
                 raise N.NativeError('p2l_sg2_ws_bytes rejected batch %d' % B)

@@ -185,20 +185,6 @@ def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
     assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
-@pytest.mark.parametrize('variant', [0, 1])
-@pytest.mark.parametrize('case', [c for c in CONV_CASES if c['taps'] == 9 and c['Cout'] % 64 == 0
-                                  and c['H'] >= 16 and not c.get('splitk')],
-                         ids=lambda c: '-'.join('%s%s' % (k, v) for k, v in c.items()) if isinstance(c, dict) else str(c))
-def test_conv_fwd_v2_variants(dev, O, case, variant):
-    """the persistent double-buffered 3x3 kernel (csrc/p2l_conv2.hip) on the same cases"""
-    from pix2latent_amd import _native as N
-    N.check(N.lib().p2l_set_conv_variant(variant))
-    try:
-        test_conv_fwd(dev, O, case, 0)
-    finally:
-        N.check(N.lib().p2l_set_conv_variant(-1))
-
-
 @pytest.mark.parametrize('taps,Cin,Cout,H', [(9, 64, 128, 16), (1, 128, 64, 16), (9, 3, 64, 32), (9, 128, 3, 32)])
 def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
     """the transpose_flip packing turns the same kernel into the input-gradient."""

@@ -10,21 +10,24 @@ pytestmark = pytest.mark.gpu
 
 PIX_TOL = 1e-3
 LOSS_TOL = 1e-3
-# Gradients of this network are discontinuous in the activations (ReLU masks,
-# max-pool / soft-max arg-max): the CPU oracle ITSELF moves by relL2 ~3e-3 (dz, dc)
-# between fp32 and fp64 (measured, DESIGN.md "numerics").  Gradient parity is
-# therefore asserted as relative L2 error < 1e-2 plus cosine > 0.9999, not as a
-# max-norm bound.
-GRAD_REL_L2 = 1e-2
-GRAD_COS = 0.9999
+# Gradients of this network are discontinuous in the activations (ReLU masks, max-pool /
+# soft-max arg-max): the CPU oracle ITSELF moves by relL2 ~3e-3 (dz, dc) between fp32 and
+# fp64.  The fp64 oracle is therefore the truth, and the native fp32 path must be no further
+# from it than FLOOR_X times the fp32 oracle's own distance (+ a small absolute slack) --
+# the rule of tests/test_stylegan2_gpu.py; layer-by-layer gradients are compared the same
+# way in tests/test_biggan_grad64_gpu.py.
+FLOOR_X, SLACK = 3.0, 2e-4
 
 
-def grad_close(got, ref, name):
-    got = got.detach().cpu().double().flatten()
-    ref = ref.detach().cpu().double().flatten()
-    rel = ((got - ref).norm() / ref.norm()).item()
-    cos = (got @ ref / (got.norm() * ref.norm())).item()
-    assert rel < GRAD_REL_L2 and cos > GRAD_COS, '%s: relL2 %g cos %.8f' % (name, rel, cos)
+def _rel(a, b):
+    a, b = a.detach().cpu().double().flatten(), b.detach().cpu().double().flatten()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def grad_close(got, ref32, ref64, name):
+    floor, dist = _rel(ref32, ref64), _rel(got, ref64)
+    assert dist < FLOOR_X * floor + SLACK, \
+        '%s: native vs fp64 oracle %g, fp32 oracle vs fp64 oracle %g' % (name, dist, floor)
 
 
 @pytest.fixture(scope='module')
@@ -45,22 +48,38 @@ def setup(dev):
     return dict(W=W, Wv=Wv, model=model, loss=loss, z=z, c=c, target=target, weight=weight, B=B)
 
 
-@pytest.fixture(scope='module')
-def oracle_run(setup):
-    """one CPU oracle forward+backward shared by the tests below."""
+def _oracle(s, dtype, with_intermediates=False):
     from oracle import biggan_ref as R, lpips_ref as L
-    s = setup
-    z = s['z'].clone().requires_grad_(True)
-    c = s['c'].clone().requires_grad_(True)
-    out, inter = R.biggan_forward(s['W'], z, c, return_intermediates=True)
-    rec = L.reconstruction_loss(out, s['target'], s['weight'])
-    per = L.perceptual_loss(s['Wv'], out, s['target'], s['weight'])
+    W = {k: v.to(dtype) for k, v in s['W'].items()}
+    Wv = {k: v.to(dtype) for k, v in s['Wv'].items()}
+    z = s['z'].to(dtype).clone().requires_grad_(True)
+    c = s['c'].to(dtype).clone().requires_grad_(True)
+    target, weight = s['target'].to(dtype), s['weight'].to(dtype)
+    out, inter = R.biggan_forward(W, z, c, return_intermediates=True)
+    rec = L.reconstruction_loss(out, target, weight)
+    per = L.perceptual_loss(Wv, out, target, weight)
     loss = rec + 10 * per
     out.retain_grad()
     loss.mean().backward()          # closure.py:58
-    return dict(out=out.detach(), inter={k: v.detach() for k, v in inter.items()},
-                rec=rec.detach(), per=per.detach(), loss=loss.detach(),
-                dz=z.grad, dc=c.grad, dout=out.grad)
+    # the loss alone from a detached image: d loss / d out, d LPIPS / d out, and L1 only
+    o2 = out.detach().clone().requires_grad_(True)
+    L.perceptual_loss(Wv, o2, target, weight).mean().backward()
+    z1 = s['z'][:1].to(dtype).clone().requires_grad_(True)
+    c1 = s['c'][:1].to(dtype).clone().requires_grad_(True)
+    l1 = L.reconstruction_loss(R.biggan_forward(W, z1, c1), target[:1], weight[:1])
+    l1.mean().backward()
+    return dict(out=out.detach(), rec=rec.detach(), per=per.detach(), loss=loss.detach(),
+                dz=z.grad, dc=c.grad, dout=out.grad, dper=o2.grad, l1=l1.detach(), dz_l1=z1.grad,
+                inter={k: v.detach() for k, v in inter.items()} if with_intermediates else None)
+
+
+@pytest.fixture(scope='module')
+def oracle_run(setup):
+    """CPU oracle forward+backward in fp32 (what the native path is compared with for
+    values) and in fp64 (the truth for gradients), shared by the tests below."""
+    o = _oracle(setup, torch.float32, with_intermediates=True)
+    o['f64'] = _oracle(setup, torch.float64)
+    return o
 
 
 def test_generator_forward_pixels(setup, oracle_run, dev):
@@ -96,7 +115,7 @@ def test_loss_backward(setup, oracle_run, dev):
     loss = s['loss'](out, s['target'].to(dev), s['weight'].to(dev))
     loss.mean().backward()
     torch.cuda.synchronize()
-    grad_close(out.grad, oracle_run['dout'], 'd loss / d out')
+    grad_close(out.grad, oracle_run['dout'], oracle_run['f64']['dout'], 'd loss / d out')
 
 
 def test_full_step_gradients_and_ranking(setup, oracle_run, dev):
@@ -110,24 +129,49 @@ def test_full_step_gradients_and_ranking(setup, oracle_run, dev):
     assert (loss.detach().cpu() - oracle_run['loss']).abs().max().item() < LOSS_TOL
     assert np.array_equal(np.argsort(loss.detach().cpu().numpy()),
                           np.argsort(oracle_run['loss'].numpy())), 'CMA ranking differs'
-    grad_close(z.grad, oracle_run['dz'], 'dz')
-    grad_close(c.grad, oracle_run['dc'], 'dc')
+    grad_close(z.grad, oracle_run['dz'], oracle_run['f64']['dz'], 'dz')
+    grad_close(c.grad, oracle_run['dc'], oracle_run['f64']['dc'], 'dc')
 
 
 def test_l1_only_config1(setup, oracle_run, dev):
     """BASELINE config 1: invert_biggan_adam, num_samples=1, L1 loss only."""
     import pix2latent_amd.loss_functions as LF
-    from oracle import biggan_ref as R, lpips_ref as L
     s = setup
-    z = s['z'][:1].clone().requires_grad_(True)
-    c = s['c'][:1].clone().requires_grad_(True)
-    out = R.biggan_forward(s['W'], z, c)
-    ref = L.reconstruction_loss(out, s['target'][:1], s['weight'][:1])
-    ref.mean().backward()
     zd = s['z'][:1].to(dev).requires_grad_(True)
     cd = s['c'][:1].to(dev).requires_grad_(True)
     rl = LF.ReconstructionLoss()
     got = rl(s['model'](z=zd, c=cd), s['target'][:1].to(dev), s['weight'][:1].to(dev))
     got.mean().backward()
-    assert (got.detach().cpu() - ref.detach()).abs().max().item() < LOSS_TOL
-    grad_close(zd.grad, z.grad, 'dz (L1 only)')
+    assert (got.detach().cpu() - oracle_run['l1']).abs().max().item() < LOSS_TOL
+    grad_close(zd.grad, oracle_run['dz_l1'], oracle_run['f64']['dz_l1'], 'dz (L1 only)')
+
+
+def test_perceptual_loss_alone_is_differentiable(setup, oracle_run, dev):
+    """PerceptualLoss (reference loss_functions.py:127-148) used on its own: value and the
+    gradient of the LPIPS term alone (p2l_projloss_bwd, use_lpips = 2)."""
+    import pix2latent_amd.loss_functions as LF
+    s = setup
+    pl = LF.PerceptualLoss(net='vgg', weights=s['Wv'], device=dev)
+    out = oracle_run['out'].to(dev).requires_grad_(True)
+    per = pl(out, s['target'].to(dev), s['weight'].to(dev))
+    per.mean().backward()
+    assert (per.detach().cpu() - oracle_run['per']).abs().max().item() < LOSS_TOL / 10
+    grad_close(out.grad, oracle_run['dper'], oracle_run['f64']['dper'], 'd LPIPS / d out')
+
+
+def test_loss_broadcasts_like_the_reference_and_rejects_misfits(setup, oracle_run, dev):
+    """target [1,3,H,W] / [3,H,W], weight and loss_mask with ONE channel (the reference
+    multiplies them against [B,3,H,W] with torch broadcasting); a wrong H/W is an error, not
+    an out-of-bounds read."""
+    from oracle import lpips_ref as L
+    s = setup
+    out = oracle_run['out'].to(dev)
+    w1 = s['weight'][:1, :1]                       # [1,1,H,W]
+    m1 = (torch.rand(1, 1, 256, 256, generator=torch.Generator().manual_seed(9)) > 0.3).float()
+    got = s['loss'](out, s['target'][0].to(dev), w1.to(dev), m1.to(dev))
+    ref = L.projection_loss(s['Wv'], oracle_run['out'], s['target'][:1], w1, m1)
+    assert (got.cpu() - ref).abs().max().item() < LOSS_TOL
+    with pytest.raises(ValueError, match='does not broadcast'):
+        s['loss'](out, s['target'][:, :, :128].to(dev), s['weight'].to(dev))
+    with pytest.raises(ValueError, match='does not broadcast'):
+        s['loss'](out, s['target'].to(dev), s['weight'][:2].to(dev))

@@ -218,7 +218,7 @@ def test_hybrid_nevergrad_on_stylegan2(sg, dev):
                                    max_batch_size=3)
     opt.ng_seed = 0
     variables, outs, losses = opt.optimize(num_samples=8, meta_steps=2, grad_steps=3, last_grad_steps=4)
-    ng_opt = list(opt.ng_optimizers.values())[0]
+    ng_opt = opt.sampler.opt
     assert ng_opt.num_ask == 8 * 3 and ng_opt.num_tell == 8 * 2
     assert ng_opt.budget == 2 * 3
     final = np.array(losses[-1][1]['loss'])
@@ -226,7 +226,7 @@ def test_hybrid_nevergrad_on_stylegan2(sg, dev):
     assert losses[-1][0] == 2 * 3 + 4
     assert outs[0].shape[-2] >= SIZE          # collage of the final samples
     # Adam refinement lowers the loss of what was asked
-    z0 = torch.stack([torch.as_tensor(c.args[0], dtype=torch.float32) for c in opt._sampled[('input', 'z')]])
+    z0 = torch.stack([torch.as_tensor(c.args[0], dtype=torch.float32) for c in opt.sampler._handle])
     with torch.no_grad():
         l_asked = opt.loss_fn(model(z=z0.to(dev)), target.to(dev), weight.to(dev), loss_mask.to(dev)).cpu().numpy()
     assert final.mean() < l_asked.mean()
