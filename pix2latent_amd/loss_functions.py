@@ -322,12 +322,25 @@ class _LossEngine(object):
         return slot
 
 
+def _channels(t):
+    return None if t is None else (t.size(0) if t.dim() == 3 else t.size(1))
+
+
 def _apply(eng, output, target, weight, loss_mask, beta, mode):
     B = output.size(0)
-    return _ProjLossFn.apply(output, eng.bind('target', target, B, like=output),
+    # Reference broadcasting quirk (loss_functions.py:119-123): with a ONE-channel
+    # `_weight = loss_mask * weight` the numerator sum(|t - o| * _weight) runs over the 3
+    # image channels but the denominator sum(_weight) over one, i.e. the L1 term is 3x the
+    # 3-channel-weight value.  (The LPIPS map has one channel itself, so its term is not.)
+    wc, mc = _channels(weight), _channels(loss_mask)
+    l1_factor = 3.0 if (wc == 1 and mc in (None, 1)) else 1.0
+    if mode == 2:
+        l1_factor = 1.0
+    loss = _ProjLossFn.apply(output, eng.bind('target', target, B, like=output),
                              eng.bind('weight', weight, B, like=output),
-                             eng.bind('loss_mask', loss_mask, B, like=output), eng, float(beta),
-                             mode)
+                             eng.bind('loss_mask', loss_mask, B, like=output), eng,
+                             float(beta) / l1_factor, mode)
+    return loss if l1_factor == 1.0 else l1_factor * loss
 
 
 class _ProjLossFn(torch.autograd.Function):

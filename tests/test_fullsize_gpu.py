@@ -197,7 +197,7 @@ def test_c5_transform_basincma_around_ffhq_1024_wplus(ffhq_wplus, dev):
                                                       (st._t + 0.1 * t_rows[:2].cpu())[:, 1:]),
                                             [2, 3, size, size], align_corners=False),
             align_corners=False)
-        assert (got[:2].cpu() - ref).abs().max().item() < 1e-5
+        assert (got[:2].cpu() - ref).abs().max().item() < 1e-4   # fp32 grid coordinates at 1024 px
         # the un-warped scoring used for tell is reproducible and finite at this size
         a = opt.losses_for_tell(variables)
         b = opt.losses_for_tell(variables)
@@ -255,7 +255,8 @@ def test_c4_hybrid_nevergrad_cars_512_num_samples_32(dev):
     final = np.array(losses[-1][1]['loss'])
     assert final.shape == (32,) and np.isfinite(final).all() and losses[-1][0] == 4
     z = torch.stack(list(variables.input.z.data))
-    assert z.abs().max().item() <= 2.0 + 1e-6                  # Clamp ran after NormalPerturb
-    # the perturbation is the reference's stream: replay it on the asked values
+    # Clamp(2) runs (after NormalPerturb) BEFORE each forward; the Adam update that follows
+    # moves a latent by at most ~lr
+    assert z.abs().max().item() <= 2.0 + 0.05 + 1e-3
     asked = torch.stack([torch.as_tensor(c.args[0], dtype=torch.float32) for c in opt.sampler._handle])
-    assert asked.shape == (32, 512)
+    assert asked.shape == (32, 512) and not torch.equal(asked.to(dev), z.detach())
