@@ -347,7 +347,7 @@ def main():
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         exec_tflops = xflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
-        bf3 = N.default_wfmt() == N.WFMT_BF16X3
+        bf3 = N.default_wfmt() != N.WFMT_F32
         # PMC counters cannot be read from inside the timed process: `traffic` is the
         # committed result of the separate rocprofv3 --pmc passes over this same command
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent

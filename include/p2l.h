@@ -200,8 +200,23 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     Packed layout (an image of the kernel's LDS weight tile, streamed by LDS-direct DMA):
  *       [K_pad/16 chunks][N_pad/32 tiles][slabs: 9 taps | 16 = phase*4+tap][32 rows][96 B],
  *       row = [x1 k0-7 | x1 k8-15 | x2 k0-7 | x2 k8-15 | x3 k0-7 | x3 k8-15] as bf16, the
- *       16-byte chunk index XOR-ed with bit 3 of the row.  N_pad must equal P2LConv.Cout. */
-enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1 };
+ *       16-byte chunk index XOR-ed with bit 3 of the row.  N_pad must equal P2LConv.Cout.
+ *   P2L_WFMT_BF16X3W: the same arithmetic and the same packed image, FOLLOWED by the
+ *     Winograd F(2x2,3x3) transform-domain image of the weights (G g G^T in fp64, rounded to
+ *     fp32, split into the same three bf16 pieces; [K_pad/16][16 frequencies][N_pad/32]
+ *     [3 pieces][64 lanes] x 16 B = MFMA B-fragment order).  p2l_conv_fwd / p2l_conv_dgrad_arb
+ *     then run stride-1 3x3 layers whose grid is whole 16x16-pixel x 64-channel blocks in the
+ *     Winograd form (2.25x fewer matrix products, csrc/p2l_wino.hip) and everything else on the
+ *     direct kernel.  Results agree with P2L_WFMT_BF16X3 to fp32 rounding.
+ *     p2l_packed_weight_floats() gives the buffer size of any format. */
+enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2 };
+size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt);
+/* which P2L_WFMT_BF16X3W launches take the Winograd form: 0 = none, 1 = those whose grid gives
+ * every CU a block (default; $P2L_WINO overrides the default), 2 = every eligible shape
+ * (tests: small grids too) */
+int p2l_set_wino_mode(int mode);
+int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
+                              int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
                              int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I, int N_pad, int K_pad,

@@ -117,18 +117,46 @@ class P2LLossCache(C.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
-WFMT_F32, WFMT_BF16X3 = 0, 1
+WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W = 0, 1, 2
 
 
 def default_wfmt():
-    """weight / arithmetic format of the 3x3 convs: bf16x3 (fp32-equivalent on the bf16
-    matrix pipe, see include/p2l.h) unless P2L_CONV_WFMT=f32 asks for the exact-fp32 MFMA."""
+    """weight / arithmetic format of the 3x3 convs (include/p2l.h): bf16x3 = fp32-equivalent
+    3-way split on the bf16 matrix pipe, with the Winograd-domain weight image appended so that
+    eligible layers run in the F(2x2,3x3) form; P2L_CONV_WFMT=bf16x3-direct keeps every layer
+    on the direct kernel, =f32 asks for the exact-fp32 MFMA."""
     v = os.environ.get('P2L_CONV_WFMT', 'bf16x3').lower()
     if v in ('f32', 'fp32', '0'):
         return WFMT_F32
-    if v in ('bf16x3', 'bf3', '1'):
+    if v in ('bf16x3-direct', 'bf3d', '1'):
         return WFMT_BF16X3
-    raise ValueError('P2L_CONV_WFMT=%r (expected f32 or bf16x3)' % v)
+    if v in ('bf16x3', 'bf3', 'bf16x3w', '2'):
+        return WFMT_BF16X3W
+    raise ValueError('P2L_CONV_WFMT=%r (expected f32, bf16x3 or bf16x3-direct)' % v)
+
+
+def pack_conv_weight(src, taps, n_pad, k_pad, flip, wfmt, subpix_mode=None):
+    """[O,I,kh,kw] fp32 device tensor -> packed weight buffer of format `wfmt` (1x1 convs are
+    always fp32; subpix_mode 0 / 1 = the 16 phase-tap matrices of the sub-pixel forms)"""
+    L = lib()
+    O, I = src.shape[0], src.shape[1]
+    src = src.detach().float().contiguous()
+    if taps != 9:
+        wfmt = WFMT_F32
+    if subpix_mode is not None:
+        n = 16 * n_pad * k_pad
+        dst = torch.empty(n * 3 // 2 if wfmt != WFMT_F32 else n, device=src.device, dtype=torch.float32)
+        fn = L.p2l_pack_conv_weight_subpix_bf3 if wfmt != WFMT_F32 else L.p2l_pack_conv_weight_subpix
+        check(fn(ptr(src), O, I, n_pad, k_pad, int(flip), int(subpix_mode), ptr(dst), stream()),
+              'p2l_pack_conv_weight_subpix')
+        return dst
+    n = L.p2l_packed_weight_floats(taps, n_pad, k_pad, wfmt)
+    dst = torch.empty(n, device=src.device, dtype=torch.float32)
+    fn = {WFMT_F32: L.p2l_pack_conv_weight, WFMT_BF16X3: L.p2l_pack_conv_weight_bf3,
+          WFMT_BF16X3W: L.p2l_pack_conv_weight_bf3w}[wfmt]
+    check(fn(ptr(src), O, I, taps, n_pad, k_pad, int(flip), ptr(dst), stream()),
+          'p2l_pack_conv_weight')
+    return dst
 POOL_NONE, POOL_MAX, POOL_SUM = 0, 1, 2
 PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 
@@ -137,6 +165,7 @@ EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
+    'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode',
     'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
@@ -183,7 +212,8 @@ def lib():
         _lib.p2l_arb_defer_cancel.restype = None
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
-                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes'):
+                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes',
+                     'p2l_packed_weight_floats'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

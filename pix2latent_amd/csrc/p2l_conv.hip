@@ -65,25 +65,6 @@ struct ConvProf {
   int seq = 0, period = 1, phase = 0;       // sampling (p2l_prof_step)
 } g_prof;
 
-__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
-  if (act == P2L_ACT_RELU) {
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-  } else if (act == P2L_ACT_TANH) {
-    v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
-  } else if (act == P2L_ACT_LRELU_SQRT2) {   // FusedLeakyReLU: lrelu(0.2) * sqrt(2)
-    const float a = 1.41421356237f, c = 0.2f * 1.41421356237f;
-    v.x *= v.x > 0.f ? a : c; v.y *= v.y > 0.f ? a : c;
-    v.z *= v.z > 0.f ? a : c; v.w *= v.w > 0.f ? a : c;
-  }
-  return v;
-}
-__device__ __forceinline__ f32x4 ld4(const float* p, unsigned off) {
-  return *reinterpret_cast<const f32x4*>(p + (size_t)off);
-}
-__device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
-  *reinterpret_cast<f32x4*>(p + (size_t)off) = v;
-}
-
 // Vectorised epilogue.  The MFMA C layout gives a lane one channel of 16 pixels:
 // storing that directly is 4-byte accesses, 128 B per pixel and instruction.  Instead
 // every wave dumps its 32 x (NT*32) accumulator tile into LDS (free after the K loop)
@@ -110,9 +91,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
   __syncthreads();
 
   const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
-  const bool arb = k.arb_x != nullptr;
-  const bool pool_sum = k.pool == P2L_POOL_SUM;
-  f32x4 sgx = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+  EpiSums S;
 #pragma unroll
   for (int it0 = 0; it0 < ITEMS; it0 += 64) {
     const int it = it0 + lane;
@@ -123,125 +102,15 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
     const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
     if (b >= k.B || n >= k.n_store) continue;
     const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
-    // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of the output buffer
-    const unsigned OW = (unsigned)k.obW;
-    const unsigned pix0 = ((unsigned)(b * k.obH) + ((unsigned)oy0 << osh) + (unsigned)ph_y) * OW +
-                          ((unsigned)ox0 << osh) + (unsigned)ph_x;
-    const unsigned sub[4] = {0u, 1u << osh, OW << osh, (OW << osh) + (1u << osh)};
-    // border quads of a grid that is not a multiple of the tile
-    bool ok[4] = {true, true, true, true};
-    if (k.partial) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ok[s] = (oy0 + (s >> 1) < k.H) && (ox0 + (s & 1) < k.W);
-      if (!ok[0]) continue;
-    }
     f32x4 v[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * EP + c4 * 4) * k.alpha;
-    const unsigned ppix = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (k.W >> 1) + (ox0 >> 1));
-
-    if (!arb) {
-      f32x4 bias4 = {0, 0, 0, 0};
-      if (k.bias) bias4 = ld4(k.bias, (unsigned)n);
-      f32x4 osc = {1.f, 1.f, 1.f, 1.f};
-      if (k.oscale) osc = ld4(k.oscale, (unsigned)(b * k.oscale_bstride + n));
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (!ok[s]) continue;
-        const unsigned pix = pix0 + sub[s];
-        f32x4 t = v[s] * osc + bias4;
-        if (k.noise) t += k.noise_w * k.noise[(size_t)pix];
-        if (k.res) t += ld4(k.res, (k.res_ups ? ppix : pix) * (unsigned)k.res_ld + (unsigned)n);
-        t = act4(t, k.act);
-        if (k.mask) {
-          const f32x4 m = ld4(k.mask, pix * (unsigned)k.mask_ld + (unsigned)n);
-          t.x = m.x > 0.f ? t.x : 0.f; t.y = m.y > 0.f ? t.y : 0.f;
-          t.z = m.z > 0.f ? t.z : 0.f; t.w = m.w > 0.f ? t.w : 0.f;
-        }
-        if (k.y) st4(k.y, pix * (unsigned)k.y_ld + (unsigned)n, t);
-        v[s] = t;
-      }
-      if (k.pool) {
-        f32x4 p;
-        if (k.pool == P2L_POOL_MAX) {
-          p.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
-          p.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
-          p.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
-          p.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
-        } else {
-          p = (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        st4(k.yp, ppix * (unsigned)k.yp_ld + (unsigned)n, p);
-      }
-    } else {
-      const f32x4 s4 = ld4(k.arb_s, (unsigned)(b * k.arb_bstride + n));
-      const f32x4 t4 = ld4(k.arb_t, (unsigned)(b * k.arb_bstride + n));
-      const bool has_skip = k.arb_skip && n < k.arb_skip_C;
-      const int nv = pool_sum ? 1 : 4;
-      if (pool_sum) v[0] = (v[0] + v[1]) + (v[2] + v[3]);
-      float* dst = pool_sum ? k.yp : k.y;
-      const unsigned dld = (unsigned)(pool_sum ? k.yp_ld : k.y_ld);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (s < nv) {
-          const unsigned pix = pool_sum ? ppix : pix0 + sub[s];
-          const f32x4 xv = ld4(k.arb_x, pix * (unsigned)k.arb_x_ld + (unsigned)n);
-          const f32x4 pre = xv * s4 + t4;
-          f32x4 g = v[s];
-          if (!k.arb_nomask) {
-            g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
-            g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
-          }
-          f32x4 o = g * s4;
-          if (has_skip) {
-            const unsigned ld = (unsigned)k.arb_skip_ld;
-            if (k.arb_skip_ups) {
-              // this output pixel's 2x2 children in the [B,2Ho,2Wo,*] gradient
-              const int Wo = pool_sum ? (k.W >> 1) : k.W, Ho = pool_sum ? (k.H >> 1) : k.H;
-              const int yy = pool_sum ? (oy0 >> 1) : oy0 + (s >> 1);
-              const int xx = pool_sum ? (ox0 >> 1) : ox0 + (s & 1);
-              const unsigned W2 = 2u * (unsigned)Wo;
-              const unsigned cq = ((unsigned)(b * 2 * Ho + 2 * yy)) * W2 + 2u * (unsigned)xx;
-              o += (ld4(k.arb_skip, cq * ld + n) + ld4(k.arb_skip, (cq + 1) * ld + n)) +
-                   (ld4(k.arb_skip, (cq + W2) * ld + n) + ld4(k.arb_skip, (cq + W2 + 1) * ld + n));
-            } else {
-              o += ld4(k.arb_skip, pix * ld + (unsigned)n);
-            }
-          }
-          st4(dst, pix * dld + (unsigned)n, o);
-          sgx += g * xv;
-          sg += g;
-        }
-      }
-    }
+    epi_item(k, v, b, oy0, ox0, n, osh, ph_y, ph_x, S);
   }
-  if (arb) {
-    // lanes with equal (lane % C4) hold the same 4 channels for different quads
-#pragma unroll
-    for (int o = C4; o < 64; o <<= 1) {
-      sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
-      sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
-      sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
-      sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
-    }
-    __syncthreads();                      // everyone is done reading the tile dumps
-    float* red = smem;                    // [2][4 waves][COLS]
-    if (lane < C4) {
-      *reinterpret_cast<f32x4*>(red + wave * COLS + lane * 4) = sgx;
-      *reinterpret_cast<f32x4*>(red + (4 + wave) * COLS + lane * 4) = sg;
-    }
-    __syncthreads();
-    const int tid = threadIdx.x;
-    if (tid < COLS && n0 + tid < k.n_store) {
-      const float a = (red[tid] + red[COLS + tid]) + (red[2 * COLS + tid] + red[3 * COLS + tid]);
-      const float t = (red[4 * COLS + tid] + red[5 * COLS + tid]) +
-                      (red[6 * COLS + tid] + red[7 * COLS + tid]);
-      const size_t o = ((size_t)b0 * k.arb_nblk + tile_in_image) * k.Cout + n0 + tid;
-      k.arb_partial[o] = a;
-      k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = t;
-    }
-  }
+  if (k.arb_x != nullptr)
+    epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
+                             (size_t)b0 * k.arb_nblk + tile_in_image, n0);
 }
 
 // BF3 = fp32-equivalent arithmetic on the bf16 matrix pipe (16x the fp32 MFMA rate):
@@ -255,26 +124,8 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 // the 16-byte chunk index XOR-ed with bit 3 of the row (16 consecutive rows then cover all
 // 64 banks exactly once per ds_read_b128, no padding).  The C layout is the same as the
 // fp32 instruction's, so the epilogues are shared.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr bool kDmaWeights = true;   // bf16x3 3x3: weight tile by LDS-direct DMA (see the kernel)
-
-// position of logical 16-byte chunk c (0..5) inside LDS row `row`: lowest bit XOR-ed with
-// bit 3 of the row.  Rows 8 or 24 apart start on the same bank (96-byte pitch = 24 dwords)
-// and get distinct 16-byte windows this way; a window may only move by +-4 dwords (row
-// bases are multiples of 8 dwords), so rows 16 apart - which the 2x2-quad pixel order does
-// put into one ds_read_b128 lane group - still collide: measured 19 % of LDS cycles, at
-// 33 % LDS utilisation (a rotation over all 6 chunks was tried: 46 % conflicts).
-__device__ __forceinline__ int bf3_chunk(int c, int row) { return c ^ ((row >> 3) & 1); }
-
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-  h = __builtin_convertvector(v, bf16x4);
-  const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
-  m = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-  l = __builtin_convertvector(r2, bf16x4);
-}
 
 template <int TAPS, int BN, int KC, int A_ITERS, int PRO, bool UPS, bool BF3 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
@@ -293,9 +144,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
 
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int HW_ = TW + 2, HH_ = TH + 2;
-  const int a_rows = (TAPS != 1) ? TB * HH_ * HW_ : 128;
+  const int HP = (TAPS != 1) ? k.hp : HW_;                  // LDS pitch of a patch line (rows)
+  const int a_rows = (TAPS != 1) ? TB * HH_ * HW_ : 128;    // staged pixels
+  const int a_rows_lds = (TAPS != 1) ? TB * HH_ * HP : 128; // LDS rows they occupy
   float* As = smem;
-  float* Bs = smem + a_rows * PITCH;
+  float* Bs = smem + a_rows_lds * PITCH;
 
   // ---- which tile -------------------------------------------------------
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
@@ -338,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         const int hy = rem / HW_, hx = rem - hy * HW_;
         iy = y0 + hy - 1;
         ix = x0 + hx - 1;
+        a_loff[it] = ((tb * HH_ + hy) * HP + hx) * PITCH + v * 4;
       } else {
         const int Q = p >> 2, s = p & 3;
         const int qx = Q & ((TW >> 1) - 1);
@@ -473,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
       const int qx = Q & ((TW >> 1) - 1);
       const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
       const int tb = Q >> (k.tw_log + k.th_log - 2);
-      a_row0 = (tb * HH_ + 2 * qy + (s >> 1)) * HW_ + 2 * qx + (s & 1);
+      a_row0 = (tb * HH_ + 2 * qy + (s >> 1)) * HP + 2 * qx + (s & 1);
     } else {
       a_row0 = i;
     }
@@ -620,13 +474,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           oy = 1 - (cls >> 1);
           ox = 1 - (cls & 1);
         }
-        win_row = oy * HW_ + ox;
+        win_row = oy * HP + ox;
       }
       bf16x8 af[2][3], bq[2][3];
       auto lda = [&](int tap, bf16x8 (&a)[3]) {
         const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
         const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
-        const int arow = a_row0 + win_row + dy * HW_ + dx;
+        const int arow = a_row0 + win_row + dy * HP + dx;
         const float* ar = As + arow * 24;
         const float* aq = ar + bf3_chunk(lhi, arow) * 4;      // pieces at +0 / +32 / +64 bytes
         a[0] = *reinterpret_cast<const bf16x8*>(aq);
@@ -710,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           oy = 1 - (cls >> 1);
           ox = 1 - (cls & 1);
         }
-        win0 = (oy * HW_ + ox) * PITCH;
+        win0 = (oy * HP + ox) * PITCH;
       }
       if constexpr (BF3) {
         // Fragment software pipeline.  Unit u = (tap, n-tile j): 6 MFMAs (192 issue cycles)
@@ -724,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         auto lda = [&](int tap, bf16x8 (&a)[3]) {
           const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
           const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
-          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HP + dx : 0);
           const float* ar = As + arow * 24;
           const float* aq = ar + bf3_chunk(lhi, arow) * 4;
           a[0] = *reinterpret_cast<const bf16x8*>(aq);
@@ -765,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
         const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
         const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
         if (BF3) {
-          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HW_ + dx : 0);
+          const int arow = a_row0 + ((TAPS != 1) ? win0 / PITCH + dy * HP + dx : 0);
           const float* ar = As + arow * 24;
           const float* aq = ar + bf3_chunk(lhi, arow) * 4;
           const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq);
@@ -795,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvK k) {
           for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[j], acc[j], 0, 0, 0);
           continue;
         }
-        const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HW_ + dx) * PITCH : 0);
+        const float* ap = a_frag + ((TAPS != 1) ? win0 + (dy * HP + dx) * PITCH : 0);
   #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk * 8);
@@ -1069,6 +923,37 @@ int choose_tile(const P2LConv* d, ConvK& k) {
   return P2L_OK;
 }
 
+// LDS pitch (rows) of one line of the staged input patch (ConvK::hp).  Brute-forced over the
+// ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) for the 2x2-quad pixel order and
+// the 96-byte swizzled row: 16-wide tiles -> 24 (1.0 LDS cycle per lane group instead of 2.0
+// at 18), 8-wide -> 12 (2.0 instead of 3.0); 23 KB of patch instead of 17 KB still leaves
+// two blocks per CU (78.3 KB each).
+int halo_pitch(int TW, bool bf3) {
+  if (!bf3) return TW + 2;
+  return TW == 16 ? 24 : (TW == 8 ? 12 : TW + 2);
+}
+
+// Winograd form: weights carry the transform-domain image (P2L_WFMT_BF16X3W), plain 3x3
+// (no upsample fusion, no split-K request), whole 8x16 blocks, and enough blocks to give
+// every CU two ($P2L_WINO=0 switches it off, =2 forces it for any grid size: tests)
+static int g_wino_mode = -1;
+static int wino_mode() {
+  if (g_wino_mode < 0) { const char* e = getenv("P2L_WINO"); g_wino_mode = e ? atoi(e) : 1; }
+  return g_wino_mode;
+}
+extern "C" int p2l_set_wino_mode(int mode) {
+  if (mode < 0 || mode > 2) return P2L_EINVAL;
+  g_wino_mode = mode;
+  return P2L_OK;
+}
+bool wino_eligible(const P2LConv* d, const ConvK& k) {
+  if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || wino_mode() == 0) return false;
+  if (d->H % 8 || d->W % 16 || !p2l_wino_weight_ok(d->Cout, d->Cin) || k.splitk > 1) return false;
+  if (d->x_ld % 4) return false;
+  const int nblk = d->B * (d->H / 8) * (d->W / 16) * (d->Cout / 64);
+  return wino_mode() == 2 || nblk >= 448;
+}
+
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
 // share a CU's matrix pipes, so time ~ ceil(blocks / 256 CUs) * work-per-block.
@@ -1169,7 +1054,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (d->pool != P2L_POOL_NONE && !yp) return P2L_EINVAL;
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
-  if (d->wfmt != P2L_WFMT_F32 && (d->wfmt != P2L_WFMT_BF16X3 || d->taps != 9)) return P2L_EUNSUP;
+  if (d->wfmt != P2L_WFMT_F32 &&
+      ((d->wfmt != P2L_WFMT_BF16X3 && d->wfmt != P2L_WFMT_BF16X3W) || d->taps != 9))
+    return P2L_EUNSUP;
   if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
   if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
   if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
@@ -1196,6 +1083,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   int rc = choose_tile(d, k);
   if (rc) return rc;
   k.iH = d->H; k.iW = d->W; k.ibH = d->H; k.ibW = d->W; k.obH = d->H; k.obW = d->W;
+  k.hp = halo_pitch(1 << k.tw_log, d->wfmt != P2L_WFMT_F32 && d->taps == 9);
   if (ex) {
     k.oscale = ex->oscale; k.oscale_bstride = ex->oscale_bstride;
     k.noise = ex->noise; k.noise_w = ex->noise_w;
@@ -1256,6 +1144,23 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
     (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
   }
+  // ---- Winograd F(2x2,3x3) form (p2l_wino.hip): stride-1 3x3 layers whose grid fills the
+  //      chip with 8x16-pixel x 64-channel blocks; everything else stays on the direct kernel
+  if (wino_eligible(d, k)) {
+    ConvK kw = k;                    // (arb_nblk keeps the 128-pixel tiling of the caller's buffer)
+    kw.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
+    kw.tiles_x = d->W / 16; kw.tiles_y = d->H / 8;
+    kw.n_mtiles = d->B * kw.tiles_x * kw.tiles_y;
+    kw.n_ntiles = d->Cout / 64;
+    kw.nchunks = d->Cin / 16;
+    kw.splitk = 1;
+    rc = p2l_wino_launch(kw, d->pro, st);
+    if (prof_slot >= 0) {
+      g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * 4;   // 16 per quad
+      (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    }
+    return rc;
+  }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
   if (d->ups >= 2) {
     if (d->taps != 9 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
@@ -1282,8 +1187,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.ups = 0;
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256) && k.tb_log == 0;
-    const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
-    size_t lds_sp = (size_t)(a_rows_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
+    const bool bf3 = d->wfmt != P2L_WFMT_F32;
+    const int a_lds_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * k.hp;
+    size_t lds_sp = (size_t)(a_lds_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
     if (lds_epi > lds_sp) lds_sp = lds_epi;
     dim3 grid(k.n_mtiles * k.n_ntiles, d->ups == 2 ? 4 : 1), block(256);
@@ -1322,8 +1228,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
-  const bool bf3 = d->wfmt == P2L_WFMT_BF16X3;
-  size_t lds = (size_t)(a_rows + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
+  const bool bf3 = d->wfmt != P2L_WFMT_F32;
+  const int a_rows_lds = (d->taps == 9) ? TB * (TH + 2) * k.hp : 128;
+  size_t lds = (size_t)(a_rows_lds + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
   {
     // the vectorised epilogue re-uses the staging LDS for 4 wave tiles of 32 x (bn+4)
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
@@ -1541,6 +1448,27 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
 }
 
 // bf16x3 pre-split weights for the BF3 conv kernels: 1.5 x taps*K_pad*N_pad floats
+// P2L_WFMT_BF16X3W: the direct bf16x3 tile image followed -- for shapes the Winograd kernel
+// takes (p2l_wino_weight_ok) -- by the transform-domain image of the same weights
+extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt) {
+  const size_t direct = (size_t)taps * N_pad * K_pad;
+  if (wfmt == P2L_WFMT_F32) return direct;
+  size_t n = direct * 3 / 2;
+  if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
+    n += p2l_wino_weight_floats(N_pad, K_pad);
+  return n;
+}
+
+extern "C" int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
+                                         int K_pad, int transpose_flip, float* w_packed,
+                                         void* stream) {
+  int rc = p2l_pack_conv_weight_bf3(w_oihw, O, I, taps, N_pad, K_pad, transpose_flip, w_packed,
+                                    stream);
+  if (rc || !p2l_wino_weight_ok(N_pad, K_pad)) return rc;
+  return p2l_wino_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip,
+                       w_packed + (size_t)taps * N_pad * K_pad * 3 / 2, (hipStream_t)stream);
+}
+
 extern "C" int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
                                         int K_pad, int transpose_flip, float* w_packed,
                                         void* stream) {

@@ -1,4 +1,4 @@
-// Shared by the conv kernels (p2l_conv.hip, p2l_conv2.hip): kernel argument block and
+// Shared by the conv kernels (p2l_conv.hip): kernel argument block and
 // the fused epilogue.
 #pragma once
 #include "p2l_common.h"
@@ -41,7 +41,50 @@ struct ConvK {
   //   1 = forward: low-res input, 4 output phases (blockIdx.y), output stride 2
   //   2 = input-gradient: the 4 phase planes of the high-res dY are 4 K-slices
   int sp_mode, sp_ncc;   // sp_ncc = channel chunks per phase plane (mode 2)
+  // LDS pitch (in rows) of one line of the staged input patch; >= tile width + 2.  bf16x3:
+  // 24 for 16-wide tiles, which puts the two pixel rows a wave's ds_read_b128 lane group
+  // touches on disjoint banks (with tile width + 2 = 18 every activation-fragment read was a
+  // 2-way bank conflict: rows 16 apart share a bank window for the 96-byte row).
+  int hp;
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+  if (act == P2L_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  } else if (act == P2L_ACT_TANH) {
+    v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+  } else if (act == P2L_ACT_LRELU_SQRT2) {   // FusedLeakyReLU: lrelu(0.2) * sqrt(2)
+    const float a = 1.41421356237f, c = 0.2f * 1.41421356237f;
+    v.x *= v.x > 0.f ? a : c; v.y *= v.y > 0.f ? a : c;
+    v.z *= v.z > 0.f ? a : c; v.w *= v.w > 0.f ? a : c;
+  }
+  return v;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p, unsigned off) {
+  return *reinterpret_cast<const f32x4*>(p + (size_t)off);
+}
+__device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p + (size_t)off) = v;
+}
+
+// position of logical 16-byte chunk c (0..5) inside LDS row `row`: lowest bit XOR-ed with
+// bit 3 of the row.  Rows 8 or 24 apart start on the same bank (96-byte pitch = 24 dwords)
+// and get distinct 16-byte windows this way; a window may only move by +-4 dwords (row
+// bases are multiples of 8 dwords), so rows 16 apart - which the 2x2-quad pixel order does
+// put into one ds_read_b128 lane group - still collide unless the patch lines are 24 rows
+// apart in LDS (ConvK::hp; a rotation over all 6 chunks was tried: 46 % conflicts).
+__device__ __forceinline__ int bf3_chunk(int c, int row) { return c ^ ((row >> 3) & 1); }
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = __builtin_convertvector(v, bf16x4);
+  const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+  m = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+  l = __builtin_convertvector(r2, bf16x4);
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == P2L_ACT_RELU) return fmaxf(v, 0.f);
@@ -97,6 +140,148 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
 }
 
 
+// ---- one epilogue item ------------------------------------------------------------------
+// quad = 2x2 output pixels with top-left (oy0, ox0) of image b, times FOUR consecutive output
+// channels n..n+3.  v[s] = alpha-scaled accumulators of the quad's pixels in the order
+// (0,0) (0,1) (1,0) (1,1).  Handles every epilogue mode of the conv kernels:
+//   v = v*oscale + bias + noise + residual ; act ; mask ; store ; 2x2 max/sum pool, or
+//   ARB (input-gradient convs): g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ;
+//   running sums of g*x and g per channel (S)  [da 2x2-summed first if pool == SUM].
+// osh = 1: sub-pixel forward, the block writes phase (ph_y, ph_x) of the output buffer.
+struct EpiSums {
+  f32x4 sgx = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+};
+
+__device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, int oy0, int ox0,
+                                         int n, int osh, int ph_y, int ph_x, EpiSums& S) {
+  const bool arb = k.arb_x != nullptr;
+  const bool pool_sum = k.pool == P2L_POOL_SUM;
+  // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of the output buffer
+  const unsigned OW = (unsigned)k.obW;
+  const unsigned pix0 = ((unsigned)(b * k.obH) + ((unsigned)oy0 << osh) + (unsigned)ph_y) * OW +
+                        ((unsigned)ox0 << osh) + (unsigned)ph_x;
+  const unsigned sub[4] = {0u, 1u << osh, OW << osh, (OW << osh) + (1u << osh)};
+  // border quads of a grid that is not a multiple of the tile
+  bool ok[4] = {true, true, true, true};
+  if (k.partial) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ok[s] = (oy0 + (s >> 1) < k.H) && (ox0 + (s & 1) < k.W);
+    if (!ok[0]) return;
+  }
+  const unsigned ppix = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (k.W >> 1) + (ox0 >> 1));
+
+  if (!arb) {
+    f32x4 bias4 = {0, 0, 0, 0};
+    if (k.bias) bias4 = ld4(k.bias, (unsigned)n);
+    f32x4 osc = {1.f, 1.f, 1.f, 1.f};
+    if (k.oscale) osc = ld4(k.oscale, (unsigned)(b * k.oscale_bstride + n));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (!ok[s]) continue;
+      const unsigned pix = pix0 + sub[s];
+      f32x4 t = v[s] * osc + bias4;
+      if (k.noise) t += k.noise_w * k.noise[(size_t)pix];
+      if (k.res) t += ld4(k.res, (k.res_ups ? ppix : pix) * (unsigned)k.res_ld + (unsigned)n);
+      t = act4(t, k.act);
+      if (k.mask) {
+        const f32x4 m = ld4(k.mask, pix * (unsigned)k.mask_ld + (unsigned)n);
+        t.x = m.x > 0.f ? t.x : 0.f; t.y = m.y > 0.f ? t.y : 0.f;
+        t.z = m.z > 0.f ? t.z : 0.f; t.w = m.w > 0.f ? t.w : 0.f;
+      }
+      if (k.y) st4(k.y, pix * (unsigned)k.y_ld + (unsigned)n, t);
+      v[s] = t;
+    }
+    if (k.pool) {
+      f32x4 p;
+      if (k.pool == P2L_POOL_MAX) {
+        p.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
+        p.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
+        p.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
+        p.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
+      } else {
+        p = (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      st4(k.yp, ppix * (unsigned)k.yp_ld + (unsigned)n, p);
+    }
+  } else {
+    const f32x4 s4 = ld4(k.arb_s, (unsigned)(b * k.arb_bstride + n));
+    const f32x4 t4 = ld4(k.arb_t, (unsigned)(b * k.arb_bstride + n));
+    const bool has_skip = k.arb_skip && n < k.arb_skip_C;
+    const int nv = pool_sum ? 1 : 4;
+    if (pool_sum) v[0] = (v[0] + v[1]) + (v[2] + v[3]);
+    float* dst = pool_sum ? k.yp : k.y;
+    const unsigned dld = (unsigned)(pool_sum ? k.yp_ld : k.y_ld);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < nv) {
+        const unsigned pix = pool_sum ? ppix : pix0 + sub[s];
+        const f32x4 xv = ld4(k.arb_x, pix * (unsigned)k.arb_x_ld + (unsigned)n);
+        const f32x4 pre = xv * s4 + t4;
+        f32x4 g = v[s];
+        if (!k.arb_nomask) {
+          g.x = pre.x > 0.f ? g.x : 0.f; g.y = pre.y > 0.f ? g.y : 0.f;
+          g.z = pre.z > 0.f ? g.z : 0.f; g.w = pre.w > 0.f ? g.w : 0.f;
+        }
+        f32x4 o = g * s4;
+        if (has_skip) {
+          const unsigned ld = (unsigned)k.arb_skip_ld;
+          if (k.arb_skip_ups) {
+            // this output pixel's 2x2 children in the [B,2Ho,2Wo,*] gradient
+            const int Wo = pool_sum ? (k.W >> 1) : k.W, Ho = pool_sum ? (k.H >> 1) : k.H;
+            const int yy = pool_sum ? (oy0 >> 1) : oy0 + (s >> 1);
+            const int xx = pool_sum ? (ox0 >> 1) : ox0 + (s & 1);
+            const unsigned W2 = 2u * (unsigned)Wo;
+            const unsigned cq = ((unsigned)(b * 2 * Ho + 2 * yy)) * W2 + 2u * (unsigned)xx;
+            o += (ld4(k.arb_skip, cq * ld + n) + ld4(k.arb_skip, (cq + 1) * ld + n)) +
+                 (ld4(k.arb_skip, (cq + W2) * ld + n) + ld4(k.arb_skip, (cq + W2 + 1) * ld + n));
+          } else {
+            o += ld4(k.arb_skip, pix * ld + (unsigned)n);
+          }
+        }
+        st4(dst, pix * dld + (unsigned)n, o);
+        S.sgx += g * xv;
+        S.sg += g;
+      }
+    }
+  }
+}
+
+// ARB: per-(block, channel) partial sums of g*x and g.  Lanes with equal (lane % C4) hold the
+// same 4 channels for different quads; NW = 4 waves took part.  `slot` = row of arb_partial
+// ((image * arb_nblk + tile) of the 128-pixel tiling the caller sized the buffer for).
+template <int COLS, int C4>
+__device__ __forceinline__ void epi_arb_reduce(const ConvK& k, EpiSums& S, float* smem, int wave,
+                                               int lane, int tid, size_t slot, int n0) {
+  f32x4 sgx = S.sgx, sg = S.sg;
+#pragma unroll
+  for (int o = C4; o < 64; o <<= 1) {
+    sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
+    sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
+    sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
+    sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+  }
+  __syncthreads();                      // everyone is done reading the tile dumps
+  float* red = smem;                    // [2][4 waves][COLS]
+  if (lane < C4 && wave < 4) {
+    *reinterpret_cast<f32x4*>(red + wave * COLS + lane * 4) = sgx;
+    *reinterpret_cast<f32x4*>(red + (4 + wave) * COLS + lane * 4) = sg;
+  }
+  __syncthreads();
+  if (tid < COLS && n0 + tid < k.n_store) {
+    const float a = (red[tid] + red[COLS + tid]) + (red[2 * COLS + tid] + red[3 * COLS + tid]);
+    const float t = (red[4 * COLS + tid] + red[5 * COLS + tid]) +
+                    (red[6 * COLS + tid] + red[7 * COLS + tid]);
+    const size_t o = slot * k.Cout + n0 + tid;
+    k.arb_partial[o] = a;
+    k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = t;
+  }
+}
+
 }  // namespace p2lconv
 
-// v2 (persistent, LDS double-buffered) 3x3 kernel, defined in p2l_conv2.hip
+// Winograd F(2x2,3x3) form of the bf16x3 3x3 conv (p2l_wino.hip)
+extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);
+extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad);
+int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
+                  float* dst, hipStream_t st);
+int p2l_wino_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

@@ -1,0 +1,345 @@
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution on the bf16 matrix pipe, in the
+// fp32-equivalent 3-way-split arithmetic of P2L_WFMT_BF16X3 (p2l_conv.hip).
+//
+// Same role as conv_mfma_kernel<TAPS=9,BF3> -- nn.Conv2d forward and input-gradient of the
+// BigGAN-deep GenBlock 3x3 convs and the VGG16 features (reached from
+// pix2latent/model/biggan.py:58 and pix2latent/loss_functions.py:142 in the reference) -- with
+// 2.25x fewer matrix-pipe products: a 2x2 output quad needs 16 multiplies per (cin, cout)
+// pair in the transform domain instead of 36.
+//
+//     Y = A^T [ (G g G^T)  (.)  (B^T d B) ] A        d: 4x4 input patch, g: 3x3 kernel
+//
+// Layout of the work (MI355X-first; two blocks of 4 waves per CU):
+//   * block = 8x16 output pixels of one image = 32 quads ("tiles", GEMM M; the same patch and
+//     the same 2x2-quad notion as the direct kernel), 64 output channels (GEMM N), K-chunks
+//     of 16 input channels;
+//   * wave w owns the transform-domain frequencies 4w .. 4w+3 for all 32 tiles and 64 channels:
+//     4 freq x 2 N-tiles accumulators of 32x32 (128 VGPR).  Frequencies never mix before the
+//     output transform, so a weight fragment is needed by exactly one wave: the
+//     pre-transformed, pre-split weights are laid out in MFMA B-fragment order and go
+//     global -> registers (1 KB coalesced per wave-load, one frequency ahead), never
+//     through LDS;
+//   * per chunk the 10x18x16 input patch is staged once in LDS as fp32 (prologue affine /
+//     ReLU applied while staging), then every thread transforms one (tile, 4 channels,
+//     half of the frequencies) -- 16 ds_read_b128, 32 adds -- splits the 8 results into three
+//     bf16 pieces and writes them into the [frequency][tile] operand image (49 KB, the
+//     96-byte swizzled row format of the direct kernel: A-fragment reads are conflict-free);
+//     66 KB of LDS per block: while one block transforms, the CU's other block multiplies;
+//   * 6 v_mfma_f32_32x32x16_bf16 per (frequency, N-tile, chunk), fp32 accumulate;
+//   * epilogue: the accumulators of the 4 waves meet in LDS (2 passes of 32 channels), every
+//     thread inverse-transforms one (tile, 4 channels) and runs the shared epilogue item
+//     (p2l_conv_k.h: bias / residual / activation / mask / pooling / fused activation backward).
+// Numerics: transforms are exact-rounded fp32 additions (entries of B, A are 0, +-1), G g G^T
+// is formed in fp64 at pack time; results match the direct kernel to fp32 rounding
+// (tests/test_kernels_gpu.py runs both against the same tolerance).
+#include "p2l_conv_k.h"
+
+using namespace p2lconv;
+
+namespace {
+
+constexpr int WN_THREADS = 256;
+constexpr int WN_RAW_PITCH = 24;                    // floats per staged pixel (16 channels + pad):
+                                                    // conflict-free ds_read_b128 in the transform
+constexpr int WN_RAW_ROWS = 10 * 18;                // 8x16 outputs + halo
+constexpr int WN_RAW_FLOATS = WN_RAW_ROWS * WN_RAW_PITCH;
+constexpr int WN_V_ROWS = 16 * 32;                  // [frequency][tile], 96 B each
+constexpr int WN_DUMP_PITCH = 32;                   // floats per (frequency, tile) in the epilogue
+constexpr size_t WN_LDS_BYTES = (size_t)(WN_RAW_FLOATS + WN_V_ROWS * 24) * sizeof(float);
+static_assert(16 * 32 * WN_DUMP_PITCH <= WN_RAW_FLOATS + WN_V_ROWS * 24, "epilogue dump fits");
+
+__device__ __forceinline__ void store_split(float* Vs, int row, int v, const f32x4 x) {
+  bf16x4 ph, pm, pl;
+  split3(x, ph, pm, pl);
+  char* rb = reinterpret_cast<char*>(Vs) + row * 96 + (v & 1) * 8;
+  char* rq = rb + bf3_chunk(v >> 1, row) * 16;      // pieces at +0 / +32 / +64 bytes
+  *reinterpret_cast<bf16x4*>(rq) = ph;
+  *reinterpret_cast<bf16x4*>(rq + 32) = pm;
+  *reinterpret_cast<bf16x4*>(rq + 64) = pl;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* raw = smem;
+  float* Vs = smem + WN_RAW_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // ---- which block --------------------------------------------------------------------
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
+  const int tiles_per_image = k.tiles_x * k.tiles_y;
+  const int b = mt / tiles_per_image;
+  const int tile_in_image = mt - b * tiles_per_image;
+  const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
+  const int y0 = by * 8, x0 = bx * 16, n0 = nt * 64;
+
+  // ---- staging descriptors: 180 pixels x 4 channel quads over 256 threads -------------
+  constexpr int A_ITERS = 3;
+  const int sv = tid & 3;                            // channel quad: the same for every item
+  int a_goff[A_ITERS], a_loff[A_ITERS];
+  unsigned a_valid = 0;
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int p = (tid + WN_THREADS * it) >> 2;
+    a_goff[it] = 0;
+    a_loff[it] = (p < WN_RAW_ROWS) ? p * WN_RAW_PITCH + sv * 4 : -1;
+    if (p < WN_RAW_ROWS) {
+      const int hy = p / 18, hx = p - hy * 18;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
+        a_goff[it] = ((b * k.H + iy) * k.W + ix) * k.x_ld + sv * 4;
+        a_valid |= 1u << it;
+      }
+    }
+  }
+  const int s_off = b * k.pro_bstride + sv * 4;
+  f32x4 xr[A_ITERS], sr, tr;
+  auto load_raw = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + c * 16);
+    if (PRO != P2L_PRO_NONE) {
+      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + c * 16);
+      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + c * 16);
+    }
+  };
+  auto write_raw = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      if (a_loff[it] < 0) continue;
+      f32x4 v = xr[it];
+      if (PRO != P2L_PRO_NONE) {
+        v = v * sr + tr;
+        if (PRO == P2L_PRO_AFFINE_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding AFTER the prologue
+      *reinterpret_cast<f32x4*>(raw + a_loff[it]) = v;
+    }
+  };
+
+  // ---- input transform item of this thread: (half h, tile tt, channel quad tv) ----------
+  const int th = tid >> 7, tt = (tid >> 2) & 31, tv = tid & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  // frequency row i of B^T d is one signed sum of two patch rows:
+  //   row 0 = d0 - d2 ,  row 1 = d1 + d2 ,  row 2 = d2 - d1 ,  row 3 = d1 - d3
+  // half h of the block's threads produces rows 2h, 2h+1 (h is wave-uniform)
+  const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
+  auto transform = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int fr = 2 * th + i;
+      const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
+      const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
+      const float sb = (fr == 1) ? 1.f : -1.f;
+      f32x4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c) * WN_RAW_PITCH);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c) * WN_RAW_PITCH);
+        R[c] = a + sb * bq;                            // +-1: exact
+      }
+      const int f = fr * 4;
+      store_split(Vs, (f + 0) * 32 + tt, tv, R[0] - R[2]);
+      store_split(Vs, (f + 1) * 32 + tt, tv, R[1] + R[2]);
+      store_split(Vs, (f + 2) * 32 + tt, tv, R[2] - R[1]);
+      store_split(Vs, (f + 3) * 32 + tt, tv, R[1] - R[3]);
+    }
+  };
+
+  // ---- weight fragments: global -> registers --------------------------------------------
+  // image: [chunk][frequency][32-channel tile of Cout][piece][lane] x 16 B
+  const int n_t32 = k.Cout >> 5;
+  const f32x4* wq = reinterpret_cast<const f32x4*>(k.w);
+  f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
+  auto load_b = [&](int c, int fi, int set) {
+    const size_t base = (((size_t)c * 16 + (4 * wave + fi)) * n_t32 + (n0 >> 5)) * 3 * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bw[set][j][p] = wq[base + (size_t)(j * 3 + p) * 64];
+  };
+
+  f32x16 acc[4][2];                                    // [freq][N-tile]
+#pragma unroll
+  for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fi][j][r] = 0.f;
+
+  const int nchunks = k.nchunks;
+  // weight fragments are fetched ONE frequency ahead into two alternating register sets
+  // (48 VGPR); only the set of frequency 0 is live across the staging / transform phases
+  load_raw(0);
+  load_b(0, 0, 0);
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    write_raw();
+    __syncthreads();
+    if (more) load_raw(c + 1);
+    transform();
+    __syncthreads();
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+      if (fi + 1 < 4) load_b(c, fi + 1, (fi + 1) & 1);
+      else if (more) load_b(c + 1, 0, 0);
+      const int row = (4 * wave + fi) * 32 + l31;
+      const float* aq = Vs + row * 24 + bf3_chunk(lhi, row) * 4;
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 8);
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(aq + 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][0]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][1]);
+        const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][2]);
+        f32x16 t = acc[fi][j];                         // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
+        acc[fi][j] = t;
+      }
+    }
+    // the next write_raw() touches only `raw` (free since the transform barrier); the barrier
+    // after it orders every wave's MFMA reads of Vs before the next transform's writes
+  }
+  __syncthreads();
+
+  // ---- epilogue: 2 passes of 32 output channels --------------------------------------------
+  // dump[f][tile][32 channels] <- C layout: lane = channel column, register r = tile row
+  // (r&3) + 8*(r>>2) + 4*lhi.  Writes are lane-contiguous, item reads 128 B per tile contiguous.
+  float* dump = smem;
+  EpiSums S;
+  const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
+  const int ety = e_t >> 3, etx = e_t & 7;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {           // (compile-time: the accumulators must stay in registers)
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tile = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        dump[((4 * wave + fi) * 32 + tile) * WN_DUMP_PITCH + l31] = acc[fi][j][r];
+      }
+    __syncthreads();
+    const int nb = n0 + j * 32;
+    if (nb + e_c4 * 4 < k.n_store) {
+      f32x4 T[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {                  // A^T M, column jj
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        T[0][jj] = (m0 + m1) + m2;
+        T[1][jj] = (m1 - m2) - m3;
+      }
+      f32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                     // (A^T M) A
+        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
+        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
+      }
+      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
+    }
+    if (k.arb_x != nullptr) {
+      // the block IS tile (by, bx) of the 128-pixel tiling the caller's partial sums use
+      epi_arb_reduce<32, 8>(k, S, smem, wave, lane, tid,
+                            (size_t)b * k.arb_nblk + tile_in_image, nb);
+      S = EpiSums();
+    }
+    __syncthreads();                                   // dump is rewritten by the next pass
+  }
+}
+
+// ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
+__global__ void wino_pack_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
+                                 int transpose_flip) {
+  // one thread per (chunk cc, frequency f, 32-channel tile jn, lane): 8 input channels of one
+  // output channel -> three 16-byte pieces
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n_t32 = N_pad >> 5;
+  const size_t total = (size_t)(K_pad >> 4) * 16 * n_t32 * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  size_t q = idx >> 6;
+  const int jn = (int)(q % n_t32); q /= n_t32;
+  const int f = (int)(q & 15);
+  const int cc = (int)(q >> 4);
+  const int n = jn * 32 + (lane & 31);
+  const int fi = f >> 2, fj = f & 3;
+  const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  bf16x8 p1, p2, p3;
+  for (int e = 0; e < 8; ++e) {
+    const int kk = cc * 16 + (lane >> 5) * 8 + e;
+    double u = 0.0;
+    if (n < N && kk < K) {
+      for (int a = 0; a < 3; ++a)
+        for (int bb = 0; bb < 3; ++bb) {
+          // conv weight [n][kk][a][bb]; input-gradient form: w[kk][n] mirrored
+          const float g = transpose_flip ? w[(((size_t)kk * I + n) * 3 + (2 - a)) * 3 + (2 - bb)]
+                                         : w[(((size_t)n * I + kk) * 3 + a) * 3 + bb];
+          u += G[fi][a] * (double)g * G[fj][bb];
+        }
+    }
+    const float x = (float)u;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    p1[e] = h; p2[e] = m; p3[e] = (__bf16)r2;
+  }
+  bf16x8* out = reinterpret_cast<bf16x8*>(dst) +
+                ((((size_t)cc * 16 + f) * n_t32 + jn) * 3) * 64 + lane;
+  out[0] = p1; out[64] = p2; out[128] = p3;
+}
+
+}  // namespace
+
+// floats of the Winograd image for an N_pad x K_pad 3x3 conv (16 frequencies x 6 bytes)
+extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad) {
+  return (size_t)N_pad * K_pad * 24;
+}
+
+// shapes the Winograd kernel takes (the launcher adds the per-launch conditions)
+extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad) {
+  return N_pad % 64 == 0 && K_pad % 16 == 0;
+}
+
+int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
+                  float* dst, hipStream_t st) {
+  const size_t total = (size_t)(K_pad >> 4) * 16 * (N_pad >> 5) * 64;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, dst, O,
+                     I, N_pad, K_pad, transpose_flip);
+  return p2l_check_launch();
+}
+
+int p2l_wino_launch(const ConvK& k, int pro, hipStream_t st) {
+  dim3 grid(k.n_mtiles * k.n_ntiles), block(WN_THREADS);
+#define P2L_WN(PRO)                                                                          \
+  do {                                                                                       \
+    static bool attr_set = false;                                                            \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)wino_conv_kernel<PRO>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(wino_conv_kernel<PRO>, grid, block, WN_LDS_BYTES, st, k);             \
+  } while (0)
+  if (pro == P2L_PRO_NONE) P2L_WN(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_WN(P2L_PRO_AFFINE_RELU);
+  else P2L_WN(P2L_PRO_AFFINE);
+#undef P2L_WN
+  return p2l_check_launch();
+}

@@ -129,17 +129,8 @@ class _VggLpipsParams(object):
         return t.data_ptr()
 
     def _pack(self, w, taps, n_pad, k_pad, flip):
-        O, I = w.shape[0], w.shape[1]
-        src = w.detach().to(self.dev, torch.float32).contiguous()
-        if taps == 9 and getattr(self, 'wfmt', N.WFMT_F32) == N.WFMT_BF16X3:
-            dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=self.dev, dtype=torch.float32)
-            N.check(self.lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad,
-                                                      int(flip), N.ptr(dst), N.stream()),
-                    'p2l_pack_conv_weight_bf3')
-        else:
-            dst = torch.empty(taps * n_pad * k_pad, device=self.dev, dtype=torch.float32)
-            N.check(self.lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                                  N.ptr(dst), N.stream()), 'p2l_pack_conv_weight')
+        dst = N.pack_conv_weight(w.detach().to(self.dev, torch.float32), taps, n_pad, k_pad, flip,
+                                 getattr(self, 'wfmt', N.WFMT_F32) if taps == 9 else N.WFMT_F32)
         torch.cuda.current_stream().synchronize()
         self.keep.append(dst)
         return dst.data_ptr()

@@ -134,35 +134,15 @@ class BigGAN(nn.Module):
         return t
 
     def _pack_conv(self, w, taps, n_pad, k_pad, flip):
-        O, I = w.shape[0], w.shape[1]
-        src = w.detach().to(self._dev, torch.float32).contiguous()
-        if taps == 9 and self._wfmt == N.WFMT_BF16X3:
-            dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=self._dev, dtype=torch.float32)
-            N.check(self._lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad,
-                                                       int(flip), N.ptr(dst), N.stream()),
-                    'p2l_pack_conv_weight_bf3')
-        else:
-            dst = torch.empty(taps * n_pad * k_pad, device=self._dev, dtype=torch.float32)
-            N.check(self._lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad,
-                                                   int(flip), N.ptr(dst), N.stream()),
-                    'p2l_pack_conv_weight')
+        dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), taps, n_pad, k_pad, flip,
+                                 self._wfmt)
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst
 
     def _pack_subpix(self, w, n_pad, k_pad, flip):
-        O, I = w.shape[0], w.shape[1]
-        src = w.detach().to(self._dev, torch.float32).contiguous()
-        if self._wfmt == N.WFMT_BF16X3:
-            dst = torch.empty(16 * n_pad * k_pad * 3 // 2, device=self._dev, dtype=torch.float32)
-            N.check(self._lib.p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad,
-                                                              int(flip), 0, N.ptr(dst), N.stream()),
-                    'p2l_pack_conv_weight_subpix_bf3')
-        else:
-            dst = torch.empty(16 * n_pad * k_pad, device=self._dev, dtype=torch.float32)
-            N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 0,
-                                                          N.ptr(dst), N.stream()),
-                    'p2l_pack_conv_weight_subpix')
+        dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), 9, n_pad, k_pad, flip,
+                                 self._wfmt, subpix_mode=0)
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst

@@ -141,23 +141,8 @@ class StyleGAN2(nn.Module):
         return t.data_ptr()
 
     def _pack_w(self, w, taps, n_pad, k_pad, flip, subpix=False):
-        O, I = w.shape[0], w.shape[1]
-        src = w.detach().to(self._dev, torch.float32).contiguous()
-        n = (16 if subpix else taps) * n_pad * k_pad
-        bf3 = taps == 9 and self._wfmt == N.WFMT_BF16X3
-        dst = torch.empty(n * 3 // 2 if bf3 else n, device=self._dev, dtype=torch.float32)
-        if subpix and bf3:
-            N.check(self._lib.p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad, int(flip),
-                                                              1, N.ptr(dst), N.stream()), 'pack_subpix_bf3')
-        elif bf3:
-            N.check(self._lib.p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                                       N.ptr(dst), N.stream()), 'pack_conv_bf3')
-        elif subpix:
-            N.check(self._lib.p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), 1,
-                                                          N.ptr(dst), N.stream()), 'pack_subpix')
-        else:
-            N.check(self._lib.p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                                   N.ptr(dst), N.stream()), 'pack_conv')
+        dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), taps, n_pad, k_pad, flip,
+                                 self._wfmt, subpix_mode=1 if subpix else None)
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst.data_ptr()

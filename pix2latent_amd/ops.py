@@ -23,32 +23,11 @@ def mfma_probe(A, B):
 
 
 def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False, wfmt=N.WFMT_F32):
-    O, I = w_oihw.shape[0], w_oihw.shape[1]
-    src = w_oihw.contiguous().float()
-    if wfmt == N.WFMT_BF16X3:
-        dst = torch.empty(taps * n_pad * k_pad * 3 // 2, device=src.device)
-        N.check(_lib().p2l_pack_conv_weight_bf3(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                                N.ptr(dst), N.stream()), 'pack_conv_weight_bf3')
-        return dst
-    dst = torch.empty(taps * n_pad * k_pad, device=src.device)
-    N.check(_lib().p2l_pack_conv_weight(N.ptr(src), O, I, taps, n_pad, k_pad, int(flip),
-                                        N.ptr(dst), N.stream()), 'pack_conv_weight')
-    return dst
+    return N.pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip, wfmt)
 
 
 def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0, wfmt=N.WFMT_F32):
-    O, I = w_oihw.shape[0], w_oihw.shape[1]
-    src = w_oihw.contiguous().float()
-    if wfmt == N.WFMT_BF16X3:
-        dst = torch.empty(16 * n_pad * k_pad * 3 // 2, device=src.device)
-        N.check(_lib().p2l_pack_conv_weight_subpix_bf3(N.ptr(src), O, I, n_pad, k_pad, int(flip),
-                                                       mode, N.ptr(dst), N.stream()),
-                'pack_subpix_bf3')
-        return dst
-    dst = torch.empty(16 * n_pad * k_pad, device=src.device)
-    N.check(_lib().p2l_pack_conv_weight_subpix(N.ptr(src), O, I, n_pad, k_pad, int(flip), mode,
-                                               N.ptr(dst), N.stream()), 'pack_subpix')
-    return dst
+    return N.pack_conv_weight(w_oihw, 9, n_pad, k_pad, flip, wfmt, subpix_mode=mode)
 
 
 def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,

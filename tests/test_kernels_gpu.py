@@ -56,13 +56,31 @@ CONV_CASES = [
     dict(B=2, H=32, Cin=16, Cout=64, taps=9, pro='affine', act='relu', bias=True),   # VGG conv0 form
     dict(B=2, H=32, Cin=64, Cout=32, taps=9, act='tanh', n_store=16, bias=True),     # rgb form
     dict(B=1, H=64, Cin=64, Cout=64, taps=9, splitk=2, bias=True),
+    # shapes the Winograd form takes (H % 16 == 0, Cout % 64 == 0) with every epilogue family
+    dict(B=2, H=32, Cin=32, Cout=128, taps=9, pro='affine_relu', bias=True, act='relu', pool='max'),
+    dict(B=1, H=48, Cin=48, Cout=64, taps=9, res='same', alpha=0.5, bias=True),
+    dict(B=2, H=16, Cin=128, Cout=64, taps=9, mask=True, pro='affine'),
+    dict(B=2, H=32, Cin=16, Cout=64, taps=9, res='ups', bias=True),
 ]
 
 
-WFMTS = [0, 1]        # P2L_WFMT_F32 (exact fp32 MFMA), P2L_WFMT_BF16X3 (3-way bf16 split, 6 products)
+# P2L_WFMT_F32 (exact fp32 MFMA), P2L_WFMT_BF16X3 (3-way bf16 split, 6 products, direct kernel),
+# P2L_WFMT_BF16X3W (same arithmetic; eligible shapes run in the Winograd F(2x2,3x3) form)
+WFMTS = [0, 1, 2]
+WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd']
 
 
-@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
+@pytest.fixture(autouse=True)
+def _force_winograd_for_small_grids(dev):
+    """the default only sends launches with >= 224 blocks to the Winograd kernel; the test
+    shapes are small, so force it for every eligible shape and restore the default after"""
+    from pix2latent_amd import _native as N
+    N.check(N.lib().p2l_set_wino_mode(2))
+    yield
+    N.check(N.lib().p2l_set_wino_mode(1))
+
+
+@pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: '-'.join('%s%s' % (k, v) for k, v in c.items()))
 def test_conv_fwd(dev, O, case, wfmt):
     """both weight formats must meet the SAME tolerance: bf16x3 is an fp32-equivalent
@@ -137,7 +155,7 @@ def test_conv_fwd(dev, O, case, wfmt):
         assert relerr(got, exp) < tol, 'pooled'
 
 
-@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 96)])
 def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
     """3x3 conv on a nearest-x2 upsampled input in sub-pixel form (ups=2) and its
@@ -165,7 +183,7 @@ def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
     assert relerr(nchw(da), a.grad) < 2e-5
 
 
-@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
     g = torch.Generator().manual_seed(14)
     B, C, Co, h = 2, 64, 64, 16
@@ -207,7 +225,7 @@ def test_conv_dgrad_matches_autograd(dev, O, taps, Cin, Cout, H):
 
 
 @pytest.mark.parametrize('splitk', [1, 4], ids=['epilogue', 'splitk-finish'])
-@pytest.mark.parametrize('wfmt', WFMTS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 @pytest.mark.parametrize('taps,ups,skip', [(9, False, None), (9, True, None), (1, False, 'same'),
                                            (1, False, 'ups')])
 def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk):
