@@ -951,7 +951,7 @@ bool wino_eligible(const P2LConv* d, const ConvK& k) {
   if (d->H % 8 || d->W % 16 || !p2l_wino_weight_ok(d->Cout, d->Cin) || k.splitk > 1) return false;
   if (d->x_ld % 4) return false;
   const int nblk = d->B * (d->H / 8) * (d->W / 16) * (d->Cout / 64);
-  return wino_mode() == 2 || nblk >= 448;
+  return wino_mode() == 2 || nblk >= 256;
 }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last

@@ -4,13 +4,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pix2latent_amd import ops, _native as N
 dev = torch.device('cuda'); B = 18
-WF = int(os.environ.get('PROBE_WFMT', '1'))
-SH = [(256, 64, 64, 9), (128, 128, 128, 9), (64, 256, 256, 9), (32, 512, 512, 9), (256, 64, 128, 1), (64, 256, 512, 1)]
-for H, Cin, Cout, taps in SH:
-    k = 3 if taps == 9 else 1
-    x = torch.randn(B, H, H, Cin, device=dev)
-    wp = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k), taps, Cout, Cin, wfmt=WF if taps == 9 else 0)
-    bias = torch.randn(Cout, device=dev)
-    for _ in range(4):
-        ops.conv(x, wp, B, H, H, Cin, Cout, taps, bias=bias, wfmt=WF if taps == 9 else 0)
+SH = [(256, 64, 64, 9), (64, 256, 256, 9), (32, 512, 512, 9)]
+for WF in (1, 2):
+  for H, Cin, Cout, taps in SH:
+      k = 3 if taps == 9 else 1
+      x = torch.randn(B, H, H, Cin, device=dev)
+      wp = ops.pack_conv_weight(torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k), taps, Cout, Cin, wfmt=WF if taps == 9 else 0)
+      bias = torch.randn(Cout, device=dev)
+      for _ in range(4):
+          ops.conv(x, wp, B, H, H, Cin, Cout, taps, bias=bias, wfmt=WF if taps == 9 else 0)
 torch.cuda.synchronize()
