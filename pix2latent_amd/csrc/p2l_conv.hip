@@ -950,8 +950,12 @@ bool wino_eligible(const P2LConv* d, const ConvK& k) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || wino_mode() == 0) return false;
   if (d->H % 8 || d->W % 16 || !p2l_wino_weight_ok(d->Cout, d->Cin) || k.splitk > 1) return false;
   if (d->x_ld % 4) return false;
+  // measured per layer inside the bench step (profiles/round2_wino_layers.txt): 1.05-1.29x over
+  // the direct kernel, except when the grid is just over one round of the chip's 512 block
+  // slots (576 blocks: 0.92-0.95x - the kernel's longer prologue / epilogue is paid twice for
+  // a second round that is 12 % full)
   const int nblk = d->B * (d->H / 8) * (d->W / 16) * (d->Cout / 64);
-  return wino_mode() == 2 || nblk >= 256;
+  return wino_mode() == 2 || (nblk >= 256 && (nblk <= 512 || nblk >= 896));
 }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last

@@ -35,7 +35,6 @@
 #include "p2l_conv_k.h"
 
 #include <cstdlib>
-#include <type_traits>
 
 using namespace p2lconv;
 
@@ -179,13 +178,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
       for (int r = 0; r < 16; ++r) acc[fi][j][r] = 0.f;
 
   const int nchunks = k.nchunks;
-  // Two blocks share a CU.  Left alone they run in lockstep -- both transforming, then both
-  // multiplying -- and the phases add up instead of overlapping (measured: transform-only
-  // 0.162 ms + MFMA-only 0.170 ms = the 0.356 ms of the full kernel).  Blocks of the second
-  // dispatch round (the 2nd resident block of every CU) start half a chunk period late.
-  if (k.abl & 16) {
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(40);
-  }
   // weight fragments are fetched ONE frequency ahead into two alternating register sets
   // (48 VGPR); only the set of frequency 0 is live across the staging / transform phases
   load_raw(0);
@@ -274,247 +266,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined form: ONE block of 4 waves per CU, one wave per SIMD with the whole
-// 512-register budget.  The two-blocks-per-CU kernel above does not overlap its phases
-// (measured: transform-only 0.162 ms + multiply-only 0.170 ms = 0.356 ms full, 64^2 256->256,
-// B = 18; co-resident blocks run in lockstep and staggering them changes nothing), so here
-// every wave does both jobs at once: while the matrix pipe works through the 8 (frequency,
-// N-tile) units of chunk c -- 6 MFMAs = 192 pipe cycles each -- the wave's VALU / LDS slots in
-// between carry 1/8 of ITS share of the input transform of chunk c+1 (one transformed value:
-// 4 adds, the 3-way bf16 split, 3 ds_write_b64), the weight fragments of the same unit of
-// chunk c+1 (a whole chunk of look-ahead, 96 VGPR) and the staging of chunks c+2 / c+3.
-// Operand image and staged patch are double-buffered in LDS (98 + 35 KB): one barrier per chunk.
-// ---------------------------------------------------------------------------------------------
-constexpr int WP_RAW_FLOATS = WN_RAW_FLOATS;                      // one patch buffer
-constexpr int WP_V_FLOATS = WN_V_ROWS * 24;                       // one operand image
-constexpr size_t WP_LDS_BYTES = (size_t)(2 * WP_RAW_FLOATS + 2 * WP_V_FLOATS) * sizeof(float);
-
-template <int PRO>
-__global__ __launch_bounds__(WN_THREADS, 1) void wino_conv_kernel_p(const ConvK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw0 = smem;                                  // raw[2], V[2]
-  float* V0 = smem + 2 * WP_RAW_FLOATS;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
-  const int tiles_per_image = k.tiles_x * k.tiles_y;
-  const int b = mt / tiles_per_image;
-  const int tile_in_image = mt - b * tiles_per_image;
-  const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
-  const int y0 = by * 8, x0 = bx * 16, n0 = nt * 64;
-
-  constexpr int A_ITERS = 3;
-  const int sv = tid & 3;
-  int a_goff[A_ITERS], a_loff[A_ITERS];
-  unsigned a_valid = 0;
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
-    const int p = (tid + WN_THREADS * it) >> 2;
-    a_goff[it] = 0;
-    a_loff[it] = (p < WN_RAW_ROWS) ? p * WN_RAW_PITCH + sv * 4 : -1;
-    if (p < WN_RAW_ROWS) {
-      const int hy = p / 18, hx = p - hy * 18;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
-        a_goff[it] = ((b * k.H + iy) * k.W + ix) * k.x_ld + sv * 4;
-        a_valid |= 1u << it;
-      }
-    }
-  }
-  const int s_off = b * k.pro_bstride + sv * 4;
-  f32x4 xr[A_ITERS], sr, tr;
-  auto load_raw = [&](int c) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
-      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + c * 16);
-    if (PRO != P2L_PRO_NONE) {
-      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + c * 16);
-      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + c * 16);
-    }
-  };
-  auto write_raw = [&](float* raw) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      if (a_loff[it] < 0) continue;
-      f32x4 v = xr[it];
-      if (PRO != P2L_PRO_NONE) {
-        v = v * sr + tr;
-        if (PRO == P2L_PRO_AFFINE_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-      }
-      if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(raw + a_loff[it]) = v;
-    }
-  };
-
-  // transform item of this thread: (half th, tile tt, channel quad tv); slice s = 0..7 of it
-  // produces frequency (2*th + (s>>2))*4 + (s&3)
-  const int th = tid >> 7, tt = (tid >> 2) & 31, tv = tid & 3;
-  const int t_off = (2 * (tt >> 3) * 18 + 2 * (tt & 7)) * WN_RAW_PITCH + tv * 4;
-  f32x4 R[4];
-  auto transform_rows = [&](const float* raw, int i) {       // R = signed sum of two patch rows
-    const int fr = 2 * th + i;
-    const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
-    const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
-    const float sb = (fr == 1) ? 1.f : -1.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(raw + t_off + (ra * 18 + c) * WN_RAW_PITCH);
-      const f32x4 bq = *reinterpret_cast<const f32x4*>(raw + t_off + (rb * 18 + c) * WN_RAW_PITCH);
-      R[c] = a + sb * bq;
-    }
-  };
-  auto transform_out = [&](float* Vs, int s) {
-    const int col = s & 3;
-    const int f = (2 * th + (s >> 2)) * 4 + col;
-    const f32x4 v = (col == 0) ? R[0] - R[2] : (col == 1) ? R[1] + R[2]
-                  : (col == 2) ? R[2] - R[1] : R[1] - R[3];
-    store_split(Vs, f * 32 + tt, tv, v);
-  };
-
-  const int n_t32 = k.Cout >> 5;
-  const f32x4* wq = reinterpret_cast<const f32x4*>(k.w);
-  f32x4 bw[8][3];                                      // [unit = freq*2 + N-tile][piece]
-  auto load_b = [&](int c, int u) {
-    const size_t base = ((((size_t)c * 16 + (4 * wave + (u >> 1))) * n_t32 + (n0 >> 5) + (u & 1)) * 3) * 64 + lane;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) bw[u][p] = wq[base + (size_t)p * 64];
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[fi][j][r] = 0.f;
-
-  const int nchunks = k.nchunks;
-  // ---- prologue: chunk 0 transformed, chunk 1 staged, chunk 2 in flight, weights of chunk 0
-  load_raw(0);
-#pragma unroll
-  for (int u = 0; u < 8; ++u) load_b(0, u);
-  write_raw(raw0);
-  if (nchunks > 1) load_raw(1);
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if ((s & 3) == 0) transform_rows(raw0, s >> 2);
-    transform_out(V0, s);
-  }
-  if (nchunks > 1) write_raw(raw0 + WP_RAW_FLOATS);
-  if (nchunks > 2) load_raw(2);
-  __syncthreads();
-
-  // (the slice must not sit behind a branch: a conditional block cannot be interleaved with
-  // the MFMAs, so the last chunk - which has no successor to prepare - is a separate copy)
-  auto chunk_body = [&](int c, auto next_c) {
-    constexpr bool next = decltype(next_c)::value;
-    const float* Vc = V0 + (c & 1) * WP_V_FLOATS;
-    float* Vn = V0 + ((c + 1) & 1) * WP_V_FLOATS;
-    const float* rawn = raw0 + ((c + 1) & 1) * WP_RAW_FLOATS;    // chunk c+1 (staged last round)
-    if (c + 2 < nchunks) write_raw(raw0 + (c & 1) * WP_RAW_FLOATS);   // chunk c+2
-    if (c + 3 < nchunks) load_raw(c + 3);
-    bf16x8 af[2][3];
-    auto lda = [&](int fi, bf16x8 (&a)[3]) {
-      const int row = (4 * wave + fi) * 32 + l31;
-      const float* aq = Vc + row * 24 + bf3_chunk(lhi, row) * 4;
-      a[0] = *reinterpret_cast<const bf16x8*>(aq);
-      a[1] = *reinterpret_cast<const bf16x8*>(aq + 8);
-      a[2] = *reinterpret_cast<const bf16x8*>(aq + 16);
-    };
-    lda(0, af[0]);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int fi = u >> 1, j = u & 1;
-      if (j == 0 && fi + 1 < 4) lda(fi + 1, af[(fi + 1) & 1]);
-      const bf16x8 (&a)[3] = af[fi & 1];
-      const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[u][0]);
-      const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[u][1]);
-      const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[u][2]);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 t = acc[fi][j];
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b1, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b3, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b2, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b2, t, 0, 0, 0);
-      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b1, t, 0, 0, 0);
-      acc[fi][j] = t;
-      // this unit's slice of the NEXT chunk; the wave issues in order, so the slice has to sit
-      // BETWEEN the MFMAs in program order to run in their shadow (32 pipe cycles each):
-      // the sched_group_barrier sequence below asks for MFMA, ~7 VALU, 1 LDS op, 1 load, ...
-      if (next) {
-        load_b(c + 1, u);
-        if ((u & 3) == 0) transform_rows(rawn, u >> 2);
-        transform_out(Vn, u);
-      }
-#pragma unroll
-      for (int m = 0; m < 6; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // a weight-fragment load
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // LDS reads (A fragments / patch rows)
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // VALU of the transform slice
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // an operand-image write
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-  };
-  for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::true_type{});
-  chunk_body(nchunks - 1, std::false_type{});
-
-  // ---- epilogue (same as above) ---------------------------------------------------------
-  float* dump = smem;
-  EpiSums S;
-  const int e_t = tid >> 3, e_c4 = tid & 7;
-  const int ety = e_t >> 3, etx = e_t & 7;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tile = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        dump[((4 * wave + fi) * 32 + tile) * WN_DUMP_PITCH + l31] = acc[fi][j][r];
-      }
-    __syncthreads();
-    const int nb = n0 + j * 32;
-    if (nb + e_c4 * 4 < k.n_store) {
-      f32x4 T[2][4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 32 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        T[0][jj] = (m0 + m1) + m2;
-        T[1][jj] = (m1 - m2) - m3;
-      }
-      f32x4 v[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
-        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
-      }
-      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
-    }
-    if (k.arb_x != nullptr) {
-      epi_arb_reduce<32, 8>(k, S, smem, wave, lane, tid,
-                            (size_t)b * k.arb_nblk + tile_in_image, nb);
-      S = EpiSums();
-    }
-    __syncthreads();
-  }
-}
-
 // ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
 __global__ void wino_pack_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
                                  int transpose_flip) {
@@ -578,29 +329,11 @@ int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int t
   return p2l_check_launch();
 }
 
+// (bn = 64 or 128 output channels per block: the launcher passes n_ntiles = Cout / bn)
 int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   ConvK k = k_in;
   { const char* e = getenv("P2L_ABL"); k.abl = e ? atoi(e) : 0; }
   dim3 grid(k.n_mtiles * k.n_ntiles), block(WN_THREADS);
-  static int variant = -1;      // $P2L_WINO_VARIANT: 0 = two blocks per CU, 1 = software-pipelined
-  if (variant < 0) { const char* e = getenv("P2L_WINO_VARIANT"); variant = e ? atoi(e) : 1; }
-#define P2L_WNP(PRO)                                                                         \
-  do {                                                                                       \
-    static bool attr_set = false;                                                            \
-    if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)wino_conv_kernel_p<PRO>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      attr_set = true;                                                                       \
-    }                                                                                        \
-    hipLaunchKernelGGL(wino_conv_kernel_p<PRO>, grid, block, WP_LDS_BYTES, st, k);           \
-  } while (0)
-  if (variant == 1) {
-    if (pro == P2L_PRO_NONE) P2L_WNP(P2L_PRO_NONE);
-    else if (pro == P2L_PRO_AFFINE_RELU) P2L_WNP(P2L_PRO_AFFINE_RELU);
-    else P2L_WNP(P2L_PRO_AFFINE);
-    return p2l_check_launch();
-  }
-#undef P2L_WNP
 #define P2L_WN(PRO)                                                                          \
   do {                                                                                       \
     static bool attr_set = false;                                                            \
