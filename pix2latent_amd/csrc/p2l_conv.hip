@@ -933,9 +933,16 @@ int halo_pitch(int TW, bool bf3) {
   return TW == 16 ? 24 : (TW == 8 ? 12 : TW + 2);
 }
 
-// Winograd form: weights carry the transform-domain image (P2L_WFMT_BF16X3W), plain 3x3
-// (no upsample fusion, no split-K request), whole 8x16 blocks, and enough blocks to give
-// every CU two ($P2L_WINO=0 switches it off, =2 forces it for any grid size: tests)
+// Winograd form (p2l_wino.hip).  Which launches take it is a function of the LAYER SHAPE only,
+// never of the batch: a candidate's result must not depend on how many others share its chunk
+// (tests/test_fullsize_gpu.py), so the same layer runs the same kernel for every B - and for
+// these shapes split-K is never suggested or honoured.  Conditions: weights carry the
+// transform-domain image (P2L_WFMT_BF16X3W), plain stride-1 3x3 (no upsample fusion), whole
+// 8x16-pixel x 64-channel blocks, and at least 64 such blocks PER IMAGE: measured per layer
+// inside the bench step (profiles/round2_layers_*.txt) the Winograd kernel is 1.05-1.29x the
+// direct one on those, and 0.92-1.10x on the 16^2 / 32^2 layers with fewer blocks (its longer
+// prologue / epilogue against rounds of the chip that are mostly empty).
+// $P2L_WINO=0 switches it off; mode 2 (p2l_set_wino_mode, tests) takes every eligible shape.
 static int g_wino_mode = -1;
 static int wino_mode() {
   if (g_wino_mode < 0) { const char* e = getenv("P2L_WINO"); g_wino_mode = e ? atoi(e) : 1; }
@@ -946,16 +953,11 @@ extern "C" int p2l_set_wino_mode(int mode) {
   g_wino_mode = mode;
   return P2L_OK;
 }
-bool wino_eligible(const P2LConv* d, const ConvK& k) {
+static bool wino_shape(const P2LConv* d) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || wino_mode() == 0) return false;
-  if (d->H % 8 || d->W % 16 || !p2l_wino_weight_ok(d->Cout, d->Cin) || k.splitk > 1) return false;
-  if (d->x_ld % 4) return false;
-  // measured per layer inside the bench step (profiles/round2_wino_layers.txt): 1.05-1.29x over
-  // the direct kernel, except when the grid is just over one round of the chip's 512 block
-  // slots (576 blocks: 0.92-0.95x - the kernel's longer prologue / epilogue is paid twice for
-  // a second round that is 12 % full)
-  const int nblk = d->B * (d->H / 8) * (d->W / 16) * (d->Cout / 64);
-  return wino_mode() == 2 || (nblk >= 256 && (nblk <= 512 || nblk >= 896));
+  if (d->H % 8 || d->W % 16 || d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin)) return false;
+  const int per_image = (d->H / 8) * (d->W / 16) * (d->Cout / 64);
+  return wino_mode() == 2 || per_image >= 64;
 }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
@@ -1013,7 +1015,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (d->ups >= 2) return 1;             // sub-pixel modes never split K
-  if (choose_tile(d, k) != P2L_OK) return 1;
+  if (choose_tile(d, k) != P2L_OK || wino_shape(d)) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nblk = k.n_mtiles * (d->Cout / bn);
@@ -1035,7 +1037,7 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
 static int effective_splitk(const P2LConv* d) {
-  if (d->splitk <= 1 || d->ups >= 2) return 1;
+  if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d)) return 1;
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nchunks = d->Cin / kc;
   int sk = d->splitk > nchunks ? nchunks : d->splitk;
@@ -1108,7 +1110,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
-  k.splitk = d->splitk < 1 ? 1 : d->splitk;
+  k.splitk = (d->splitk < 1 || wino_shape(d)) ? 1 : d->splitk;
   if (k.splitk > k.nchunks) k.splitk = k.nchunks;
   k.chunks_per_split = cdiv(k.nchunks, k.splitk);
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
@@ -1150,7 +1152,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   // ---- Winograd F(2x2,3x3) form (p2l_wino.hip): stride-1 3x3 layers whose grid fills the
   //      chip with 8x16-pixel x 64-channel blocks; everything else stays on the direct kernel
-  if (wino_eligible(d, k)) {
+  if (wino_shape(d)) {
     ConvK kw = k;                    // (arb_nblk keeps the 128-pixel tiling of the caller's buffer)
     kw.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
     kw.tiles_x = d->W / 16; kw.tiles_y = d->H / 8;

@@ -211,8 +211,9 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
     d.ups = 3 if subpix else 0
     d.y_ld = d.yp_ld = d.n_store = Cout
     d.splitk = splitk
+    if splitk > 1 and not _lib().p2l_conv_arb_split_fusable(C.byref(d)):
+        splitk = d.splitk = 1        # (shapes that run in the Winograd form never split K)
     if splitk > 1:
-        assert _lib().p2l_conv_arb_split_fusable(C.byref(d)) == 1
         nblk = _lib().p2l_conv_arb_nblk_ws(C.byref(d))
     else:
         assert _lib().p2l_conv_arb_fusable(C.byref(d)) == 1

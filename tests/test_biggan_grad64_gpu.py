@@ -101,7 +101,13 @@ def test_per_layer_cbn_gradients(runs):
             floor = rel(o32['cbn'][p][k], o64['cbn'][p][k])
             got = rel(hip['cbn'][p][k], o64['cbn'][p][k])
             report.append((p, name, got, floor))
-    bad = [r for r in report if not r[2] < FLOOR_X * r[3] + SLACK]
-    worst = max(report, key=lambda r: r[2] / (r[3] + 1e-12))
+    # the fp32 noise of one layer's gradient is a handful of discrete events (which ReLU /
+    # max-pool masks flip), so a layer's own fp32-oracle distance fluctuates around the typical
+    # level: judge every layer against the larger of its own floor and the median one.  (A wrong
+    # gradient path is not a factor-3 effect: it shows up as a relative error of order one.)
+    typical = float(np.median([r[3] for r in report]))
+    bad = [r for r in report if not r[2] < FLOOR_X * max(r[3], typical) + SLACK]
+    worst = max(report, key=lambda r: r[2] / (max(r[3], typical) + 1e-12))
+    print('typical fp32-oracle distance %.3g' % typical)
     print('worst layer: %s %s native %.3g oracle-fp32 %.3g' % worst)
     assert not bad, 'first failing (from the output side): %s %s native %.3g vs floor %.3g' % bad[0]
