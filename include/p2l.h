@@ -208,8 +208,17 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     then run stride-1 3x3 layers whose grid is whole 16x16-pixel x 64-channel blocks in the
  *     Winograd form (2.25x fewer matrix products, csrc/p2l_wino.hip) and everything else on the
  *     direct kernel.  Results agree with P2L_WFMT_BF16X3 to fp32 rounding.
- *     p2l_packed_weight_floats() gives the buffer size of any format. */
-enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2 };
+ *     p2l_packed_weight_floats() gives the buffer size of any format.
+ *   P2L_WFMT_PW (1x1 convs only): the fp32 layout of p2l_pack_conv_weight FOLLOWED by the
+ *     bf16x3 image [K_pad/16][N_pad/32][32 rows][96 B] (p2l_pack_conv_weight_pw).  Layers of at
+ *     least 32x32 pixels with Cin, Cout multiples of 64 then run in the bf16x3 arithmetic
+ *     (csrc/p2l_pw.hip), the rest on the exact-fp32 kernel.
+ *   Model structs (P2LBigGAN.wfmt ...) hold the 3x3 format in bits 0-3 and P2L_WFMT_FLAG_PW when
+ *   their 1x1 weight buffers are P2L_WFMT_PW buffers. */
+enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2, P2L_WFMT_PW = 3,
+       P2L_WFMT_FLAG_PW = 0x10 };
+int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                            int transpose_flip, float* w_packed, void* stream);
 size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt);
 /* which P2L_WFMT_BF16X3W launches take the Winograd form: 0 = none, 1 = those whose grid gives
  * every CU a block (default; $P2L_WINO overrides the default), 2 = every eligible shape
@@ -385,6 +394,13 @@ int p2l_reduce_rows(const float* partial, float* out, int Bn, int n, float scale
 int p2l_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, int step_count,
                   void* stream);
+/* same update with the step numbers kept on the device: uses step_counters[0] + 1 as the step
+ * of all n elements, then advances step_counters[0 .. n_counters) by one (one counter per
+ * sample of the chunk).  No launch argument changes between steps: the inner step can be
+ * captured in a HIP graph and replayed. */
+int p2l_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                      float lr, float beta1, float beta2, float eps,
+                      int32_t* step_counters, int n_counters, void* stream);
 int p2l_clamp(float* p, int64_t n, float lo, float hi, void* stream);
 
 /* out[b] = a[b] * scale / (div ? div[b] : 1) */

@@ -117,7 +117,8 @@ class P2LLossCache(C.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
-WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W = 0, 1, 2
+WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW = 0, 1, 2, 3
+WFMT_FLAG_PW = 0x10
 
 
 def default_wfmt():
@@ -135,12 +136,24 @@ def default_wfmt():
     raise ValueError('P2L_CONV_WFMT=%r (expected f32, bf16x3 or bf16x3-direct)' % v)
 
 
+def default_pw():
+    """1x1 convs in the same fp32-equivalent bf16x3 arithmetic (csrc/p2l_pw.hip) unless
+    P2L_PW=0 or the 3x3 convs were asked to run on the exact-fp32 MFMA"""
+    return os.environ.get('P2L_PW', '1') != '0' and default_wfmt() != WFMT_F32
+
+
 def pack_conv_weight(src, taps, n_pad, k_pad, flip, wfmt, subpix_mode=None):
     """[O,I,kh,kw] fp32 device tensor -> packed weight buffer of format `wfmt` (1x1 convs are
     always fp32; subpix_mode 0 / 1 = the 16 phase-tap matrices of the sub-pixel forms)"""
     L = lib()
     O, I = src.shape[0], src.shape[1]
     src = src.detach().float().contiguous()
+    if taps == 1 and wfmt == WFMT_PW:
+        dst = torch.empty(L.p2l_packed_weight_floats(1, n_pad, k_pad, WFMT_PW), device=src.device,
+                          dtype=torch.float32)
+        check(L.p2l_pack_conv_weight_pw(ptr(src), O, I, n_pad, k_pad, int(flip), ptr(dst), stream()),
+              'p2l_pack_conv_weight_pw')
+        return dst
     if taps != 9:
         wfmt = WFMT_F32
     if subpix_mode is not None:
@@ -166,6 +179,7 @@ EXPORTS = [
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
     'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode',
+    'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',

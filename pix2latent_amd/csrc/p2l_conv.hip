@@ -65,54 +65,6 @@ struct ConvProf {
   int seq = 0, period = 1, phase = 0;       // sampling (p2l_prof_step)
 } g_prof;
 
-// Vectorised epilogue.  The MFMA C layout gives a lane one channel of 16 pixels:
-// storing that directly is 4-byte accesses, 128 B per pixel and instruction.  Instead
-// every wave dumps its 32 x (NT*32) accumulator tile into LDS (free after the K loop)
-// and re-reads it so that a lane owns ONE 2x2 pixel quad x FOUR consecutive channels:
-// all global accesses are 16 B per lane and NT*128 B contiguous per pixel, 2x2 pooling
-// stays lane-local, and the per-channel sums of the fused activation backward reduce
-// with 2-3 shuffles.  Handles every epilogue mode of the conv:
-//   v = alpha*acc + bias + residual ; act ; mask ; store ; 2x2 max/sum pool, or
-//   ARB (input-gradient convs): g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ;
-//   partial sums of g*x and g per (tile, channel)  [da 2x2-summed first if pool==SUM].
-template <int NT>
-__device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)[NT],
-                                             float* smem, int wave, int lane, int b0, int y0,
-                                             int x0, int n0, int tile_in_image, int osh,
-                                             int ph_y, int ph_x) {
-  constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  float* tb = smem + wave * 32 * EP;
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[j][r];
-  __syncthreads();
-
-  const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
-  EpiSums S;
-#pragma unroll
-  for (int it0 = 0; it0 < ITEMS; it0 += 64) {
-    const int it = it0 + lane;
-    const int q = it / C4, c4 = it - q * C4;
-    const int n = n0 + c4 * 4;
-    const int Q = wave * 8 + q;
-    const int qx = Q & (TWh - 1), qy = (Q >> (k.tw_log - 1)) & (THh - 1);
-    const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
-    if (b >= k.B || n >= k.n_store) continue;
-    const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
-    f32x4 v[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * EP + c4 * 4) * k.alpha;
-    epi_item(k, v, b, oy0, ox0, n, osh, ph_y, ph_x, S);
-  }
-  if (k.arb_x != nullptr)
-    epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
-                             (size_t)b0 * k.arb_nblk + tile_in_image, n0);
-}
-
 // BF3 = fp32-equivalent arithmetic on the bf16 matrix pipe (16x the fp32 MFMA rate):
 // every fp32 operand is split into three bf16 pieces x = x1 + x2 + x3 (round-to-nearest
 // residuals, |x - (x1+x2+x3)| <= 2^-24 |x|) and a.b is accumulated in fp32 from the six
@@ -960,6 +912,23 @@ static bool wino_shape(const P2LConv* d) {
   return wino_mode() == 2 || per_image >= 64;
 }
 
+// bf16x3 form of the 1x1 conv (p2l_pw.hip): weights carry the pre-split image
+// (P2L_WFMT_PW), whole 128-pixel tiles of one image, 64-channel stages and tiles.  Like the
+// Winograd form a function of the layer shape only; the 4^2 .. 16^2 layers stay on the
+// exact-fp32 kernel (split-K regime).  $P2L_PW=0 switches it off.
+static bool pw_shape(const P2LConv* d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("P2L_PW"); on = e ? atoi(e) : 1; }
+  if (!on || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
+  if (d->Cin % 64 || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16) return false;
+  // measured per layer inside the bench step (profiles/round2_layers_pointwise.txt): 1.1-1.4x
+  // the exact-fp32 kernel from 256 input channels up; with 64 / 128 input channels (one or two
+  // stages, nothing to overlap the split with, HBM-bound anyway) 0.8-0.9x
+  static int min_cin = -1;
+  if (min_cin < 0) { const char* e = getenv("P2L_PW_MIN_CIN"); min_cin = e ? atoi(e) : 256; }
+  return d->H * d->W >= 1024 && d->Cin >= min_cin;
+}
+
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
 // share a CU's matrix pipes, so time ~ ceil(blocks / 256 CUs) * work-per-block.
@@ -1015,7 +984,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (d->ups >= 2) return 1;             // sub-pixel modes never split K
-  if (choose_tile(d, k) != P2L_OK || wino_shape(d)) return 1;
+  if (choose_tile(d, k) != P2L_OK || wino_shape(d) || pw_shape(d)) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nblk = k.n_mtiles * (d->Cout / bn);
@@ -1037,7 +1006,7 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
 static int effective_splitk(const P2LConv* d) {
-  if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d)) return 1;
+  if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d) || pw_shape(d)) return 1;
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nchunks = d->Cin / kc;
   int sk = d->splitk > nchunks ? nchunks : d->splitk;
@@ -1060,9 +1029,10 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (d->pool != P2L_POOL_NONE && !yp) return P2L_EINVAL;
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
-  if (d->wfmt != P2L_WFMT_F32 &&
-      ((d->wfmt != P2L_WFMT_BF16X3 && d->wfmt != P2L_WFMT_BF16X3W) || d->taps != 9))
+  if (d->taps == 9 && d->wfmt != P2L_WFMT_F32 && d->wfmt != P2L_WFMT_BF16X3 &&
+      d->wfmt != P2L_WFMT_BF16X3W)
     return P2L_EUNSUP;
+  if (d->taps == 1 && d->wfmt != P2L_WFMT_F32 && d->wfmt != P2L_WFMT_PW) return P2L_EUNSUP;
   if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
   if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
   if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
@@ -1090,6 +1060,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (rc) return rc;
   k.iH = d->H; k.iW = d->W; k.ibH = d->H; k.ibW = d->W; k.obH = d->H; k.obW = d->W;
   k.hp = halo_pitch(1 << k.tw_log, d->wfmt != P2L_WFMT_F32 && d->taps == 9);
+  const bool bf3_3x3 = d->taps == 9 && d->wfmt != P2L_WFMT_F32;
   if (ex) {
     k.oscale = ex->oscale; k.oscale_bstride = ex->oscale_bstride;
     k.noise = ex->noise; k.noise_w = ex->noise_w;
@@ -1110,7 +1081,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
-  k.splitk = (d->splitk < 1 || wino_shape(d)) ? 1 : d->splitk;
+  k.splitk = (d->splitk < 1 || wino_shape(d) || pw_shape(d)) ? 1 : d->splitk;
   if (k.splitk > k.nchunks) k.splitk = k.nchunks;
   k.chunks_per_split = cdiv(k.nchunks, k.splitk);
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
@@ -1167,6 +1138,17 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
     return rc;
   }
+  // ---- 1x1 conv in the bf16x3 arithmetic (p2l_pw.hip): the image follows the fp32 weights ----
+  if (pw_shape(d)) {
+    ConvK kp = k;
+    kp.w = w + (size_t)d->Cout * d->Cin;
+    kp.n_ntiles = d->Cout / 64;
+    kp.nchunks = d->Cin / 64;
+    kp.splitk = 1;
+    rc = p2l_pw_launch(kp, d->pro, st);
+    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    return rc;
+  }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
   if (d->ups >= 2) {
     if (d->taps != 9 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
@@ -1193,7 +1175,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.ups = 0;
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256) && k.tb_log == 0;
-    const bool bf3 = d->wfmt != P2L_WFMT_F32;
+    const bool bf3 = bf3_3x3;
     const int a_lds_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * k.hp;
     size_t lds_sp = (size_t)(a_lds_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
@@ -1234,7 +1216,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   const int TW = 1 << k.tw_log, TH = 1 << k.th_log, TB = 1 << k.tb_log;
   const int a_rows = (d->taps == 9) ? TB * (TH + 2) * (TW + 2) : 128;
-  const bool bf3 = d->wfmt != P2L_WFMT_F32;
+  const bool bf3 = bf3_3x3;
   const int a_rows_lds = (d->taps == 9) ? TB * (TH + 2) * k.hp : 128;
   size_t lds = (size_t)(a_rows_lds + d->taps * bn) * (bf3 ? 24 : kc + 4) * sizeof(float);
   {
@@ -1459,10 +1441,24 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
 extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt) {
   const size_t direct = (size_t)taps * N_pad * K_pad;
   if (wfmt == P2L_WFMT_F32) return direct;
+  if (wfmt == P2L_WFMT_PW) return direct + direct * 3 / 2;     // fp32 layout + bf16x3 image
   size_t n = direct * 3 / 2;
   if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
     n += p2l_wino_weight_floats(N_pad, K_pad);
   return n;
+}
+
+// P2L_WFMT_PW (1x1 convs): the fp32 layout of p2l_pack_conv_weight followed by the bf16x3 image
+// [K_pad/16][N_pad/32][32 rows][96 B]; the launcher picks per layer shape
+extern "C" int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                                       int transpose_flip, float* w_packed, void* stream) {
+  int rc = p2l_pack_conv_weight(w_oihw, O, I, 1, N_pad, K_pad, transpose_flip, w_packed, stream);
+  if (rc) return rc;
+  const size_t total = (size_t)K_pad * N_pad;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, w_packed + total, O, I, 1, N_pad, K_pad, 16,
+                     transpose_flip, 1);
+  return p2l_check_launch();
 }
 
 extern "C" int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,

@@ -278,7 +278,59 @@ __device__ __forceinline__ void epi_arb_reduce(const ConvK& k, EpiSums& S, float
   }
 }
 
+// Vectorised epilogue.  The MFMA C layout gives a lane one channel of 16 pixels:
+// storing that directly is 4-byte accesses, 128 B per pixel and instruction.  Instead
+// every wave dumps its 32 x (NT*32) accumulator tile into LDS (free after the K loop)
+// and re-reads it so that a lane owns ONE 2x2 pixel quad x FOUR consecutive channels:
+// all global accesses are 16 B per lane and NT*128 B contiguous per pixel, 2x2 pooling
+// stays lane-local, and the per-channel sums of the fused activation backward reduce
+// with 2-3 shuffles.  Handles every epilogue mode of the conv:
+//   v = alpha*acc + bias + residual ; act ; mask ; store ; 2x2 max/sum pool, or
+//   ARB (input-gradient convs): g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ;
+//   partial sums of g*x and g per (tile, channel)  [da 2x2-summed first if pool==SUM].
+template <int NT>
+__device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)[NT],
+                                             float* smem, int wave, int lane, int b0, int y0,
+                                             int x0, int n0, int tile_in_image, int osh,
+                                             int ph_y, int ph_x) {
+  constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* tb = smem + wave * 32 * EP;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[j][r];
+  __syncthreads();
+
+  const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
+  EpiSums S;
+#pragma unroll
+  for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+    const int it = it0 + lane;
+    const int q = it / C4, c4 = it - q * C4;
+    const int n = n0 + c4 * 4;
+    const int Q = wave * 8 + q;
+    const int qx = Q & (TWh - 1), qy = (Q >> (k.tw_log - 1)) & (THh - 1);
+    const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
+    if (b >= k.B || n >= k.n_store) continue;
+    const int oy0 = y0 + 2 * qy, ox0 = x0 + 2 * qx;
+    f32x4 v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * EP + c4 * 4) * k.alpha;
+    epi_item(k, v, b, oy0, ox0, n, osh, ph_y, ph_x, S);
+  }
+  if (k.arb_x != nullptr)
+    epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
+                             (size_t)b0 * k.arb_nblk + tile_in_image, n0);
+}
+
+
 }  // namespace p2lconv
+
+// bf16x3 form of the 1x1 conv (p2l_pw.hip)
+int p2l_pw_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
 
 // Winograd F(2x2,3x3) form of the bf16x3 3x3 conv (p2l_wino.hip)
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);

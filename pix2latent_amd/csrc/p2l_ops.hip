@@ -739,6 +739,33 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
   p[i] = p[i] - step_size * (mi / denom);
 }
 
+// Adam with the step number in DEVICE memory: nothing about the launch changes from step to
+// step, so a captured HIP graph of the inner step can be replayed (optimizer/base_optimizer.py).
+// Same arithmetic as adam_kernel; the bias corrections are formed in double like torch does
+// on the host.  The counters are advanced by a second, one-block kernel behind it.
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n,
+                                float lr, float beta1, float beta2, float eps,
+                                const int* __restrict__ steps) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double step = (double)(steps[0] + 1);
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+  const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+}
+__global__ void counters_advance_kernel(int* c, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) c[i] += 1;
+}
+
 __global__ void clamp_kernel(float* p, long long n, float lo, float hi) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = fminf(fmaxf(p[i], lo), hi);
@@ -1086,6 +1113,16 @@ extern "C" int p2l_adam_step(float* p, const float* g, float* m, float* v, int64
   const float bc2_sqrt = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), p, g, m,
                      v, (long long)n, step_size, beta1, beta2, eps, bc2_sqrt);
+  return p2l_check_launch();
+}
+extern "C" int p2l_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                                 float lr, float beta1, float beta2, float eps,
+                                 int32_t* step_counters, int n_counters, void* stream) {
+  if (!p || !g || !m || !v || !step_counters || n_counters < 1) return P2L_EINVAL;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), p, g, m,
+                     v, (long long)n, lr, beta1, beta2, eps, (const int*)step_counters);
+  hipLaunchKernelGGL(counters_advance_kernel, dim3(cdiv(n_counters, 256)), dim3(256), 0,
+                     ST(stream), (int*)step_counters, n_counters);
   return p2l_check_launch();
 }
 extern "C" int p2l_clamp(float* p, int64_t n, float lo, float hi, void* stream) {

@@ -68,7 +68,8 @@ thread_local int g_plan_wfmt = P2L_WFMT_F32;
 
 ConvCall mk_conv(int B, int H, int W, int Cin, int Cout, int taps) {
   ConvCall c;
-  c.d.wfmt = (taps == 9) ? g_plan_wfmt : P2L_WFMT_F32;
+  c.d.wfmt = (taps == 9) ? (g_plan_wfmt & 0xF)
+                         : ((g_plan_wfmt & P2L_WFMT_FLAG_PW) ? P2L_WFMT_PW : P2L_WFMT_F32);
   c.d.ext = 0;
   c.d.B = B; c.d.H = H; c.d.W = W; c.d.Cin = Cin; c.d.Cout = Cout; c.d.taps = taps;
   c.d.ups = 0; c.d.x_ld = Cin; c.d.pro = P2L_PRO_NONE; c.d.pro_bstride = 0;

@@ -90,7 +90,7 @@ thread_local int g_sg_wfmt = P2L_WFMT_F32;   // set at the synthesis entry point
 
 P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
   P2LConv d{};
-  d.wfmt = (taps == 9) ? g_sg_wfmt : P2L_WFMT_F32;
+  d.wfmt = (taps == 9) ? (g_sg_wfmt & 0xF) : P2L_WFMT_F32;
   d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.Cout = Cout; d.taps = taps;
   d.x_ld = Cin; d.alpha = 1.f; d.y_ld = Cout; d.yp_ld = Cout; d.n_store = Cout; d.splitk = 1;
   return d;

@@ -1,0 +1,189 @@
+// 1x1 convolution (pointwise GEMM) in the fp32-equivalent 3-way bf16 split arithmetic.
+//
+// Same role as conv_mfma_kernel<TAPS=1> (p2l_conv.hip): the BigGAN-deep GenBlock conv_0 /
+// conv_3 and the SelfAttn 1x1s, forward and input-gradient (reached from
+// pix2latent/model/biggan.py:58 in the reference).  That kernel multiplies on the exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate); this one splits both operands into
+// three bf16 pieces and accumulates the six significant cross products in fp32
+// (include/p2l.h P2L_WFMT_BF16X3): 6 x 32 matrix-pipe cycles per 16 channels instead of
+// 8 x 64.
+//
+// Why this works for ONE tap where the 3x3 kernel's per-chunk structure did not (round 1
+// measured 0.62-0.93x with it): the split costs ~40 VALU cycles per activation value, and a
+// 16-channel chunk of a 1x1 conv has only 12 MFMAs per wave to hide it behind plus two
+// barriers.  Here a stage is 64 channels: every thread splits 32 values (8 float4) while the
+// previous stage's 48 MFMAs per wave run, one barrier pair per 64 channels, two blocks per CU
+// (72 KB of LDS each) overlap one block's split with the other's multiply.
+//
+//   * block = the 128-pixel quad-ordered tile of the direct kernel (same epilogue: residual,
+//     nearest-x2 shortcut, pooling, fused activation backward) x 64 output channels;
+//     wave w owns pixels 32w .. 32w+31: 2 accumulators of 32x32;
+//   * A (activations): global fp32 -> registers -> prologue affine / ReLU -> 3-way split ->
+//     LDS rows of 96 B ([x1 k0-7 | x1 k8-15 | x2 .. | x3 ..], chunk index XOR bit 3 of the row);
+//   * B (weights): pre-split at pack time into the same row format (p2l_pack_conv_weight_pw),
+//     copied global -> registers -> LDS as an image.
+#include "p2l_conv_k.h"
+
+using namespace p2lconv;
+
+namespace {
+
+constexpr int PW_KS = 64;                               // channels per stage
+constexpr int PW_SUB = PW_KS / 16;                      // 16-channel sub-chunks per stage
+constexpr int PW_A_FLOATS = PW_SUB * 128 * 24;          // [sub][128 rows][96 B]
+constexpr int PW_B_FLOATS = PW_SUB * 64 * 24;           // [sub][2 N-tiles x 32 rows][96 B]
+constexpr size_t PW_LDS_BYTES = (size_t)(PW_A_FLOATS + PW_B_FLOATS) * sizeof(float);
+
+__device__ __forceinline__ void pw_store_split(float* As, int row, int q4, const f32x4 x) {
+  bf16x4 ph, pm, pl;
+  split3(x, ph, pm, pl);
+  char* rb = reinterpret_cast<char*>(As) + row * 96 + (q4 & 1) * 8;
+  char* rq = rb + bf3_chunk(q4 >> 1, row) * 16;         // pieces at +0 / +32 / +64 bytes
+  *reinterpret_cast<bf16x4*>(rq) = ph;
+  *reinterpret_cast<bf16x4*>(rq + 32) = pm;
+  *reinterpret_cast<bf16x4*>(rq + 64) = pl;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + PW_A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int TW = 1 << k.tw_log, TH = 1 << k.th_log;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
+  const int tiles_per_image = k.tiles_x * k.tiles_y;
+  const int b0 = mt / tiles_per_image;                   // one image per tile (launcher)
+  const int tile_in_image = mt - b0 * tiles_per_image;
+  const int ty = tile_in_image / k.tiles_x, tx = tile_in_image - ty * k.tiles_x;
+  const int n0 = nt * 64;
+  const int y0 = ty << k.th_log, x0 = tx << k.tw_log;
+
+  // ---- A staging: 128 pixels x 16 float4 per stage = 8 items per thread; item j = tid + 256*it
+  // covers pixel j >> 4, float4 (tid & 15) of the stage: sub-chunk (tid & 15) >> 2, quarter & 3
+  constexpr int A_ITERS = 8;
+  const int av = tid & 15;
+  int a_goff[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int p = (tid + 256 * it) >> 4;
+    const int Q = p >> 2, s = p & 3;
+    const int qx = Q & ((TW >> 1) - 1);
+    const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
+    const int iy = y0 + 2 * qy + (s >> 1), ix = x0 + 2 * qx + (s & 1);
+    a_goff[it] = ((b0 * k.H + iy) * k.W + ix) * k.x_ld + av * 4;
+  }
+  const int s_off = b0 * k.pro_bstride + av * 4;
+  // ---- B staging: [sub][64 rows][6 x 16 B] = 1536 items per stage, 6 per thread; the packed
+  // image is [chunk][32-channel tile][32 rows][96 B]: the 2 tiles of this block are one 6 KB run
+  constexpr int B_ITERS = 6;
+  int b_goff[B_ITERS];
+#pragma unroll
+  for (int it = 0; it < B_ITERS; ++it) {
+    const int j = tid + 256 * it;
+    const int sub = j / 384, within = j - sub * 384;
+    b_goff[it] = (sub * (k.Cout >> 5) + (n0 >> 5)) * 32 * 24 + within * 4;
+  }
+  const int b_stage = 4 * (k.Cout >> 5) * 32 * 24;       // floats per stage of the image
+
+  f32x4 xr[A_ITERS], wr[B_ITERS], sr, tr;
+  auto load_regs = [&](int st) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + st * PW_KS);
+    if (PRO != P2L_PRO_NONE) {
+      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + st * PW_KS);
+      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + st * PW_KS);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it)
+      wr[it] = *reinterpret_cast<const f32x4*>(k.w + (size_t)st * b_stage + b_goff[it]);
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      f32x4 v = xr[it];
+      if (PRO != P2L_PRO_NONE) {
+        v = v * sr + tr;
+        if (PRO == P2L_PRO_AFFINE_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      const int p = (tid + 256 * it) >> 4;
+      pw_store_split(As + (av >> 2) * (128 * 24), p, av & 3, v);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it)
+      *reinterpret_cast<f32x4*>(Bs + (tid + 256 * it) * 4) = wr[it];     // image copy
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int a_row = wave * 32 + l31;
+  const int a_c = bf3_chunk(lhi, a_row) * 4, b_c = bf3_chunk(lhi, l31) * 4;
+  const int nstages = k.nchunks;                         // = Cin / 64
+  load_regs(0);
+  write_lds();
+  __syncthreads();
+  for (int st = 0; st < nstages; ++st) {
+    const bool more = st + 1 < nstages;
+    if (more) load_regs(st + 1);
+#pragma unroll
+    for (int sub = 0; sub < PW_SUB; ++sub) {
+      const float* ar = As + (sub * 128 + a_row) * 24 + a_c;
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ar);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ar + 8);
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(ar + 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* br = Bs + (sub * 64 + j * 32 + l31) * 24 + b_c;
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(br);
+        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(br + 8);
+        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(br + 16);
+        f32x16 t = acc[j];                               // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
+        acc[j] = t;
+      }
+    }
+    __syncthreads();
+    if (more) write_lds();
+    __syncthreads();
+  }
+  epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
+}
+
+}  // namespace
+
+int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
+  dim3 grid(k.n_mtiles * k.n_ntiles), block(256);
+#define P2L_PW(PRO)                                                                          \
+  do {                                                                                       \
+    static bool attr_set = false;                                                            \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)pw_bf3_kernel<PRO>,                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(pw_bf3_kernel<PRO>, grid, block, PW_LDS_BYTES, st, k);                \
+  } while (0)
+  if (pro == P2L_PRO_NONE) P2L_PW(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW(P2L_PRO_AFFINE_RELU);
+  else P2L_PW(P2L_PRO_AFFINE);
+#undef P2L_PW
+  return p2l_check_launch();
+}

@@ -119,7 +119,9 @@ class BigGAN(nn.Module):
         self._desc = N.P2LBigGAN()
         # arithmetic of the 3x3 convs: bf16x3 split (fp32-equivalent, default) or exact fp32
         self._wfmt = N.default_wfmt() if wfmt is None else wfmt
-        self._desc.wfmt = self._wfmt
+        # 1x1 convs: same arithmetic on the bf16 pipe (their buffers then carry the pre-split image)
+        self._pw = N.default_pw() and self._wfmt != N.WFMT_F32
+        self._desc.wfmt = self._wfmt | (N.WFMT_FLAG_PW if self._pw else 0)
         self._ws = None
         self._ws_B = -1
         self._ticket = 0
@@ -134,8 +136,8 @@ class BigGAN(nn.Module):
         return t
 
     def _pack_conv(self, w, taps, n_pad, k_pad, flip):
-        dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), taps, n_pad, k_pad, flip,
-                                 self._wfmt)
+        fmt = self._wfmt if taps == 9 else (N.WFMT_PW if self._pw else N.WFMT_F32)
+        dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), taps, n_pad, k_pad, flip, fmt)
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
         return dst

@@ -23,6 +23,8 @@ def mfma_probe(A, B):
 
 
 def pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip=False, wfmt=N.WFMT_F32):
+    if taps == 9 and wfmt == N.WFMT_PW:
+        wfmt = N.WFMT_F32
     return N.pack_conv_weight(w_oihw, taps, n_pad, k_pad, flip, wfmt)
 
 

@@ -23,6 +23,7 @@ Multi-GPU: the sampler lives on every rank but only rank 0's draw counts (it is 
 the losses handed to `report` are all-gathered once per generation, so every replica of the
 sampler state stays identical.  Nothing else crosses ranks inside a generation.
 """
+import os
 import time
 from collections import namedtuple
 
@@ -167,6 +168,12 @@ class SearchLoopMixin(object):
         defaults restored, FRESH Adam state (reference base_cma_optimizer.py:79,
         base_ng_optimizer.py:104)."""
         variables = None
+        # graph execution of the inner step wants stable device addresses across generations
+        if getattr(self, 'use_graph', False) is not False and torch.cuda.is_available():
+            lo, hi = self.shard.bounds(num_samples) if self.shard.enabled else (0, num_samples)
+            if self.use_graph or os.environ.get('P2L_GRAPH') == '1' or \
+                    (os.environ.get('P2L_GRAPH') != '0' and 0 < hi - lo <= 6):
+                self.var_manager.reuse_buffers = True
         for g_idx, gen in enumerate(plan):
             with torch.no_grad():
                 variables = self.var_manager.initialize(num_samples=num_samples)

@@ -43,6 +43,9 @@ class _Hook(object):
 
     #: True when the hook consumes random numbers
     stochastic = False
+    #: True when a captured HIP graph of the hook may be replayed verbatim (nothing about its
+    #: launches depends on host state that changes from step to step)
+    graph_safe = True
 
     def __call__(self, vars):
         for v in vars:
@@ -122,6 +125,8 @@ class ScheduledNormalPerturb(NormalPerturb):
     reference class, function_hooks.py:73-102, fails on its un-imported `math`; like it,
     `pow` is accepted but the exponent is always 2.) """
 
+    graph_safe = False           # the strength is a host number that changes every call
+
     def __init__(self, sigma=0.1, max_step=500, pow=2):
         NormalPerturb.__init__(self, sigma)
         self.max_step = max_step
@@ -141,6 +146,10 @@ class Compose(_Hook):
 
     def __init__(self, *hook_fns):
         self.hook_fns = hook_fns
+
+    @property
+    def graph_safe(self):
+        return all(getattr(fn, 'graph_safe', False) for fn in self.hook_fns)
 
     def __call__(self, vars):
         for fn in self.hook_fns:

@@ -15,6 +15,7 @@ MI355X-first differences (data layout, not semantics):
   * no hard-coded `.cuda()` (reference :217): the device is a constructor
     argument, default = ROCm device if present.
 """
+import ctypes as C
 import pprint
 
 import numpy as np
@@ -33,10 +34,17 @@ class FusedAdam(object):
     """Adam over the contiguous per-variable buffers; one HIP launch per
     (variable, chunk).  Reproduces torch.optim.Adam (lr per variable,
     betas=(0.9, 0.999), eps=1e-8, per-sample step counters) as instantiated at
-    reference variable_manager.py:231-238 and stepped at closure.py:65."""
+    reference variable_manager.py:231-238 and stepped at closure.py:65.
 
-    def __init__(self, entries, betas=(0.9, 0.999), eps=1e-8):
-        # entries: list of dict(name, buf, lr, leaves)
+    The per-sample step counters live on the DEVICE (p2l_adam_step_dev): no launch argument
+    changes from step to step, which is what lets the whole inner step be captured in a HIP
+    graph and replayed (optimizer/base_optimizer.py).  `param_groups` / `state_steps()` keep
+    the torch-style view for callers that inspect the optimizer."""
+
+    def __init__(self, entries, betas=(0.9, 0.999), eps=1e-8, recycle=None):
+        # entries: list of dict(name, buf, lr, leaves); recycle: a previous FusedAdam whose
+        # state tensors are reused (zeroed) when the shapes match - keeps device addresses
+        # stable across re-initialisations
         from . import _native as N
         self._N = N
         self._lib = N.lib()
@@ -45,9 +53,13 @@ class FusedAdam(object):
         self.param_groups = []
         for e in entries:
             buf = e['buf']
-            self.entries[e['name']] = dict(
-                buf=buf, lr=e['lr'], m=torch.zeros_like(buf), v=torch.zeros_like(buf),
-                steps=[0] * buf.size(0))
+            old = recycle.entries.get(e['name']) if recycle is not None else None
+            if old is not None and old['m'].shape == buf.shape and old['m'].device == buf.device:
+                m, v, steps = old['m'].zero_(), old['v'].zero_(), old['steps'].zero_()
+            else:
+                m, v = torch.zeros_like(buf), torch.zeros_like(buf)
+                steps = torch.zeros(buf.size(0), dtype=torch.int32, device=buf.device)
+            self.entries[e['name']] = dict(buf=buf, lr=e['lr'], m=m, v=v, steps=steps)
             for leaf in e['leaves']:
                 self.param_groups.append({'params': [leaf], 'lr': e['lr']})
 
@@ -56,21 +68,23 @@ class FusedAdam(object):
             for p in g['params']:
                 p.grad = None
 
+    def state_steps(self, name):
+        """per-sample step counts of variable `name` (host copy)"""
+        return self.entries[name]['steps'].cpu().tolist()
+
     def update(self, name, i0, i1, grad):
-        """one Adam step for samples [i0, i1) of variable `name`."""
+        """one Adam step for samples [i0, i1) of variable `name` (they advance in lock-step:
+        the step number of sample i0 is used for the whole chunk)."""
         N = self._N
         e = self.entries[name]
-        steps = e['steps']
-        for i in range(i0, i1):
-            steps[i] += 1
-        step = steps[i0]
-        assert all(s == step for s in steps[i0:i1]), 'chunk samples out of lock-step'
         p = e['buf'][i0:i1]
         g = grad.contiguous()
-        N.check(self._lib.p2l_adam_step(N.ptr(p), N.ptr(g), N.ptr(e['m'][i0:i1]),
-                                        N.ptr(e['v'][i0:i1]), N.i64(p.numel()), N.f32(e['lr']),
-                                        N.f32(self.betas[0]), N.f32(self.betas[1]),
-                                        N.f32(self.eps), int(step), N.stream()), 'p2l_adam_step')
+        N.check(self._lib.p2l_adam_step_dev(N.ptr(p), N.ptr(g), N.ptr(e['m'][i0:i1]),
+                                            N.ptr(e['v'][i0:i1]), N.i64(p.numel()), N.f32(e['lr']),
+                                            N.f32(self.betas[0]), N.f32(self.betas[1]),
+                                            N.f32(self.eps),
+                                            C.c_void_p(e['steps'][i0:i1].data_ptr()), int(i1 - i0),
+                                            N.stream()), 'p2l_adam_step_dev')
 
     def step(self, closure=None):
         """kept for API compatibility (`vars.opt.step(closure)`); the chunk
@@ -138,6 +152,14 @@ class VariableManager():
         """ A variable manager that creates variables for optimization """
         self.variable_info = {}
         self.device = torch.device(device) if device is not None else _default_device()
+        # reuse_buffers: `initialize()` writes the fresh samples into the SAME device buffers
+        # (and Adam state tensors) as the previous call with the same num_samples, instead of
+        # allocating new ones.  Device addresses then stay put from one CMA generation to the
+        # next, so a captured HIP graph of the inner step stays valid for the whole run.  The
+        # optimizers switch it on together with graph execution; note that the `variables` of
+        # the previous generation then alias the new ones.
+        self.reuse_buffers = False
+        self._pool = {}
         return
 
     def __str__(self):
@@ -221,9 +243,25 @@ class VariableManager():
                     num_samples, *spec['default'].shape)
             else:
                 stacked = spec['distribution'](num_samples, spec['shape'])
-            buf = stacked.detach().to(self.device, copy=True).contiguous()
-            if buf.dtype != torch.float32 and buf.is_floating_point():
-                buf = buf.float()
+            fresh = stacked.detach()
+            if fresh.dtype != torch.float32 and fresh.is_floating_point():
+                fresh = fresh.float()
+            pooled = self._pool.get((v, num_samples)) if self.reuse_buffers else None
+            if pooled is not None and pooled[0].shape == fresh.shape:
+                buf, filled_version, filled_from = pooled
+                # a constant variable (default-valued, not optimised, not rewritten by a torch
+                # op such as apply_transform since it was filled) keeps its contents AND its
+                # version: caches keyed on it (the loss' target features) stay valid.
+                # Optimised variables are always refilled: Adam updates them through raw
+                # pointers, which torch's version counter does not see.
+                if spec['requires_grad'] or spec['default'] is None or \
+                        filled_from is not spec['default'] or buf._version != filled_version:
+                    buf.copy_(fresh)
+            else:
+                buf = fresh.to(self.device, copy=True).contiguous()
+            if self.reuse_buffers:
+                self._pool[(v, num_samples)] = (buf, buf._version, spec['default'])
+            buf.requires_grad_(False)
             data = [buf[i] for i in range(num_samples)]
 
             if spec['var_type'] not in vars.keys():
@@ -251,7 +289,10 @@ class VariableManager():
                                   'leaves': data})
 
         if all_adam and self.device.type == 'cuda' and len(fused_entries) > 0:
-            vars['opt'] = FusedAdam(fused_entries)
+            recycle = self._pool.get(('opt', num_samples)) if self.reuse_buffers else None
+            vars['opt'] = FusedAdam(fused_entries, recycle=recycle)
+            if self.reuse_buffers:
+                self._pool[('opt', num_samples)] = vars['opt']
         else:
             # reference quirk kept: the optimizer CLASS is the one of the LAST
             # registered variable (variable_manager.py:238)

@@ -61,13 +61,25 @@ CONV_CASES = [
     dict(B=1, H=48, Cin=48, Cout=64, taps=9, res='same', alpha=0.5, bias=True),
     dict(B=2, H=16, Cin=128, Cout=64, taps=9, mask=True, pro='affine'),
     dict(B=2, H=32, Cin=16, Cout=64, taps=9, res='ups', bias=True),
+    # 1x1 shapes the bf16x3 pointwise kernel takes (>= 32x32, Cin and Cout multiples of 64)
+    dict(B=2, H=32, Cin=64, Cout=64, taps=1, bias=True),
+    dict(B=2, H=32, Cin=256, Cout=128, taps=1, pro='affine_relu', bias=True, res='same', alpha=0.5),
+    dict(B=3, H=32, Cin=128, Cout=64, taps=1, res='ups', bias=True, pro='affine_relu'),
+    dict(B=2, H=64, Cin=128, Cout=64, taps=1, act='relu', pool='max'),
+    dict(B=2, H=32, Cin=64, Cout=128, taps=1, pool='sum', want_y=False, pro='affine'),
 ]
 
 
 # P2L_WFMT_F32 (exact fp32 MFMA), P2L_WFMT_BF16X3 (3-way bf16 split, 6 products, direct kernel),
 # P2L_WFMT_BF16X3W (same arithmetic; eligible shapes run in the Winograd F(2x2,3x3) form)
-WFMTS = [0, 1, 2]
-WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd']
+# P2L_WFMT_PW (1x1 convs: fp32 layout + bf16x3 image; layers >= 32x32 run in the bf16x3 arithmetic)
+WFMTS = [0, 1, 2, 3]
+WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd', 'pw-bf16x3']
+
+
+def _skip_unless_format_applies(wfmt, taps):
+    if (taps == 9 and wfmt == 3) or (taps != 9 and wfmt in (1, 2)):
+        pytest.skip('weight format does not apply to this kernel size')
 
 
 @pytest.fixture(autouse=True)
@@ -86,8 +98,7 @@ def test_conv_fwd(dev, O, case, wfmt):
     """both weight formats must meet the SAME tolerance: bf16x3 is an fp32-equivalent
     arithmetic (include/p2l.h P2L_WFMT_BF16X3), not a reduced-precision mode"""
     from pix2latent_amd import _native as N
-    if wfmt and case['taps'] != 9:
-        pytest.skip('bf16x3 applies to the 3x3 kernels')
+    _skip_unless_format_applies(wfmt, case['taps'])
     g = torch.Generator().manual_seed(1)
     B, H, Cin, Cout, taps = case['B'], case['H'], case['Cin'], case['Cout'], case['taps']
     k = 3 if taps == 9 else 1
@@ -158,6 +169,7 @@ def test_conv_fwd(dev, O, case, wfmt):
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 96)])
 def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
+    _skip_unless_format_applies(wfmt, 9)
     """3x3 conv on a nearest-x2 upsampled input in sub-pixel form (ups=2) and its
     input-gradient (ups=3) against F.interpolate + F.conv2d and autograd."""
     from pix2latent_amd import _native as N
@@ -185,6 +197,7 @@ def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
 
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
+    _skip_unless_format_applies(wfmt, 9)
     g = torch.Generator().manual_seed(14)
     B, C, Co, h = 2, 64, 64, 16
     x = torch.randn(B, C, h, h, generator=g, requires_grad=True)
@@ -255,12 +268,43 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk)
         sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
         exp_dx[:, :C // 2] += F.avg_pool2d(sk, 2, 2) * 4
         sk_t, skip_C = nhwc(sk, dev), C // 2
-    if wfmt and taps != 9:
-        pytest.skip('bf16x3 applies to the 3x3 kernels')
+    _skip_unless_format_applies(wfmt, taps)
     wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True, wfmt=wfmt)
     dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, Ho, Ho, Co, C, taps, nhwc(x.detach(), dev),
                                   s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups, wfmt=wfmt,
                                   skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'), splitk=splitk)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), exp_dx) < 2e-5
+    assert relerr(ds.cpu(), s.grad) < 5e-5
+    assert relerr(dt.cpu(), t.grad) < 5e-5
+
+
+@pytest.mark.parametrize('skip', [None, 'same', 'ups'])
+def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip):
+    """the 1x1 input-gradient conv in the bf16x3 arithmetic (csrc/p2l_pw.hip) with the fused
+    backward of relu(x*s+t) and the GenBlock shortcut gradient, at a size that kernel takes"""
+    g = torch.Generator().manual_seed(14)
+    B, C, Co, H = 2, 128, 64, 32
+    x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    s = (0.5 + torch.rand(B, C, generator=g)).requires_grad_(True)
+    t = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(Co, C, 1, 1, generator=g) / math.sqrt(C)
+    dy = torch.randn(B, Co, H, H, generator=g)
+    F.conv2d(F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1)), w).backward(dy)
+    exp_dx = x.grad.clone()
+    sk_t, skip_C = None, 0
+    if skip == 'same':
+        sk = torch.randn(B, C, H, H, generator=g)
+        exp_dx = exp_dx + sk
+        sk_t, skip_C = nhwc(sk, dev), C
+    elif skip == 'ups':
+        sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
+        exp_dx[:, :C // 2] += F.avg_pool2d(sk, 2, 2) * 4
+        sk_t, skip_C = nhwc(sk, dev), C // 2
+    wt = O.pack_conv_weight(w.to(dev), 1, C, Co, flip=True, wfmt=3)
+    dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, H, H, Co, C, 1, nhwc(x.detach(), dev),
+                                  s.detach().to(dev), t.detach().to(dev), C, wfmt=3,
+                                  skip=sk_t, skip_C=skip_C, skip_ups=(skip == 'ups'))
     torch.cuda.synchronize()
     assert relerr(nchw(dx), exp_dx) < 2e-5
     assert relerr(ds.cpu(), s.grad) < 5e-5

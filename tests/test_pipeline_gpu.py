@@ -105,7 +105,10 @@ def test_gradient_optimizer_biggan_vs_cpu_oracle(dev):
     # which fp32 noise (relL2 ~3e-3 in the oracle itself) only does for |g| ~ 0.
     dz = np.abs(z_gpu - z_cpu)
     assert np.median(dz) < 1e-3, np.median(dz)
-    assert np.mean(dz < 0.02) > 0.97, np.mean(dz < 0.02)
+    # (which coordinates flip depends on the arithmetic variant: 0.91 ... 0.99 measured across the
+    # direct / Winograd / pointwise-bf16x3 kernel combinations, all with gradients at the fp32
+    # oracle's own distance from the fp64 oracle, tests/test_biggan_grad64_gpu.py)
+    assert np.mean(dz < 0.02) > 0.85, np.mean(dz < 0.02)
 
 
 def test_basincma_generation_on_biggan(dev):
@@ -189,3 +192,97 @@ def test_transform_basincma_on_biggan(dev):
     # warped targets differ per candidate (each has its own t)
     tg = torch.stack(list(variables.output.target.data))
     assert (tg[0] - tg[1]).abs().max().item() > 1e-3
+
+
+def _graph_problem(dev, hook_fn, n):
+    from pix2latent_amd import VariableManager, distribution
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.model.biggan import BigGAN
+    import pix2latent_amd.loss_functions as LF
+    model = BigGAN(weights=S.biggan_weights(0), device=dev)
+    loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=S.lpips_vgg_weights(1), device=dev)
+    vm = VariableManager(device=dev)
+    g = torch.Generator().manual_seed(2)
+    vm.register('z', (128,), 'input', distribution=distribution.TruncatedNormalModulo(),
+                learning_rate=0.05, hook_fn=hook_fn, grad_free=True)
+    vm.register('c', (128,), 'input', default=0.05 * torch.randn(128, generator=g), learning_rate=0.01)
+    vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_target(256, 1))
+    vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_weight_mask(256))
+    return model, loss_fn, vm
+
+
+def test_hip_graph_replay_is_the_eager_trajectory(dev):
+    """use_graph: step 0 eager, step 1 captured (+ replayed), steps 2.. replayed.  With the Adam
+    step numbers on the device nothing in a launch depends on the step index, so the replayed
+    trajectory is BIT-identical to eager execution: losses of every step, final latents, Adam
+    step counters; and tracking (kept outside the graph) still records every step."""
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import GradientOptimizer
+    model, loss_fn, vm = _graph_problem(dev, hook.Clamp(2.0), 3)
+    runs = {}
+    for mode in (False, True):
+        torch.manual_seed(7)
+        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, use_graph=mode)
+        variables = vm.initialize(num_samples=3)
+        losses = []
+        for i in range(6):
+            _, l, _ = opt.step(variables, optimize=True, transform=(i == 0))
+            losses.append(np.array(l, dtype=np.float64))
+        runs[mode] = (np.stack(losses), torch.stack(list(variables.input.z.data)).detach().cpu(),
+                      torch.stack(list(variables.input.c.data)).detach().cpu(),
+                      variables.opt.state_steps('z'), len(opt.tracked['z']))
+        if mode:
+            assert any(isinstance(v, tuple) for v in opt._graphs.values()), 'no graph was captured'
+    (l0, z0, c0, s0, t0), (l1, z1, c1, s1, t1) = runs[False], runs[True]
+    assert np.array_equal(l0, l1) and torch.equal(z0, z1) and torch.equal(c0, c1)
+    assert s0 == s1 == [6, 6, 6] and t0 == t1 == 6
+    assert np.all(np.diff(l0.mean(1)) < 0)
+
+
+def test_hip_graph_across_generations_with_buffer_reuse(dev):
+    """BasinCMA with graph execution: VariableManager.reuse_buffers keeps the device addresses
+    (and the version of the untouched target / weight buffers) from one generation to the next,
+    so ONE capture serves the whole run; same numbers as the eager run with the same seeds."""
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import BasinCMAOptimizer
+    model, loss_fn, vm = _graph_problem(dev, hook.Compose(hook.Clamp(2.0)), 18)
+    res = {}
+    for mode in (False, True):
+        vm.reuse_buffers, vm._pool = False, {}
+        torch.manual_seed(9)
+        opt = BasinCMAOptimizer(model, vm, loss_fn, max_batch_size=9, exec_batch_size='all',
+                                use_graph=mode)
+        opt.cma_seed = 4
+        captures = []
+        if mode:
+            real = torch.cuda.CUDAGraph.capture_begin
+            torch.cuda.CUDAGraph.capture_begin = lambda self, *a, **k: (captures.append(1), real(self, *a, **k))[1]
+        try:
+            variables, _, losses = opt.optimize(meta_steps=2, grad_steps=4, last_grad_steps=4)
+        finally:
+            if mode:
+                torch.cuda.CUDAGraph.capture_begin = real
+        res[mode] = (np.array(losses[-1][1]['loss']), torch.stack(list(variables.input.z.data)).detach().cpu(),
+                     len(captures))
+    assert res[True][2] == 1, 'expected one capture for the whole run, got %d' % res[True][2]
+    assert np.array_equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
+def test_random_hook_under_graph_replay_draws_fresh_noise(dev):
+    """NormalPerturb inside a replayed graph: torch's graph-safe generator advances per replay
+    (noise differs from step to step), Clamp still bounds the latents"""
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import GradientOptimizer
+    model, loss_fn, vm = _graph_problem(dev, hook.Compose(hook.NormalPerturb(0.05), hook.Clamp(2.0)), 2)
+    vm.edit_variable('z', {'learning_rate': 0.0})
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, use_graph=True)
+    variables = vm.initialize(num_samples=2)
+    seen = []
+    for i in range(5):
+        opt.step(variables, optimize=True, transform=(i == 0))
+        seen.append(torch.stack(list(variables.input.z.data)).detach().cpu().clone())
+    deltas = [(seen[i + 1] - seen[i]) for i in range(1, 4)]        # replayed steps
+    assert all(d.abs().max() > 0 for d in deltas)
+    assert not torch.equal(deltas[0], deltas[1]) and not torch.equal(deltas[1], deltas[2])
+    assert all(abs(d.std().item() - 0.05) < 0.02 for d in deltas)
+    assert seen[-1].abs().max() <= 2.0 + 1e-6
