@@ -205,7 +205,8 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     Winograd F(2x2,3x3) transform-domain image of the weights (G g G^T in fp64, rounded to
  *     fp32, split into the same three bf16 pieces; [K_pad/16][16 frequencies][N_pad/32]
  *     [3 pieces][64 lanes] x 16 B = MFMA B-fragment order).  p2l_conv_fwd / p2l_conv_dgrad_arb
- *     then run stride-1 3x3 layers whose grid is whole 16x16-pixel x 64-channel blocks in the
+ *     then run stride-1 3x3 layers made of whole 8x16-pixel x 64-channel blocks (at least 64 per
+ *     image: a function of the layer shape only, never of the batch) in the
  *     Winograd form (2.25x fewer matrix products, csrc/p2l_wino.hip) and everything else on the
  *     direct kernel.  Results agree with P2L_WFMT_BF16X3 to fp32 rounding.
  *     p2l_packed_weight_floats() gives the buffer size of any format.

@@ -3,16 +3,19 @@ rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; collected separately, as the TCC
 cannot hold both).  Units/corrections per MI355X_MICROARCH.md "HBM": the counters are in
 KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads ->
 x2; WRITE_SIZE is taken as reported (uncalibrated).
-Usage: traffic_json.py <fetch_summary.csv> <write_summary.csv> <out.json>"""
+Usage: traffic_json.py <fetch_summary.csv> <write_summary.csv> <out.json> [commit] [box] [command]"""
 import csv
 import json
 import sys
+
+# every kernel a 3x3 launch of the bench step can be: direct (TAPS=9), sub-pixel (TAPS=4), Winograd
+KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'wino_conv_kernel')
 
 
 def per_launch(path, counter):
     calls, total = 0, 0.0
     for r in csv.DictReader(open(path)):
-        if r['Counter'] == counter and 'conv_mfma_kernel<9,' in r['Kernel_Name']:
+        if r['Counter'] == counter and any(k in r['Kernel_Name'] for k in KERNELS):
             calls += int(r['Dispatches'])
             total += float(r['Sum'])
     return calls, (total / calls if calls else 0.0)
@@ -21,7 +24,10 @@ def per_launch(path, counter):
 nf, f = per_launch(sys.argv[1], 'FETCH_SIZE')
 nw, w = per_launch(sys.argv[2], 'WRITE_SIZE')
 out = {
-    'kernel': 'conv_mfma_kernel<TAPS=9,...> (all 3x3 instantiations)',
+    'kernel': '3x3 conv launches: conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel',
+    'commit': sys.argv[4] if len(sys.argv) > 4 else None,
+    'box': sys.argv[5] if len(sys.argv) > 5 else None,
+    'command': sys.argv[6] if len(sys.argv) > 6 else None,
     'fetch_launches': nf, 'write_launches': nw,
     'fetch_size_raw_bytes_per_launch': round(f * 1024),
     'fetch_bytes_per_launch': round(f * 1024 * 2),
