@@ -24,11 +24,13 @@ for n in NS:
     vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
     opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, exec_batch_size=n)
     variables = vm.initialize(num_samples=n)
-    for i in range(3):
+    for i in range(4):       # (with HIP-graph execution the step is captured on its third call)
         opt.step(variables, optimize=True, transform=(i == 0))
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(8):
         opt.step(variables, optimize=True)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / 8 * 1e3
-    print('local candidates %2d: %.2f ms/step  %.0f evals/s per GPU  (%.2f ms per candidate)' % (n, ms, n / ms * 1e3, ms / n))
+    graphed = any(isinstance(v, tuple) for v in opt._graphs.values())
+    print('local candidates %2d: %.2f ms/step  %.0f evals/s per GPU  (%.2f ms per candidate)%s' % (
+        n, ms, n / ms * 1e3, ms / n, '  [HIP graph replay]' if graphed else ''))
