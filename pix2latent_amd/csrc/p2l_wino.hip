@@ -190,15 +190,21 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
     if (!(k.abl & 2)) transform();
     __syncthreads();
     if (k.abl & 8) continue;
+    bf16x8 af[2][3];
+    auto lda = [&](int fi, bf16x8 (&a)[3]) {
+      const int row = (4 * wave + fi) * 32 + l31;
+      const float* aq = Vs + row * 24 + bf3_chunk(lhi, row) * 4;
+      a[0] = *reinterpret_cast<const bf16x8*>(aq);
+      a[1] = *reinterpret_cast<const bf16x8*>(aq + 8);
+      a[2] = *reinterpret_cast<const bf16x8*>(aq + 16);
+    };
+    lda(0, af[0]);
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi) {
       if (fi + 1 < 4) load_b(c, fi + 1, (fi + 1) & 1);
       else if (more) load_b(c + 1, 0, 0);
-      const int row = (4 * wave + fi) * 32 + l31;
-      const float* aq = Vs + row * 24 + bf3_chunk(lhi, row) * 4;
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(aq);
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(aq + 8);
-      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(aq + 16);
+      if (fi + 1 < 4) lda(fi + 1, af[(fi + 1) & 1]);     // next frequency's A fragments in flight
+      const bf16x8 a1 = af[fi & 1][0], a2 = af[fi & 1][1], a3 = af[fi & 1][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][0]);
