@@ -188,6 +188,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
     __syncthreads();
     if (more && !(k.abl & 4)) load_raw(c + 1);
     if (!(k.abl & 2)) transform();
+    load_b(c, 1, 1);                 // frequency 1's fragments: in flight across the barrier
     __syncthreads();
     if (k.abl & 8) continue;
     bf16x8 af[2][3];
@@ -201,8 +202,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
     lda(0, af[0]);
 #pragma unroll
     for (int fi = 0; fi < 4; ++fi) {
-      if (fi + 1 < 4) load_b(c, fi + 1, (fi + 1) & 1);
-      else if (more) load_b(c + 1, 0, 0);
+      if (fi >= 1 && fi + 1 < 4) load_b(c, fi + 1, (fi + 1) & 1);
+      else if (fi == 3 && more) load_b(c + 1, 0, 0);
       if (fi + 1 < 4) lda(fi + 1, af[(fi + 1) & 1]);     // next frequency's A fragments in flight
       const bf16x8 a1 = af[fi & 1][0], a2 = af[fi & 1][1], a3 = af[fi & 1][2];
 #pragma unroll
