@@ -929,6 +929,20 @@ static bool pw_shape(const P2LConv* d) {
   return d->H * d->W >= 1024 && d->Cin >= min_cin;
 }
 
+// streaming bf16x3 form of the 1x1 conv (pws_bf3_kernel): 64 / 128 input channels, at least as
+// many output channels -- the channel-expanding, HBM-bound layers.  Shape-only, like the
+// other kernel choices (results must not depend on the batch a candidate is evaluated in).
+static bool pws_shape(const P2LConv* d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("P2L_PWS"); on = e ? atoi(e) : 1; }
+  if (!on || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
+  if ((d->Cin != 64 && d->Cin != 128) || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16)
+    return false;
+  return d->H * d->W >= 1024 && d->Cout >= d->Cin;
+}
+// either bf16x3 pointwise kernel: no split-K
+static bool pw_any(const P2LConv* d) { return pw_shape(d) || pws_shape(d); }
+
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
 // share a CU's matrix pipes, so time ~ ceil(blocks / 256 CUs) * work-per-block.
@@ -984,7 +998,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (d->ups >= 2) return 1;             // sub-pixel modes never split K
-  if (choose_tile(d, k) != P2L_OK || wino_shape(d) || pw_shape(d)) return 1;
+  if (choose_tile(d, k) != P2L_OK || wino_shape(d) || pw_any(d)) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nblk = k.n_mtiles * (d->Cout / bn);
@@ -1006,7 +1020,7 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
 static int effective_splitk(const P2LConv* d) {
-  if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d) || pw_shape(d)) return 1;
+  if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d) || pw_any(d)) return 1;
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nchunks = d->Cin / kc;
   int sk = d->splitk > nchunks ? nchunks : d->splitk;
@@ -1081,7 +1095,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
-  k.splitk = (d->splitk < 1 || wino_shape(d) || pw_shape(d)) ? 1 : d->splitk;
+  k.splitk = (d->splitk < 1 || wino_shape(d) || pw_any(d)) ? 1 : d->splitk;
   if (k.splitk > k.nchunks) k.splitk = k.nchunks;
   k.chunks_per_split = cdiv(k.nchunks, k.splitk);
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
@@ -1146,6 +1160,16 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     kp.nchunks = d->Cin / 64;
     kp.splitk = 1;
     rc = p2l_pw_launch(kp, d->pro, st);
+    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    return rc;
+  }
+  if (pws_shape(d)) {
+    ConvK kp = k;
+    kp.w = w + (size_t)d->Cout * d->Cin;
+    kp.nchunks = d->Cin / 16;
+    kp.splitk = 1;
+    kp.arb_nblk = (d->H >> 1) * (d->W >> 4);      // one partial row per 32-pixel block
+    rc = p2l_pws_launch(kp, d->pro, st);
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
   }
@@ -1282,6 +1306,7 @@ extern "C" int p2l_conv_arb_fusable(const P2LConv* d) {
 extern "C" int p2l_conv_arb_nblk(const P2LConv* d) {
   ConvK k{};
   if (!d || choose_tile(d, k) != P2L_OK) return 0;
+  if (pws_shape(d)) return (d->H >> 1) * (d->W >> 4);   // 32-pixel blocks
   return k.n_mtiles / d->B;
 }
 

@@ -153,9 +153,11 @@ struct EpiSums {
   f32x4 sgx = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
 };
 
+// ARBM: -1 = decided at run time (k.arb_x), 0 / 1 = known at compile time
+template <int ARBM = -1>
 __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, int oy0, int ox0,
                                          int n, int osh, int ph_y, int ph_x, EpiSums& S) {
-  const bool arb = k.arb_x != nullptr;
+  const bool arb = ARBM < 0 ? (k.arb_x != nullptr) : (ARBM == 1);
   const bool pool_sum = k.pool == P2L_POOL_SUM;
   // osh = 1: sub-pixel forward, this block writes phase (ph_y, ph_x) of the output buffer
   const unsigned OW = (unsigned)k.obW;
@@ -331,6 +333,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 
 // bf16x3 form of the 1x1 conv (p2l_pw.hip)
 int p2l_pw_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
+int p2l_pws_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);   // 64 / 128 input channels
 
 // Winograd F(2x2,3x3) form of the bf16x3 3x3 conv (p2l_wino.hip)
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);

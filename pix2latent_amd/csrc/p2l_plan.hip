@@ -143,6 +143,9 @@ struct BGLayout {
 
 int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   if (!m || m->n_blocks < 1 || m->n_blocks > P2L_MAX_BLOCKS || B < 1) return P2L_EINVAL;
+  // kernel choice (hence split-K workspace and activation-backward partial rows) follows the
+  // weight format: the size query and the run must lay the arena out for the same one
+  g_plan_wfmt = m->wfmt;
   Arena a;
   const int cond = m->z_dim + m->c_dim;
   L.cond = a.take((size_t)B * cond);
@@ -677,6 +680,9 @@ extern "C" size_t p2l_loss_cache_floats(int B, int H, int W, size_t nft_off[5],
 }
 
 extern "C" size_t p2l_projloss_ws_bytes(int B, int H, int W) {
+  // no descriptor here: size for the format with the largest split-K workspace (the last
+  // region of the arena; every other offset is format-independent)
+  g_plan_wfmt = P2L_WFMT_F32;
   PLLayout L;
   if (pl_layout(B, H, W, L)) return 0;
   return L.total * sizeof(float);

@@ -167,6 +167,155 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
   epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
 }
 
+
+// ---- streaming form for 64 / 128 input channels --------------------------------------------
+// The layers that EXPAND channels (BigGAN-deep conv_3 forward, conv_0 input-gradient:
+// 64->256 at 128^2, 128->512 at 64^2, 64->128 at 256^2 ...) move 4-9x more output than input
+// bytes and are HBM-bound: 75-980 MB per launch against 10 GFLOP.  What matters is HOW the
+// output rows (1-2 KB per pixel) reach DRAM.  A first version of this kernel gave a wave 32
+// pixels and let it walk over the channels 128 B at a time: every pixel row was visited 8-16
+// times, tens of microseconds apart, and the in-step time was 0.5-0.9x the exact-fp32 kernel
+// although an isolated (Infinity-Cache resident) benchmark showed 1.3-1.5x.  So:
+//
+//   * block = 32 pixels (2 image rows x 16), split ONCE into bf16x3 and staged in LDS (12 /
+//     24 KB); every wave pulls all A fragments into registers (48 / 96 VGPRs);
+//   * the 4 waves take DIFFERENT 32-channel output tiles (wave w: tiles w, w+4, ...): one
+//     sweep of the block writes 512 B contiguous per pixel, the whole row within 2-4 sweeps;
+//   * weights come straight from the packed image in L2 into B-fragment registers (the image
+//     rows ARE fragment rows), 4 sub-chunks ahead of their use; no barrier after the staging;
+//   * wave-private LDS transpose -> the shared epilogue item (16 B per lane); the per-channel
+//     sums of the fused activation backward are complete inside one wave (it saw all 32
+//     pixels): the caller's partial buffer has one row per 32-pixel block (p2l_conv_arb_nblk).
+// Same products in the same order as pw_bf3_kernel: bit-identical results.
+constexpr int PWS_EP = 36;                                // dump pitch of one 32-column tile
+
+template <int PRO, int KSUB, bool ARB>
+__global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                       // [KSUB][32 rows][96 B]
+  float* dump = smem + KSUB * 768;                        // [4 waves][32][PWS_EP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_n = k.W >> 4, per_image = tx_n * (k.H >> 1);
+  const int b0 = swz / per_image, t32 = swz - b0 * per_image;
+  const int ty = t32 / tx_n, tx = t32 - ty * tx_n;
+  const int y0 = ty * 2, x0 = tx * 16;
+
+  // ---- A: 32 pixels x Cin, quad order (row p = 4 * quad + sub-pixel), split once
+  {
+    constexpr int V4 = KSUB * 4, A_IT = 32 * V4 / 256;    // float4 per pixel; items per thread
+    f32x4 xr[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int j = tid + 256 * it;
+      const int p = j / V4, v4 = j - p * V4;
+      const int iy = y0 + ((p >> 1) & 1), ix = x0 + 2 * (p >> 2) + (p & 1);
+      xr[it] = *reinterpret_cast<const f32x4*>(
+          k.x + (size_t)((b0 * k.H + iy) * k.W + ix) * k.x_ld + v4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int j = tid + 256 * it;
+      const int p = j / V4, v4 = j - p * V4;
+      f32x4 v = xr[it];
+      if (PRO != P2L_PRO_NONE) {
+        const int so = b0 * k.pro_bstride + v4 * 4;
+        v = v * *reinterpret_cast<const f32x4*>(k.pro_s + so) +
+            *reinterpret_cast<const f32x4*>(k.pro_t + so);
+        if (PRO == P2L_PRO_AFFINE_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      pw_store_split(As + (v4 >> 2) * 768, p, v4 & 3, v);
+    }
+  }
+  __syncthreads();
+  bf16x8 a[KSUB][3];
+#pragma unroll
+  for (int sub = 0; sub < KSUB; ++sub) {
+    const float* ar = As + (sub * 32 + l31) * 24 + bf3_chunk(lhi, l31) * 4;
+    a[sub][0] = *reinterpret_cast<const bf16x8*>(ar);
+    a[sub][1] = *reinterpret_cast<const bf16x8*>(ar + 8);
+    a[sub][2] = *reinterpret_cast<const bf16x8*>(ar + 16);
+  }
+
+  // ---- B fragments from the packed image [sub][Cout/32][32 rows][96 B], ring of 4 sub-chunks
+  const int ntiles = k.Cout >> 5;
+  const float* wl = k.w + l31 * 24 + bf3_chunk(lhi, l31) * 4;
+  bf16x8 bq[4][3];
+  auto ldb = [&](int nt, int sub, bf16x8 (&b)[3]) {
+    const float* bp = wl + (size_t)(sub * ntiles + nt) * 768;
+    b[0] = *reinterpret_cast<const bf16x8*>(bp);
+    b[1] = *reinterpret_cast<const bf16x8*>(bp + 8);
+    b[2] = *reinterpret_cast<const bf16x8*>(bp + 16);
+  };
+  float* tb = dump + wave * 32 * PWS_EP;
+  const int q = lane >> 3, c4 = lane & 7;                  // epilogue item: quad q, channels 4*c4..
+  const int ox0 = x0 + 2 * q;
+  const size_t arb_slot = (size_t)b0 * k.arb_nblk + t32;
+
+  int nt = wave;
+  if (nt < ntiles) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ldb(nt, s, bq[s]);
+  }
+  for (; nt < ntiles; nt += 4) {
+    const bool more = nt + 4 < ntiles;
+    const int n0 = nt * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < KSUB; ++sub) {
+      const bf16x8 (&b)[3] = bq[sub & 3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][2], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][1], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][1], b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[0], acc, 0, 0, 0);
+      if (sub + 4 < KSUB) ldb(nt, sub + 4, bq[sub & 3]);
+      else if (more) ldb(nt + 4, sub + 4 - KSUB, bq[sub & 3]);
+    }
+    // wave-private transpose: C layout (lane = channel) -> lane = 2x2 quad x 4 channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PWS_EP + l31] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    EpiSums S;
+    const int n = n0 + c4 * 4;
+    if (n < k.n_store) {
+      f32x4 v[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * PWS_EP + c4 * 4) * k.alpha;
+      epi_item<ARB ? 1 : 0>(k, v, b0, y0, ox0, n, 0, 0, 0, S);
+    }
+    __builtin_amdgcn_wave_barrier();          // (the next tile's dump follows the reads above)
+    if (ARB) {
+      f32x4 sgx = S.sgx, sg = S.sg;
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
+        sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
+        sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
+        sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+      }
+      if (lane < 8 && n < k.n_store) {
+        const size_t o = arb_slot * k.Cout + n;
+        *reinterpret_cast<f32x4*>(k.arb_partial + o) = sgx;
+        *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + o) = sg;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
@@ -185,5 +334,26 @@ int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
   else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW(P2L_PRO_AFFINE_RELU);
   else P2L_PW(P2L_PRO_AFFINE);
 #undef P2L_PW
+  return p2l_check_launch();
+}
+
+// streaming form: one block per 32 pixels (2 rows x 16)
+int p2l_pws_launch(const ConvK& k, int pro, hipStream_t st) {
+  dim3 grid(k.B * (k.H >> 1) * (k.W >> 4)), block(256);
+  const int ksub = k.Cin / 16;
+  const size_t lds = (size_t)(ksub * 768 + 4 * 32 * PWS_EP) * sizeof(float);
+#define P2L_PWS(PRO, KSUB, ARBV)                                                             \
+  hipLaunchKernelGGL((pws_bf3_kernel<PRO, KSUB, ARBV>), grid, block, lds, st, k)
+#define P2L_PWS_K(PRO)                                                                       \
+  do {                                                                                       \
+    if (k.arb_x) { if (ksub == 4) P2L_PWS(PRO, 4, true); else P2L_PWS(PRO, 8, true); }       \
+    else { if (ksub == 4) P2L_PWS(PRO, 4, false); else P2L_PWS(PRO, 8, false); }             \
+  } while (0)
+  if (ksub != 4 && ksub != 8) return P2L_EUNSUP;
+  if (pro == P2L_PRO_NONE) P2L_PWS_K(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWS_K(P2L_PRO_AFFINE_RELU);
+  else P2L_PWS_K(P2L_PRO_AFFINE);
+#undef P2L_PWS_K
+#undef P2L_PWS
   return p2l_check_launch();
 }

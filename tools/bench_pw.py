@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from pix2latent_amd import ops as O, _native as N
 dev = 'cuda'
 CASES = [(18, 64, 256, 512), (18, 64, 512, 256), (18, 32, 1024, 256), (18, 32, 256, 1024),
-         (18, 128, 64, 256), (18, 128, 256, 64), (18, 256, 64, 128), (18, 256, 128, 64), (18, 64, 512, 64)]
+         (18, 128, 64, 256), (18, 128, 256, 64), (18, 256, 64, 128), (18, 256, 128, 64), (18, 64, 512, 64),
+         (18, 128, 128, 256), (18, 64, 128, 512), (18, 64, 64, 512), (3, 128, 64, 256), (3, 64, 128, 512)]
 for B, H, Cin, Cout in CASES:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, H, H, Cin, generator=g).to(dev)
