@@ -225,6 +225,11 @@ size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt);
  * every CU a block (default; $P2L_WINO overrides the default), 2 = every eligible shape
  * (tests: small grids too) */
 int p2l_set_wino_mode(int mode);
+/* block shape of the Winograd form: 0 = 8x16 pixels (4 waves, two blocks per CU), 1 = 16x16
+ * pixels (8 waves, split in the consumer) when that grid still fills the chip (default;
+ * $P2L_WINO16 overrides the default), 2 = 16x16 whenever H and W allow it (tests).  Both give
+ * bit-identical results. */
+int p2l_set_wino_block(int mode);
 int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
                               int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,

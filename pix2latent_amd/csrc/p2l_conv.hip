@@ -1163,12 +1163,14 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
   }
-  if (pws_shape(d)) {
+  // (forward layers only: with the fused activation backward the in-step time was 0.86x the
+  //  exact-fp32 kernel's -- its x / shortcut loads sit behind the MFMAs of a 2-wave-per-SIMD
+  //  kernel -- so those launches stay where they were)
+  if (pws_shape(d) && !arb) {
     ConvK kp = k;
     kp.w = w + (size_t)d->Cout * d->Cin;
     kp.nchunks = d->Cin / 16;
     kp.splitk = 1;
-    kp.arb_nblk = (d->H >> 1) * (d->W >> 4);      // one partial row per 32-pixel block
     rc = p2l_pws_launch(kp, d->pro, st);
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
@@ -1306,7 +1308,6 @@ extern "C" int p2l_conv_arb_fusable(const P2LConv* d) {
 extern "C" int p2l_conv_arb_nblk(const P2LConv* d) {
   ConvK k{};
   if (!d || choose_tile(d, k) != P2L_OK) return 0;
-  if (pws_shape(d)) return (d->H >> 1) * (d->W >> 4);   // 32-pixel blocks
   return k.n_mtiles / d->B;
 }
 

@@ -183,13 +183,12 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
 //     sweep of the block writes 512 B contiguous per pixel, the whole row within 2-4 sweeps;
 //   * weights come straight from the packed image in L2 into B-fragment registers (the image
 //     rows ARE fragment rows), 4 sub-chunks ahead of their use; no barrier after the staging;
-//   * wave-private LDS transpose -> the shared epilogue item (16 B per lane); the per-channel
-//     sums of the fused activation backward are complete inside one wave (it saw all 32
-//     pixels): the caller's partial buffer has one row per 32-pixel block (p2l_conv_arb_nblk).
+//   * wave-private LDS transpose -> the shared epilogue item (16 B per lane).
+// Forward epilogues only (bias / residual / activation / mask / pooling).
 // Same products in the same order as pw_bf3_kernel: bit-identical results.
 constexpr int PWS_EP = 36;                                // dump pitch of one 32-column tile
 
-template <int PRO, int KSUB, bool ARB>
+template <int PRO, int KSUB>
 __global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                       // [KSUB][32 rows][96 B]
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
   float* tb = dump + wave * 32 * PWS_EP;
   const int q = lane >> 3, c4 = lane & 7;                  // epilogue item: quad q, channels 4*c4..
   const int ox0 = x0 + 2 * q;
-  const size_t arb_slot = (size_t)b0 * k.arb_nblk + t32;
 
   int nt = wave;
   if (nt < ntiles) {
@@ -295,24 +293,9 @@ __global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * PWS_EP + c4 * 4) * k.alpha;
-      epi_item<ARB ? 1 : 0>(k, v, b0, y0, ox0, n, 0, 0, 0, S);
+      epi_item<0>(k, v, b0, y0, ox0, n, 0, 0, 0, S);
     }
     __builtin_amdgcn_wave_barrier();          // (the next tile's dump follows the reads above)
-    if (ARB) {
-      f32x4 sgx = S.sgx, sg = S.sg;
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
-        sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
-        sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
-        sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
-      }
-      if (lane < 8 && n < k.n_store) {
-        const size_t o = arb_slot * k.Cout + n;
-        *reinterpret_cast<f32x4*>(k.arb_partial + o) = sgx;
-        *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + o) = sg;
-      }
-    }
   }
 }
 
@@ -342,13 +325,9 @@ int p2l_pws_launch(const ConvK& k, int pro, hipStream_t st) {
   dim3 grid(k.B * (k.H >> 1) * (k.W >> 4)), block(256);
   const int ksub = k.Cin / 16;
   const size_t lds = (size_t)(ksub * 768 + 4 * 32 * PWS_EP) * sizeof(float);
-#define P2L_PWS(PRO, KSUB, ARBV)                                                             \
-  hipLaunchKernelGGL((pws_bf3_kernel<PRO, KSUB, ARBV>), grid, block, lds, st, k)
-#define P2L_PWS_K(PRO)                                                                       \
-  do {                                                                                       \
-    if (k.arb_x) { if (ksub == 4) P2L_PWS(PRO, 4, true); else P2L_PWS(PRO, 8, true); }       \
-    else { if (ksub == 4) P2L_PWS(PRO, 4, false); else P2L_PWS(PRO, 8, false); }             \
-  } while (0)
+#define P2L_PWS(PRO, KSUB) hipLaunchKernelGGL((pws_bf3_kernel<PRO, KSUB>), grid, block, lds, st, k)
+#define P2L_PWS_K(PRO) do { if (ksub == 4) P2L_PWS(PRO, 4); else P2L_PWS(PRO, 8); } while (0)
+  if (k.arb_x) return P2L_EUNSUP;
   if (ksub != 4 && ksub != 8) return P2L_EUNSUP;
   if (pro == P2L_PRO_NONE) P2L_PWS_K(P2L_PRO_NONE);
   else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWS_K(P2L_PRO_AFFINE_RELU);

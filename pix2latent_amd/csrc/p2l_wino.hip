@@ -273,6 +273,289 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
   }
 }
 
+// ---- 16x16-pixel blocks, 8 waves -----------------------------------------------------------
+// The 8x16-pixel kernel above fetches the chunk's whole transform-domain weight slice (96 KB
+// for 64 output channels) once per 32 tiles: with two blocks per CU that alone is ~64 B/clk,
+// the L2 -> L1 rate of a CU, and PMC showed its phases (weight wait | transform + split | MFMA)
+// running one after the other: MFMA pipe 26-34 % busy.  This form doubles the tiles per block
+// and reorganises the phases so that they overlap:
+//   * block = 16x16 output pixels = 64 tiles (2 M-tiles) x 64 output channels, 8 waves; wave w
+//     owns frequencies 2w, 2w+1: 2 freq x 2 M x 2 N accumulators (128 VGPR).  A weight
+//     fragment now serves two M-tiles: half the L2 traffic per product;
+//   * the transformed input V stays FP32 in LDS ([frequency][tile][16 channels], 64 KB, double
+//     buffered) and is split into bf16 pieces by its CONSUMER: each (frequency, M-tile)
+//     fragment is read by exactly one wave, so the split costs the same VALU work as before
+//     but now sits between that wave's MFMAs instead of in a separate phase;
+//   * waves 0-3 transform chunk c+1 and then multiply chunk c, waves 4-7 do it the other way
+//     round: waves w and w+4 share a SIMD, so its VALU and its matrix pipe are busy at the
+//     same time.  Two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
+// Same additions and products in the same order as the 8x16 kernel: bit-identical results,
+// so which of the two runs is a pure performance choice (p2l_wino_launch).
+constexpr int W16_THREADS = 512;
+constexpr int W16_RAW_ROWS = 18 * 18;
+constexpr int W16_RAW_FLOATS = W16_RAW_ROWS * WN_RAW_PITCH;            // 31,104 B
+constexpr int W16_V_FLOATS = 16 * 64 * 16;                            // one buffer: 64 KB
+constexpr size_t W16_LDS_BYTES = (size_t)(W16_RAW_FLOATS + 2 * W16_V_FLOATS) * sizeof(float);
+static_assert(W16_LDS_BYTES <= 160 * 1024, "one block per CU");
+static_assert(16 * 64 * WN_DUMP_PITCH <= 2 * W16_V_FLOATS, "epilogue dump fits");
+
+template <int PRO>
+__global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* raw = smem;
+  float* Vs = smem + W16_RAW_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
+  const int tiles_per_image = k.tiles_x * k.tiles_y;                  // 16x16-pixel tiles
+  const int b = mt / tiles_per_image;
+  const int tile_in_image = mt - b * tiles_per_image;
+  const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
+  const int y0 = by * 16, x0 = bx * 16, n0 = nt * 64;
+
+  // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
+  constexpr int A_ITERS = 3;
+  const int sv = tid & 3;
+  int a_goff[A_ITERS], a_loff[A_ITERS];
+  unsigned a_valid = 0;
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int p = (tid + W16_THREADS * it) >> 2;
+    a_goff[it] = 0;
+    a_loff[it] = (p < W16_RAW_ROWS) ? p * WN_RAW_PITCH + sv * 4 : -1;
+    if (p < W16_RAW_ROWS) {
+      const int hy = p / 18, hx = p - hy * 18;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
+        a_goff[it] = ((b * k.H + iy) * k.W + ix) * k.x_ld + sv * 4;
+        a_valid |= 1u << it;
+      }
+    }
+  }
+  const int s_off = b * k.pro_bstride + sv * 4;
+  f32x4 xr[A_ITERS], sr, tr;
+  auto load_raw = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + c * 16);
+    if (PRO != P2L_PRO_NONE) {
+      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + c * 16);
+      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + c * 16);
+    }
+  };
+  auto write_raw = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      if (a_loff[it] < 0) continue;
+      f32x4 v = xr[it];
+      if (PRO != P2L_PRO_NONE) {
+        v = v * sr + tr;
+        if (PRO == P2L_PRO_AFFINE_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(raw + a_loff[it]) = v;
+    }
+  };
+
+  // ---- input transform item: (half h, tile tt of 64, channel quad tv) --------------------
+  // V row (frequency f, tile t) holds 16 channels = four 16-byte slots; slot s of a row lives
+  // at s ^ ((t >> 2) & 3): the consumer's ds_read_b128 lane groups then hit 16 distinct slots
+  const int th = tid >> 8, tt = (tid >> 2) & 63, tv = tid & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
+  const int t_dst = tt * 16 + ((tv ^ ((tt >> 2) & 3)) << 2);
+  auto transform = [&](float* Vn) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int fr = 2 * th + i;
+      const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
+      const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
+      const float sb = (fr == 1) ? 1.f : -1.f;
+      f32x4 R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c) * WN_RAW_PITCH);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c) * WN_RAW_PITCH);
+        R[c] = a + sb * bq;
+      }
+      float* d = Vn + fr * 4 * 1024 + t_dst;
+      *reinterpret_cast<f32x4*>(d) = R[0] - R[2];
+      *reinterpret_cast<f32x4*>(d + 1024) = R[1] + R[2];
+      *reinterpret_cast<f32x4*>(d + 2048) = R[2] - R[1];
+      *reinterpret_cast<f32x4*>(d + 3072) = R[1] - R[3];
+    }
+  };
+
+  // ---- weight fragments: global -> registers, one frequency ahead -------------------------
+  const int n_t32 = k.Cout >> 5;
+  const f32x4* wq = reinterpret_cast<const f32x4*>(k.w);
+  f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
+  auto load_b = [&](int c, int fi, int set) {
+    const size_t base = (((size_t)c * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * 3 * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bw[set][j][p] = wq[base + (size_t)(j * 3 + p) * 64];
+  };
+
+  f32x16 acc[2][2][2];                                 // [freq][M-tile][N-tile]
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fi][m][j][r] = 0.f;
+
+  // ---- multiply phase of one chunk: fragments (fi, m), read fp32, split, 12 MFMAs ----------
+  const int a_sw = (l31 >> 2) & 3;
+  const int a_off0 = l31 * 16 + (((lhi * 2) ^ a_sw) << 2), a_off1 = l31 * 16 + (((lhi * 2 + 1) ^ a_sw) << 2);
+  auto multiply = [&](const float* Vc, int c, bool more) {
+    f32x4 ar[2][2];
+    auto lda = [&](int s, f32x4 (&q)[2]) {
+      const float* rowp = Vc + ((2 * wave + (s >> 1)) * 64 + (s & 1) * 32) * 16;
+      q[0] = *reinterpret_cast<const f32x4*>(rowp + a_off0);
+      q[1] = *reinterpret_cast<const f32x4*>(rowp + a_off1);
+    };
+    lda(0, ar[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int fi = s >> 1, m = s & 1;
+      if (s == 0) load_b(c, 1, 1);
+      else if (s == 2 && more) load_b(c + 1, 0, 0);
+      if (s + 1 < 4) lda(s + 1, ar[(s + 1) & 1]);
+      bf16x4 h[2], md[2], lo[2];
+      split3(ar[s & 1][0], h[0], md[0], lo[0]);
+      split3(ar[s & 1][1], h[1], md[1], lo[1]);
+      const bf16x8 a1 = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 a2 = __builtin_shufflevector(md[0], md[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8 a3 = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi][j][0]);
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[fi][j][1]);
+        const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[fi][j][2]);
+        f32x16 t = acc[fi][m][j];                       // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
+        acc[fi][m][j] = t;
+      }
+    }
+  };
+
+  const int nchunks = k.nchunks;
+  const bool mul_first = wave >= 4;
+  load_raw(0);
+  load_b(0, 0, 0);
+  write_raw();
+  __syncthreads();
+  if (nchunks > 1) load_raw(1);
+  transform(Vs);
+  __syncthreads();
+  if (nchunks > 1) { write_raw(); if (nchunks > 2) load_raw(2); }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
+    float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
+    if (mul_first) {
+      multiply(Vc, c, more);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) transform(Vn);
+    } else {
+      if (more) transform(Vn);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(Vc, c, more);
+    }
+    __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
+    if (c + 2 < nchunks) {
+      write_raw();
+      if (c + 3 < nchunks) load_raw(c + 3);
+    }
+    __syncthreads();                    // patch of chunk c+2 visible
+  }
+
+  // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..63][32 channels] ----------
+  float* dump = Vs;
+  const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
+  const int ety = e_t >> 3, etx = e_t & 7;
+  float* red = raw;                                      // [2 kinds][8 waves][32]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          dump[((2 * wave + fi) * 64 + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
+        }
+    __syncthreads();
+    const int nb = n0 + j * 32;
+    EpiSums S;
+    if (nb + e_c4 * 4 < k.n_store) {
+      f32x4 T[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {                  // A^T M, column jj
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        T[0][jj] = (m0 + m1) + m2;
+        T[1][jj] = (m1 - m2) - m3;
+      }
+      f32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                     // (A^T M) A
+        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
+        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
+      }
+      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
+    }
+    if (k.arb_x != nullptr) {
+      // waves 0-3 hold the upper 8x16-pixel tile of the caller's 128-pixel tiling, waves 4-7 the
+      // lower one: same shuffle / wave order as epi_arb_reduce (bit-identical partial sums)
+      f32x4 sgx = S.sgx, sg = S.sg;
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
+        sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
+        sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
+        sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+      }
+      if (lane < 8) {
+        *reinterpret_cast<f32x4*>(red + wave * 32 + lane * 4) = sgx;
+        *reinterpret_cast<f32x4*>(red + 256 + wave * 32 + lane * 4) = sg;
+      }
+      __syncthreads();
+      if (tid < 64 && nb + (tid & 31) < k.n_store) {
+        const int g = tid >> 5, col = tid & 31;
+        const float* r0 = red + g * 128 + col;
+        const float s0 = (r0[0] + r0[32]) + (r0[64] + r0[96]);
+        const float s1 = (r0[256] + r0[288]) + (r0[320] + r0[352]);
+        const size_t slot = (size_t)b * k.arb_nblk + (size_t)(2 * by + g) * k.tiles_x + bx;
+        const size_t o = slot * k.Cout + nb + col;
+        k.arb_partial[o] = s0;
+        k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
+      }
+    }
+    __syncthreads();                                   // dump / red are rewritten by the next pass
+  }
+}
+
 // ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
 __global__ void wino_pack_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
                                  int transpose_flip) {
@@ -336,10 +619,45 @@ int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int t
   return p2l_check_launch();
 }
 
-// (bn = 64 or 128 output channels per block: the launcher passes n_ntiles = Cout / bn)
+static int g_wino16_mode = -1;       // $P2L_WINO16: 0 = never, 1 = by grid size, 2 = whenever the shape allows
+static int wino16_mode() {
+  if (g_wino16_mode < 0) { const char* e = getenv("P2L_WINO16"); g_wino16_mode = e ? atoi(e) : 1; }
+  return g_wino16_mode;
+}
+extern "C" int p2l_set_wino_block(int mode) {
+  if (mode < 0 || mode > 2) return P2L_EINVAL;
+  g_wino16_mode = mode;
+  return P2L_OK;
+}
+
+// k arrives with the 8x16-pixel tiling (tiles_x = W/16, tiles_y = H/8, n_mtiles, n_ntiles =
+// Cout/64).  Layers whose 16x16-pixel grid still fills the chip run the 8-wave kernel; both
+// give bit-identical results.
 int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   ConvK k = k_in;
   { const char* e = getenv("P2L_ABL"); k.abl = e ? atoi(e) : 0; }
+  const int mode = wino16_mode();
+  const long blocks16 = (long)k.B * (k.H / 16) * (k.W / 16) * k.n_ntiles;
+  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || blocks16 >= 512)) {
+    k.tiles_y = k.H / 16;
+    k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
+    dim3 grid(k.n_mtiles * k.n_ntiles), block(W16_THREADS);
+#define P2L_W16(PRO)                                                                         \
+  do {                                                                                       \
+    static bool attr_set = false;                                                            \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)wino16_conv_kernel<PRO>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(wino16_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);          \
+  } while (0)
+    if (pro == P2L_PRO_NONE) P2L_W16(P2L_PRO_NONE);
+    else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16(P2L_PRO_AFFINE_RELU);
+    else P2L_W16(P2L_PRO_AFFINE);
+#undef P2L_W16
+    return p2l_check_launch();
+  }
   dim3 grid(k.n_mtiles * k.n_ntiles), block(WN_THREADS);
 #define P2L_WN(PRO)                                                                          \
   do {                                                                                       \

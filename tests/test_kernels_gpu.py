@@ -79,13 +79,25 @@ CONV_CASES = [
 # P2L_WFMT_F32 (exact fp32 MFMA), P2L_WFMT_BF16X3 (3-way bf16 split, 6 products, direct kernel),
 # P2L_WFMT_BF16X3W (same arithmetic; eligible shapes run in the Winograd F(2x2,3x3) form)
 # P2L_WFMT_PW (1x1 convs: fp32 layout + bf16x3 image; layers >= 32x32 run in the bf16x3 arithmetic)
-WFMTS = [0, 1, 2, 3]
-WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd', 'pw-bf16x3']
+# (4 = P2L_WFMT_BF16X3W again, with the 16x16-pixel / 8-wave Winograd kernel forced wherever H, W allow)
+WFMTS = [0, 1, 2, 3, 4]
+WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd', 'pw-bf16x3', 'bf16x3-winograd16']
 
 
-def _skip_unless_format_applies(wfmt, taps):
-    if (taps == 9 and wfmt == 3) or (taps != 9 and wfmt in (1, 2)):
+def _skip_unless_format_applies(wfmt, taps, H=None, ups=False):
+    if (taps == 9 and wfmt == 3) or (taps != 9 and wfmt in (1, 2, 4)):
         pytest.skip('weight format does not apply to this kernel size')
+    if wfmt == 4 and (ups or H is None or H % 16):
+        pytest.skip('the 16x16-pixel Winograd kernel does not take this shape')
+
+
+def _fmt(wfmt):
+    """test id 4 -> the real weight format (2) with the 16x16-pixel block shape forced"""
+    if wfmt == 4:
+        from pix2latent_amd import _native as N
+        N.check(N.lib().p2l_set_wino_block(2))
+        return 2
+    return wfmt
 
 
 @pytest.fixture(autouse=True)
@@ -94,8 +106,10 @@ def _force_winograd_for_small_grids(dev):
     shapes are small, so force it for every eligible shape and restore the default after"""
     from pix2latent_amd import _native as N
     N.check(N.lib().p2l_set_wino_mode(2))
+    N.check(N.lib().p2l_set_wino_block(0))
     yield
     N.check(N.lib().p2l_set_wino_mode(1))
+    N.check(N.lib().p2l_set_wino_block(1))
 
 
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
@@ -104,7 +118,8 @@ def test_conv_fwd(dev, O, case, wfmt):
     """both weight formats must meet the SAME tolerance: bf16x3 is an fp32-equivalent
     arithmetic (include/p2l.h P2L_WFMT_BF16X3), not a reduced-precision mode"""
     from pix2latent_amd import _native as N
-    _skip_unless_format_applies(wfmt, case['taps'])
+    _skip_unless_format_applies(wfmt, case['taps'], case['H'], case.get('ups', False))
+    wfmt = _fmt(wfmt)
     g = torch.Generator().manual_seed(1)
     B, H, Cin, Cout, taps = case['B'], case['H'], case['Cin'], case['Cout'], case['taps']
     k = 3 if taps == 9 else 1
@@ -175,7 +190,7 @@ def test_conv_fwd(dev, O, case, wfmt):
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 @pytest.mark.parametrize('Cin,Cout', [(64, 64), (128, 96)])
 def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
-    _skip_unless_format_applies(wfmt, 9)
+    _skip_unless_format_applies(wfmt, 9, None, True)
     """3x3 conv on a nearest-x2 upsampled input in sub-pixel form (ups=2) and its
     input-gradient (ups=3) against F.interpolate + F.conv2d and autograd."""
     from pix2latent_amd import _native as N
@@ -203,7 +218,7 @@ def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
 
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
-    _skip_unless_format_applies(wfmt, 9)
+    _skip_unless_format_applies(wfmt, 9, None, True)
     g = torch.Generator().manual_seed(14)
     B, C, Co, h = 2, 64, 64, 16
     x = torch.randn(B, C, h, h, generator=g, requires_grad=True)
@@ -274,7 +289,8 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk)
         sk = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g)
         exp_dx[:, :C // 2] += F.avg_pool2d(sk, 2, 2) * 4
         sk_t, skip_C = nhwc(sk, dev), C // 2
-    _skip_unless_format_applies(wfmt, taps)
+    _skip_unless_format_applies(wfmt, taps, Ho, False)
+    wfmt = _fmt(wfmt)
     wt = O.pack_conv_weight(w.to(dev), taps, C, Co, flip=True, wfmt=wfmt)
     dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, Ho, Ho, Co, C, taps, nhwc(x.detach(), dev),
                                   s.detach().to(dev), t.detach().to(dev), C, pool_sum=ups, wfmt=wfmt,
@@ -317,6 +333,40 @@ def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip, C, Co):
     assert relerr(nchw(dx), exp_dx) < 2e-5
     assert relerr(ds.cpu(), s.grad) < 5e-5
     assert relerr(dt.cpu(), t.grad) < 5e-5
+
+
+@pytest.mark.parametrize('arb', [False, True], ids=['forward', 'dgrad-fused-arb'])
+def test_winograd_block_shapes_bit_identical(dev, O, arb):
+    """the 8x16-pixel / 4-wave and the 16x16-pixel / 8-wave Winograd kernels do the same
+    additions and products in the same order: which one a launch gets (a grid-size decision,
+    hence batch dependent) must not change a single bit of the result"""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(21)
+    B, H, Cin, Cout = 3, 32, 48, 128
+    outs = []
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+    s = (0.5 + torch.rand(B, Cout if arb else Cin, generator=g)).to(dev)
+    t = (0.3 * torch.randn(B, Cout if arb else Cin, generator=g)).to(dev)
+    bias = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+    res = torch.randn(B, H, H, Cout, generator=g).to(dev)
+    xa = torch.randn(B, H, H, Cout, generator=g).to(dev)
+    for block in (0, 2):
+        N.check(N.lib().p2l_set_wino_block(block))
+        if not arb:
+            wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=2)
+            y, _ = O.conv(x, wp, B, H, H, Cin, Cout, 9, wfmt=2, bias=bias, pro=N.PRO_AFFINE_RELU,
+                          pro_s=s, pro_t=t, pro_bstride=Cin, res=res, alpha=0.5)
+            outs.append((y.clone(),))
+        else:
+            # input-gradient form Cin -> Cout of a conv Cout -> Cin, fused backward of relu(xa*s+t)
+            wt = O.pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), 9, Cout, Cin, flip=True, wfmt=2)
+            dx, ds, dt = O.conv_dgrad_arb(x, wt, B, H, H, Cin, Cout, 9, xa, s, t, Cout, wfmt=2,
+                                          skip=res, skip_C=Cout)
+            outs.append((dx.clone(), ds.clone(), dt.clone()))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_arb_finish_deferred_group(dev, O):

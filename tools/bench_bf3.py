@@ -16,7 +16,8 @@ for B, H, Cin, Cout in CASES:
     s = (0.5 + torch.rand(B, Cin, generator=g)).to(dev)
     t = (0.3 * torch.randn(B, Cin, generator=g)).to(dev)
     res = {}
-    for name, wf in (('f32', 0), ('bf16x3', 1), ('wino', 2)):
+    for name, wf, blk in (('f32', 0, 1), ('bf16x3', 1, 1), ('wino', 2, 0), ('wino16', 2, 2)):
+        N.check(N.lib().p2l_set_wino_block(blk))
         wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=wf)
         for _ in range(3):
             y, _ = O.conv(x, wp, B, H, H, Cin, Cout, 9, pro=N.PRO_AFFINE_RELU, pro_s=s, pro_t=t,
@@ -35,9 +36,9 @@ for B, H, Cin, Cout in CASES:
     ref = F.conv2d(a.permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
     fl = 2.0 * B * H * H * Cin * Cout * 9
     out = '%2dx%3d^2 %3d->%3d:' % (B, H, Cin, Cout)
-    for name in ('f32', 'bf16x3', 'wino'):
+    for name in ('f32', 'bf16x3', 'wino', 'wino16'):
         y, ms = res[name]
         err = (y[:nb].double() - ref).abs().max().item() / ref.abs().max().item()
-        out += '  %s %.3f ms %5.0f TF err %.1e' % (name, ms, fl / ms / 1e9, err)
-    out += '  wino/direct %.2fx' % (res['bf16x3'][1] / res['wino'][1])
+        out += '  %s %.3f ms %4.0f TF %.0e' % (name, ms, fl / ms / 1e9, err)
+    out += '  wino/direct %.2fx  wino16/wino %.2fx' % (res['bf16x3'][1] / res['wino'][1], res['wino'][1] / res['wino16'][1])
     print(out)
