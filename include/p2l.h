@@ -230,6 +230,9 @@ int p2l_set_wino_mode(int mode);
  * $P2L_WINO16 overrides the default), 2 = 16x16 whenever H and W allow it (tests).  Both give
  * bit-identical results. */
 int p2l_set_wino_block(int mode);
+/* diagnostics: device buffer (8 waves x 64 chunks x 8 uint64) that one block of every following
+ * 16x16-pixel Winograd launch fills with s_memtime stamps of its phase boundaries; NULL = off */
+int p2l_wino_set_trace(void* buf);
 int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
                               int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,

@@ -178,7 +178,7 @@ EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
-    'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode', 'p2l_set_wino_block',
+    'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode', 'p2l_set_wino_block', 'p2l_wino_set_trace',
     'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',

@@ -79,12 +79,40 @@ __device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
 // apart in LDS (ConvK::hp; a rotation over all 6 chunks was tried: 46 % conflicts).
 __device__ __forceinline__ int bf3_chunk(int c, int row) { return c ^ ((row >> 3) & 1); }
 
+// x = h + m + l with three round-to-nearest bf16 pieces.  Written on PAIRS so that every step is
+// one packed instruction per two values (4.5 VALU per value instead of the 7.5 hipcc emits for
+// the element-wise form): v_cvt_pk_bf16_f32, shift / mask back to fp32, packed subtraction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 widen2(const bf16x2 p) {
+  const unsigned u = __builtin_bit_cast(unsigned, p);
+  return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+// a - b on two values in one instruction (hipcc turns every vector subtraction, and fma(b, -1, a),
+// into scalar v_sub_f32; only additions get packed)
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
+  const f32x2 lo = pk_sub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = pk_sub(f32x2{a.z, a.w}, f32x2{b.z, b.w});
+  return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void split3_pair(const f32x2 v, bf16x2& h, bf16x2& m, bf16x2& l) {
+  h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = pk_sub(v, widen2(h));
+  m = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = pk_sub(r1, widen2(m));
+  l = __builtin_convertvector(r2, bf16x2);
+}
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-  h = __builtin_convertvector(v, bf16x4);
-  const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
-  m = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-  l = __builtin_convertvector(r2, bf16x4);
+  bf16x2 h0, m0, l0, h1, m1, l1;
+  split3_pair(f32x2{v.x, v.y}, h0, m0, l0);
+  split3_pair(f32x2{v.z, v.w}, h1, m1, l1);
+  h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+  m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3);
+  l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

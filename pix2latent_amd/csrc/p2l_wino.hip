@@ -377,19 +377,18 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
       const int fr = 2 * th + i;
       const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
       const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
-      const float sb = (fr == 1) ? 1.f : -1.f;
       f32x4 R[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c) * WN_RAW_PITCH);
         const f32x4 bq = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c) * WN_RAW_PITCH);
-        R[c] = a + sb * bq;
+        R[c] = (fr == 1) ? a + bq : sub4(a, bq);
       }
       float* d = Vn + fr * 4 * 1024 + t_dst;
-      *reinterpret_cast<f32x4*>(d) = R[0] - R[2];
+      *reinterpret_cast<f32x4*>(d) = sub4(R[0], R[2]);
       *reinterpret_cast<f32x4*>(d + 1024) = R[1] + R[2];
-      *reinterpret_cast<f32x4*>(d + 2048) = R[2] - R[1];
-      *reinterpret_cast<f32x4*>(d + 3072) = R[1] - R[3];
+      *reinterpret_cast<f32x4*>(d + 2048) = sub4(R[2], R[1]);
+      *reinterpret_cast<f32x4*>(d + 3072) = sub4(R[1], R[3]);
     }
   };
 
@@ -457,6 +456,11 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
 
   const int nchunks = k.nchunks;
   const bool mul_first = wave >= 4;
+  // phase timestamps of one block (diagnostics: p2l_wino_set_trace)
+  unsigned long long* trace =
+      (k.ws != nullptr && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
+#define P2L_TR(SLOT, C)                                                                      \
+  if (trace != nullptr && lane == 0 && (C) < 64) trace[(wave * 64 + (C)) * 8 + (SLOT)] = __builtin_amdgcn_s_memtime()
   load_raw(0);
   load_b(0, 0, 0);
   write_raw();
@@ -470,22 +474,30 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
     const bool more = c + 1 < nchunks;
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
+    P2L_TR(0, c);
     if (mul_first) {
       multiply(Vc, c, more);
       __builtin_amdgcn_sched_barrier(0);
+      P2L_TR(1, c);
       if (more) transform(Vn);
     } else {
       if (more) transform(Vn);
       __builtin_amdgcn_sched_barrier(0);
+      P2L_TR(1, c);
       multiply(Vc, c, more);
     }
+    P2L_TR(2, c);
     __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
+    P2L_TR(3, c);
     if (c + 2 < nchunks) {
       write_raw();
       if (c + 3 < nchunks) load_raw(c + 3);
     }
+    P2L_TR(4, c);
     __syncthreads();                    // patch of chunk c+2 visible
   }
+  P2L_TR(5, 0);
+#undef P2L_TR
 
   // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..63][32 channels] ----------
   float* dump = Vs;
@@ -624,6 +636,13 @@ static int wino16_mode() {
   if (g_wino16_mode < 0) { const char* e = getenv("P2L_WINO16"); g_wino16_mode = e ? atoi(e) : 1; }
   return g_wino16_mode;
 }
+static void* g_wino_trace = nullptr;
+// diagnostics: device buffer of 8 waves x 64 chunks x 8 uint64 that ONE block of every following
+// 16x16-pixel launch fills with s_memtime stamps of its phase boundaries (nullptr = off)
+extern "C" int p2l_wino_set_trace(void* buf) {
+  g_wino_trace = buf;
+  return P2L_OK;
+}
 extern "C" int p2l_set_wino_block(int mode) {
   if (mode < 0 || mode > 2) return P2L_EINVAL;
   g_wino16_mode = mode;
@@ -641,6 +660,7 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || blocks16 >= 512)) {
     k.tiles_y = k.H / 16;
     k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
+    k.ws = (float*)g_wino_trace;
     dim3 grid(k.n_mtiles * k.n_ntiles), block(W16_THREADS);
 #define P2L_W16(PRO)                                                                         \
   do {                                                                                       \

@@ -6,6 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_wino -o c -- python $R/tools/conv_probe.py > $R/gpurun_out/pmc_wino.log 2>&1
+rocprofv3 --list-avail > $R/gpurun_out/pmc_avail.txt 2>&1
 cd $R
 python - <<'PY' | tee gpurun_out/pmc_wino.txt
 import csv, glob, collections
@@ -15,7 +16,7 @@ by = collections.OrderedDict()
 for r in rows:
     n = r['Kernel_Name']
     if 'conv_mfma' not in n and 'wino_conv' not in n: continue
-    key = (int(r['Dispatch_Id']), ('wino' if 'wino' in n else 'direct'), r['Grid_Size'])
+    key = (int(r['Dispatch_Id']), ('wino16' if 'wino16' in n else 'wino8' if 'wino' in n else 'direct'), r['Grid_Size'])
     by.setdefault(key, {})[r['Counter_Name']] = float(r['Counter_Value'])
 print('disp kind grid  mfma_busy parked issue_stall issuing valu_share lds_busy lds_conf clk(GUI cycles)')
 for k, v in sorted(by.items()):
