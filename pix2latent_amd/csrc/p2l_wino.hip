@@ -286,9 +286,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
 //     buffered) and is split into bf16 pieces by its CONSUMER: each (frequency, M-tile)
 //     fragment is read by exactly one wave, so the split costs the same VALU work as before
 //     but now sits between that wave's MFMAs instead of in a separate phase;
-//   * waves 0-3 transform chunk c+1 and then multiply chunk c, waves 4-7 do it the other way
-//     round: waves w and w+4 share a SIMD, so its VALU and its matrix pipe are busy at the
-//     same time.  Two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
+//   * the transform of chunk c+1 is cut into four parts that follow the four MFMA groups of
+//     chunk c in every wave's instruction stream (a first version ran the two waves of a SIMD
+//     in opposite phase order instead: the phase trace -- p2l_wino_set_trace -- showed the
+//     multiply phases colliding on the pipe and 28 % of the chunk period without any MFMA).
+//     Two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
 // Same additions and products in the same order as the 8x16 kernel: bit-identical results,
 // so which of the two runs is a pure performance choice (p2l_wino_launch).
 constexpr int W16_THREADS = 512;
@@ -367,29 +369,43 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
   // ---- input transform item: (half h, tile tt of 64, channel quad tv) --------------------
   // V row (frequency f, tile t) holds 16 channels = four 16-byte slots; slot s of a row lives
   // at s ^ ((t >> 2) & 3): the consumer's ds_read_b128 lane groups then hit 16 distinct slots
-  const int th = tid >> 8, tt = (tid >> 2) & 63, tv = tid & 3;
+  const int th = __builtin_amdgcn_readfirstlane(tid >> 8);   // (wave-uniform: no exec-masked branches)
+  const int tt = (tid >> 2) & 63, tv = tid & 3;
   const int tty = tt >> 3, ttx = tt & 7;
   const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
   const int t_dst = tt * 16 + ((tv ^ ((tt >> 2) & 3)) << 2);
+  // the transform of one chunk in four parts (two frequency rows x two halves) so that it can
+  // sit between the MFMA groups of the previous chunk: part (i, 0) loads patch columns 0 and 2
+  // and emits frequency 4*fr+0, part (i, 1) loads columns 1 and 3 and emits the other three
+  f32x4 tq[4];                                          // loads in flight
+  f32x4 tR2;                                            // R[2] of the current frequency row
+  auto t_load = [&](int part) {
+    const int fr = 2 * th + (part >> 1);
+    const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
+    const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
+    const int c0 = part & 1;                            // columns c0, c0 + 2
+    tq[0] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0) * WN_RAW_PITCH);
+    tq[1] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0) * WN_RAW_PITCH);
+    tq[2] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0 + 2) * WN_RAW_PITCH);
+    tq[3] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0 + 2) * WN_RAW_PITCH);
+  };
+  auto t_emit = [&](int part, float* Vn) {
+    const int fr = 2 * th + (part >> 1);
+    float* d = Vn + fr * 4 * 1024 + t_dst;
+    const f32x4 Ra = (fr == 1) ? tq[0] + tq[1] : sub4(tq[0], tq[1]);     // column c0
+    const f32x4 Rb = (fr == 1) ? tq[2] + tq[3] : sub4(tq[2], tq[3]);     // column c0 + 2
+    if ((part & 1) == 0) {                              // R[0], R[2]
+      *reinterpret_cast<f32x4*>(d) = sub4(Ra, Rb);
+      tR2 = Rb;
+    } else {                                            // R[1], R[3]
+      *reinterpret_cast<f32x4*>(d + 1024) = Ra + tR2;
+      *reinterpret_cast<f32x4*>(d + 2048) = sub4(tR2, Ra);
+      *reinterpret_cast<f32x4*>(d + 3072) = sub4(Ra, Rb);
+    }
+  };
   auto transform = [&](float* Vn) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int fr = 2 * th + i;
-      const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
-      const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
-      f32x4 R[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c) * WN_RAW_PITCH);
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c) * WN_RAW_PITCH);
-        R[c] = (fr == 1) ? a + bq : sub4(a, bq);
-      }
-      float* d = Vn + fr * 4 * 1024 + t_dst;
-      *reinterpret_cast<f32x4*>(d) = sub4(R[0], R[2]);
-      *reinterpret_cast<f32x4*>(d + 1024) = R[1] + R[2];
-      *reinterpret_cast<f32x4*>(d + 2048) = sub4(R[2], R[1]);
-      *reinterpret_cast<f32x4*>(d + 3072) = sub4(R[1], R[3]);
-    }
+    for (int part = 0; part < 4; ++part) { t_load(part); t_emit(part, Vn); }
   };
 
   // ---- weight fragments: global -> registers, one frequency ahead -------------------------
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
   // ---- multiply phase of one chunk: fragments (fi, m), read fp32, split, 12 MFMAs ----------
   const int a_sw = (l31 >> 2) & 3;
   const int a_off0 = l31 * 16 + (((lhi * 2) ^ a_sw) << 2), a_off1 = l31 * 16 + (((lhi * 2 + 1) ^ a_sw) << 2);
-  auto multiply = [&](const float* Vc, int c, bool more) {
+  auto multiply = [&](const float* Vc, float* Vn, int c, bool more) {
     f32x4 ar[2][2];
     auto lda = [&](int s, f32x4 (&q)[2]) {
       const float* rowp = Vc + ((2 * wave + (s >> 1)) * 64 + (s & 1) * 32) * 16;
@@ -451,11 +467,14 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
         acc[fi][m][j] = t;
       }
+      // the patch of chunk c+1 was rewritten right after the previous barrier: every wave is
+      // long past that by now, and this step's MFMAs keep the pipe busy while the barrier fills
+      if (s == 0) __syncthreads();
+      if (more) { t_load(s); t_emit(s, Vn); }
     }
   };
 
   const int nchunks = k.nchunks;
-  const bool mul_first = wave >= 4;
   // phase timestamps of one block (diagnostics: p2l_wino_set_trace)
   unsigned long long* trace =
       (k.ws != nullptr && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
@@ -469,32 +488,20 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
   transform(Vs);
   __syncthreads();
   if (nchunks > 1) { write_raw(); if (nchunks > 2) load_raw(2); }
-  __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
     P2L_TR(0, c);
-    if (mul_first) {
-      multiply(Vc, c, more);
-      __builtin_amdgcn_sched_barrier(0);
-      P2L_TR(1, c);
-      if (more) transform(Vn);
-    } else {
-      if (more) transform(Vn);
-      __builtin_amdgcn_sched_barrier(0);
-      P2L_TR(1, c);
-      multiply(Vc, c, more);
-    }
+    multiply(Vc, Vn, c, more);
     P2L_TR(2, c);
     __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
     P2L_TR(3, c);
     if (c + 2 < nchunks) {
-      write_raw();
+      write_raw();                      // (made visible by the barrier inside the next chunk)
       if (c + 3 < nchunks) load_raw(c + 3);
     }
     P2L_TR(4, c);
-    __syncthreads();                    // patch of chunk c+2 visible
   }
   P2L_TR(5, 0);
 #undef P2L_TR
@@ -657,7 +664,9 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   { const char* e = getenv("P2L_ABL"); k.abl = e ? atoi(e) : 0; }
   const int mode = wino16_mode();
   const long blocks16 = (long)k.B * (k.H / 16) * (k.W / 16) * k.n_ntiles;
-  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || blocks16 >= 512)) {
+  // (in the bench step the 8-wave kernel is 1.03-1.10x on the layers with >= 128 input channels
+  //  and 0.93-0.98x on the 64-channel ones: its longer prologue against only 4 chunks)
+  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || (blocks16 >= 512 && k.nchunks >= 8))) {
     k.tiles_y = k.H / 16;
     k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
     k.ws = (float*)g_wino_trace;
