@@ -267,6 +267,27 @@ int p2l_gemm_ws(const P2LGemm* d, const float* A, const float* B, float* C, void
                 size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Fused self-attention (p2l_attn.hip): out[b][i][:] = sum_j softmax_j(q_i . k_j) v[j][:]   */
+/* for q [B][Nq][d], k [B][Nk][d], v [B][Nk][dv]; the Nq x Nk matrix is never stored.       */
+/* Replaces SelfAttn.forward of pytorch_pretrained_biggan (reached from                      */
+/* pix2latent/model/biggan.py:58); bf16x3 arithmetic, fp32 accumulate.                       */
+/* Shapes: d == 64, dv == 256, Nq % 128 == 0, Nk % 128 == 0 (p2l_attn_supported).            */
+/*   lse[b][i] = log sum_j exp(q_i . k_j): the row statistic the backward pass recomputes    */
+/*   the probabilities from.                                                                 */
+/*   p2l_attn_bwd_dv: dv[b][j][:] = sum_i exp(q_i . k_j - lse_i) dout[b][i][:]               */
+/* ------------------------------------------------------------------------- */
+typedef struct P2LAttn {
+  int32_t B, Nq, Nk, d, dv;
+} P2LAttn;
+int p2l_attn_supported(const P2LAttn* d);
+size_t p2l_attn_fwd_ws_bytes(const P2LAttn* d);
+int p2l_attn_fwd(const P2LAttn* d, const float* q, const float* k, const float* v, float* out,
+                 float* lse, void* ws, size_t ws_bytes, void* stream);
+size_t p2l_attn_bwd_dv_ws_bytes(const P2LAttn* d);
+int p2l_attn_bwd_dv(const P2LAttn* d, const float* q, const float* k, const float* dout,
+                    const float* lse, float* dv, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Small dense layers on the conditioning vector (gen_z, CBN gain/bias).     */
 /*   y[b][n] = sum_k x[b][k] * W[k][n] + bias[n]      (W is [K][N])          */
 /*   dx[b][k] = sum_n dy[b][n] * W[k][n]                                     */

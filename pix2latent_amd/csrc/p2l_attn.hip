@@ -1,0 +1,381 @@
+// Fused self-attention of the BigGAN-deep generator in the fp32-equivalent bf16x3 arithmetic.
+//
+// Role: SelfAttn.forward of the generator (reached from pix2latent/model/biggan.py:58 in the
+// reference -> pytorch_pretrained_biggan SelfAttn): beta = softmax(theta^T phi) over the 1024
+// pooled key positions, o = beta g, for 4096 query positions, 64 / 256 channels.  The
+// 4096 x 1024 matrix is NEVER written: a block keeps 128 query rows, streams the keys / values
+// in tiles of 32 through LDS and carries the running row maximum and row sum (online softmax).
+// The same kernel, with the roles of the two position sets swapped and the row statistics
+// given (MODE 1), recomputes the probabilities for the backward pass:
+//     MODE 0:  O[r][:]  = sum_t softmax_t(S[r][t]) W[t][:]        R = theta, T = phi, W = g
+//     MODE 1:  O[r][:]  = sum_t exp(S[t][r] - lse[t]) W[t][:]     R = phi,  T = theta, W = d(o)
+//              (= d g: the gradient of the values)
+//
+// Work layout (MI355X: two blocks of 4 waves per CU, 74 KB of LDS each):
+//   * wave = 32 private rows r: their 64 channels sit in registers as the B operand (split
+//     once); the products are formed TRANSPOSED, S^T[t][r] = T R^T, so that a lane owns ONE
+//     private row: row statistics are per-lane scalars and the probabilities leave the MFMA
+//     already in the register layout the next MFMA wants as its B operand -- the 16 values a
+//     lane holds are 16 of the 32 tile rows t; the value fragments are stored in that same
+//     (permuted) row order, so P never moves between lanes or through LDS;
+//   * O^T[channel][r] accumulates in 4 x 16 registers per wave for HALF of the 256 value
+//     channels (blockIdx selects the half; S is recomputed by both halves: 24 of 72 MFMAs);
+//   * the streamed operands are split into bf16 pieces ONCE per call by attn_prep_kernel and
+//     stored in MFMA A-fragment order, a tile is a flat 37 KB copy done by the LDS DMA
+//     (global_load_lds_dwordx4, double buffered, one barrier per tile);
+//   * every product is the 6-term bf16x3 form (include/p2l.h P2L_WFMT_BF16X3), fp32 accumulate;
+//     exp() is v_exp_f32 on (s - max) * log2(e).
+#include "p2l_conv_k.h"
+
+using namespace p2lconv;
+
+namespace {
+
+constexpr int AT_D = 64;                       // channels of theta / phi
+constexpr int AT_DV = 256;                     // channels of g
+constexpr int AT_KU = 768;                     // 16-byte units of the row-matrix part of a tile
+constexpr int AT_WU = 1536;                    // units of one value-channel half
+constexpr int AT_LU = 64;                      // units reserved for the tile's 32 row statistics
+constexpr int AT_TILE_U = AT_KU + 2 * AT_WU + AT_LU;          // global image: 3904 units / tile
+constexpr int AT_BUF_U = AT_KU + AT_WU + AT_LU;                // LDS buffer: 2368 units
+constexpr size_t AT_LDS_BYTES = (size_t)2 * AT_BUF_U * 16;     // 75,776 B
+constexpr float AT_LOG2E = 1.4426950408889634f;
+
+struct AttnK {
+  const float* r;          // private rows [B][NR][64]
+  const f32x4* img;        // streamed tiles [B][NT][AT_TILE_U]
+  float* out;              // MODE 0: [B][NR][256]; MODE 1: partial [tsplit][B][NR][256]
+  float* lse;              // MODE 0: written, [B][NR]
+  int B, NR, NT, tsplit;
+};
+
+// ---- streamed operands -> bf16x3 fragment images ------------------------------------------
+// x [B][N][64] (rows of the S product), w [B][N][256] (values), stat [B][N] or null.
+// Tile of 32 rows:  K part [t 0..3][piece][lane] : lane (row l31, half lhi) = x[row][16t + 8lhi + e]
+//                   W part [half][j 0..3][u 0..1][piece][lane] : lane (channel 128 half + 32j + l31,
+//                   lhi) = w[row(u, lhi, e)][channel], row(u,lhi,e) = 16u + 8(e>>2) + 4lhi + (e&3)
+//                   -- the order in which the S^T accumulator registers of a lane hold the rows.
+__global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ stat,
+                                                        f32x4* __restrict__ img, int N, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // (b, tile, fragment 0..20, lane)
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int q = idx >> 6;
+  const int frag = q % 21; q /= 21;                     // 0..3 K | 4..19 W | 20 statistics
+  const int NT = N >> 5;
+  const int tile = q % NT, b = q / NT;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  f32x4* dst = img + ((size_t)b * NT + tile) * AT_TILE_U;
+  if (frag == 20) {
+    if (lane < 8) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (stat) v = *reinterpret_cast<const f32x4*>(stat + (size_t)b * N + tile * 32 + lane * 4);
+      dst[AT_KU + 2 * AT_WU + lane] = v;
+    }
+    return;
+  }
+  float v[8];
+  int unit;
+  if (frag < 4) {
+    const float* src = x + ((size_t)b * N + tile * 32 + l31) * AT_D + frag * 16 + lhi * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e];
+    unit = frag * 3 * 64;
+  } else {
+    const int f = frag - 4;                              // half*8 + j*2 + u
+    const int u = f & 1, ch = (f >> 1) * 32 + l31;       // channel 0..255 = half*128 + j*32 + l31
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = 16 * u + 8 * (e >> 2) + 4 * lhi + (e & 3);
+      v[e] = w[((size_t)b * N + tile * 32 + row) * AT_DV + ch];
+    }
+    unit = AT_KU + f * 3 * 64;
+  }
+  bf16x4 h[2], m[2], l[2];
+  split3(f32x4{v[0], v[1], v[2], v[3]}, h[0], m[0], l[0]);
+  split3(f32x4{v[4], v[5], v[6], v[7]}, h[1], m[1], l[1]);
+  const bf16x8 p1 = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  const bf16x8 p2 = __builtin_shufflevector(m[0], m[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  const bf16x8 p3 = __builtin_shufflevector(l[0], l[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  dst[unit + lane] = __builtin_bit_cast(f32x4, p1);
+  dst[unit + 64 + lane] = __builtin_bit_cast(f32x4, p2);
+  dst[unit + 128 + lane] = __builtin_bit_cast(f32x4, p3);
+}
+
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 t) {
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], t, 0, 0, 0);      // smallest terms first
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], t, 0, 0, 0);
+  return t;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn_core_kernel(const AttnK a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // block = (sample, 128-row block, value-channel half, slice of the tile range)
+  int id = blockIdx.x;
+  const int h = id & 1; id >>= 1;
+  const int ts = id % a.tsplit; id /= a.tsplit;
+  const int nrb = a.NR >> 7;
+  const int rb = id % nrb, b = id / nrb;
+  const int t_per = a.NT / a.tsplit, t0 = ts * t_per;
+  const int row = rb * 128 + wave * 32 + l31;             // this lane's private row
+
+  // ---- private rows -> B fragments (split once) ------------------------------------------
+  bf16x8 rf[4][3];
+  {
+    const float* rp = a.r + ((size_t)b * a.NR + row) * AT_D + lhi * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + t * 16);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + t * 16 + 4);
+      bf16x4 hh[2], mm[2], ll[2];
+      split3(x0, hh[0], mm[0], ll[0]);
+      split3(x1, hh[1], mm[1], ll[1]);
+      rf[t][0] = __builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      rf[t][1] = __builtin_shufflevector(mm[0], mm[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      rf[t][2] = __builtin_shufflevector(ll[0], ll[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  }
+
+  // ---- tile DMA: K part | W half | statistics, 37 wave-instructions of 1 KB ---------------
+  const f32x4* img_b = a.img + (size_t)b * a.NT * AT_TILE_U;
+  auto dma_tile = [&](int tile, int buf) {
+    const f32x4* src = img_b + (size_t)tile * AT_TILE_U;
+    constexpr int NI = (MODE == 1) ? 37 : 36;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int ins = wave + 4 * i;                       // wave-instruction index
+      if (ins >= NI) continue;
+      // source unit of the first lane: K part as is, W part of this half, statistics
+      const int du = ins * 64;                            // destination unit in the buffer
+      const int su = (du < AT_KU) ? du : (du < AT_KU + AT_WU ? du + h * AT_WU : du + AT_WU);
+      const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+          (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + ((size_t)buf * AT_BUF_U + du) * 4));
+      const f32x4* g = src + su + lane;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(g), "s"(lds_base) : "memory");
+    }
+  };
+
+  f32x16 O[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[j][r] = 0.f;
+  float m_run = -__builtin_inff(), l_run = 0.f;
+
+  dma_tile(t0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int it = 0; it < t_per; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < t_per) dma_tile(t0 + it + 1, buf ^ 1);
+    const f32x4* Kb = reinterpret_cast<const f32x4*>(smem) + (size_t)buf * AT_BUF_U;
+    const f32x4* Wb = Kb + AT_KU;
+
+    // ---- S^T[t][r] = T R^T : 4 k-steps of 16 channels ------------------------------------
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bf16x8 ka[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ka[p] = __builtin_bit_cast(bf16x8, Kb[(t * 3 + p) * 64 + lane]);
+      S = mfma6(ka, rf[t], S);
+    }
+
+    // ---- probabilities ---------------------------------------------------------------------
+    if (MODE == 0) {
+      float mx = S[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * AT_LOG2E);   // exp(-inf) = 0 at start
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        S[r] = __builtin_amdgcn_exp2f((S[r] - m_new) * AT_LOG2E);
+        rs += S[r];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[j][r] *= alpha;
+    } else {
+      const float* st = reinterpret_cast<const float*>(Wb + AT_WU);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(st + 8 * g + 4 * lhi);
+        S[4 * g + 0] = __builtin_amdgcn_exp2f((S[4 * g + 0] - ls.x) * AT_LOG2E);
+        S[4 * g + 1] = __builtin_amdgcn_exp2f((S[4 * g + 1] - ls.y) * AT_LOG2E);
+        S[4 * g + 2] = __builtin_amdgcn_exp2f((S[4 * g + 2] - ls.z) * AT_LOG2E);
+        S[4 * g + 3] = __builtin_amdgcn_exp2f((S[4 * g + 3] - ls.w) * AT_LOG2E);
+      }
+    }
+    // B fragments of the second product: K-step u = accumulator registers 8u .. 8u+7
+    bf16x8 pf[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x4 hh[2], mm[2], ll[2];
+      split3(f32x4{S[8 * u + 0], S[8 * u + 1], S[8 * u + 2], S[8 * u + 3]}, hh[0], mm[0], ll[0]);
+      split3(f32x4{S[8 * u + 4], S[8 * u + 5], S[8 * u + 6], S[8 * u + 7]}, hh[1], mm[1], ll[1]);
+      pf[u][0] = __builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      pf[u][1] = __builtin_shufflevector(mm[0], mm[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      pf[u][2] = __builtin_shufflevector(ll[0], ll[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+    // ---- O^T[channel][r] += W^T P^T --------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 wa[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          wa[p] = __builtin_bit_cast(bf16x8, Wb[((j * 2 + u) * 3 + p) * 64 + lane]);
+        O[j] = mfma6(wa, pf[u], O[j]);
+      }
+
+    // next tile landed (this wave's DMAs), everyone done with this buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- output: O^T -> rows of 128 channels --------------------------------------------------
+  if (MODE == 0) {
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[j][r] *= inv;
+    if (h == 0 && lhi == 0) a.lse[(size_t)b * a.NR + row] = m_run + logf(l_run);
+  }
+  constexpr int DP = 129;                                  // odd pitch: conflict-free 4-byte writes
+  float* dump = smem + wave * 32 * DP;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dump[l31 * DP + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = O[j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* ob = a.out + (((size_t)ts * a.B + b) * a.NR + rb * 128 + wave * 32) * AT_DV + h * 128;
+#pragma unroll 4
+  for (int rr = 0; rr < 32; ++rr) {
+    ob[(size_t)rr * AT_DV + lane] = dump[rr * DP + lane];
+    ob[(size_t)rr * AT_DV + 64 + lane] = dump[rr * DP + 64 + lane];
+  }
+}
+
+// out[i] = sum_s part[s][i] in slice order (deterministic)
+__global__ __launch_bounds__(256) void attn_reduce_kernel(const float* __restrict__ part,
+                                                          float* __restrict__ out, size_t n4,
+                                                          int nsplit) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+  for (int k = 1; k < nsplit; ++k) s += reinterpret_cast<const f32x4*>(part)[(size_t)k * n4 + i];
+  reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+int attn_shape_ok(const P2LAttn* d) {
+  return d && d->B >= 1 && d->d == AT_D && d->dv == AT_DV && d->Nq >= 128 && d->Nq % 128 == 0 &&
+         d->Nk >= 128 && d->Nk % 128 == 0;
+}
+
+size_t img_bytes(int B, int N) { return (size_t)B * (N >> 5) * AT_TILE_U * 16; }
+
+int run_prep(const float* x, const float* w, const float* stat, f32x4* img, int B, int N,
+             hipStream_t st) {
+  const int total = B * (N >> 5) * 21 * 64;
+  hipLaunchKernelGGL(attn_prep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, stat, img,
+                     N, total);
+  return p2l_check_launch();
+}
+
+template <int MODE>
+int run_core(const AttnK& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_core_kernel<MODE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(a.B * (a.NR >> 7) * a.tsplit * 2), block(256);
+  hipLaunchKernelGGL(attn_core_kernel<MODE>, grid, block, AT_LDS_BYTES, st, a);
+  return p2l_check_launch();
+}
+
+// slices of the query range in the d(values) form: 8 row blocks x 2 halves per sample alone
+// leave most of the chip idle
+int dv_tsplit(const P2LAttn* d) {
+  int s = 1;
+  while (s < 8 && (long)d->B * (d->Nk >> 7) * 2 * s < 1024 && (d->Nq >> 5) % (2 * s) == 0) s *= 2;
+  return s;
+}
+
+}  // namespace
+
+extern "C" int p2l_attn_supported(const P2LAttn* d) { return attn_shape_ok(d); }
+
+extern "C" size_t p2l_attn_fwd_ws_bytes(const P2LAttn* d) {
+  return attn_shape_ok(d) ? img_bytes(d->B, d->Nk) : 0;
+}
+
+extern "C" int p2l_attn_fwd(const P2LAttn* d, const float* q, const float* k, const float* v,
+                            float* out, float* lse, void* ws, size_t ws_bytes, void* stream) {
+  if (!attn_shape_ok(d)) return P2L_EUNSUP;
+  if (!q || !k || !v || !out || !lse) return P2L_EINVAL;
+  if (!ws || ws_bytes < p2l_attn_fwd_ws_bytes(d)) return P2L_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = run_prep(k, v, nullptr, (f32x4*)ws, d->B, d->Nk, st);
+  if (rc) return rc;
+  AttnK a{};
+  a.r = q; a.img = (const f32x4*)ws; a.out = out; a.lse = lse;
+  a.B = d->B; a.NR = d->Nq; a.NT = d->Nk >> 5; a.tsplit = 1;
+  return run_core<0>(a, st);
+}
+
+extern "C" size_t p2l_attn_bwd_dv_ws_bytes(const P2LAttn* d) {
+  if (!attn_shape_ok(d)) return 0;
+  const int s = dv_tsplit(d);
+  return img_bytes(d->B, d->Nq) + (s > 1 ? (size_t)s * d->B * d->Nk * AT_DV * sizeof(float) : 0);
+}
+
+extern "C" int p2l_attn_bwd_dv(const P2LAttn* d, const float* q, const float* k,
+                               const float* dout, const float* lse, float* dv, void* ws,
+                               size_t ws_bytes, void* stream) {
+  if (!attn_shape_ok(d)) return P2L_EUNSUP;
+  if (!q || !k || !dout || !lse || !dv) return P2L_EINVAL;
+  if (!ws || ws_bytes < p2l_attn_bwd_dv_ws_bytes(d)) return P2L_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = run_prep(q, dout, lse, (f32x4*)ws, d->B, d->Nq, st);
+  if (rc) return rc;
+  const int s = dv_tsplit(d);
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + img_bytes(d->B, d->Nq));
+  AttnK a{};
+  a.r = k; a.img = (const f32x4*)ws; a.out = s > 1 ? part : dv; a.lse = nullptr;
+  a.B = d->B; a.NR = d->Nk; a.NT = d->Nq >> 5; a.tsplit = s;
+  rc = run_core<1>(a, st);
+  if (rc || s == 1) return rc;
+  const size_t n4 = (size_t)d->B * d->Nk * AT_DV / 4;
+  hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, part, dv, n4, s);
+  return p2l_check_launch();
+}

@@ -91,6 +91,39 @@ def gemm(A, B, batch, M, Nn, K, a_kmajor=False, b_kmajor=False, alpha=1.0, Cacc=
     return Cm
 
 
+def _attn_desc(q, k, v):
+    d = N.P2LAttn()
+    d.B, d.Nq, d.d = q.shape
+    d.Nk, d.dv = k.shape[1], v.shape[2]
+    return d
+
+
+def attn_fwd(q, k, v):
+    """fused softmax(q k^T) v (p2l_attn_fwd): q [B,Nq,64], k [B,Nk,64], v [B,Nk,256]
+    -> out [B,Nq,256], lse [B,Nq]"""
+    d = _attn_desc(q, k, v)
+    wsb = _lib().p2l_attn_fwd_ws_bytes(C.byref(d))
+    if wsb == 0:
+        raise N.NativeError('p2l_attn_fwd does not take this shape')
+    ws = torch.empty(wsb // 4, device=q.device)
+    out = torch.empty(d.B, d.Nq, d.dv, device=q.device)
+    lse = torch.empty(d.B, d.Nq, device=q.device)
+    N.check(_lib().p2l_attn_fwd(C.byref(d), N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), N.ptr(lse),
+                                N.ptr(ws), C.c_size_t(wsb), N.stream()), 'attn_fwd')
+    return out, lse
+
+
+def attn_bwd_dv(q, k, dout, lse):
+    """d v[j] = sum_i exp(q_i k_j - lse_i) dout[i] (p2l_attn_bwd_dv)"""
+    d = _attn_desc(q, k, dout)
+    wsb = _lib().p2l_attn_bwd_dv_ws_bytes(C.byref(d))
+    ws = torch.empty(wsb // 4, device=q.device)
+    dv = torch.empty(d.B, d.Nk, d.dv, device=q.device)
+    N.check(_lib().p2l_attn_bwd_dv(C.byref(d), N.ptr(q), N.ptr(k), N.ptr(dout), N.ptr(lse),
+                                   N.ptr(dv), N.ptr(ws), C.c_size_t(wsb), N.stream()), 'attn_bwd_dv')
+    return dv
+
+
 def linear_fwd(x, W, bias=None):
     Bn, K = x.shape
     Nn = W.shape[1]
