@@ -286,6 +286,13 @@ int p2l_attn_fwd(const P2LAttn* d, const float* q, const float* k, const float* 
 size_t p2l_attn_bwd_dv_ws_bytes(const P2LAttn* d);
 int p2l_attn_bwd_dv(const P2LAttn* d, const float* q, const float* k, const float* dout,
                     const float* lse, float* dv, void* ws, size_t ws_bytes, void* stream);
+/* dq, dk of the same attention (Nq % 256 == 0).  P and dP = dout v^T are recomputed tile by tile
+ * and never stored; dS^T[b][j][i] = P_ij (dP_ij - dout_i . out_i) is written once into `dst`
+ * (B*Nk*Nq floats, scratch) and applied to k and q. */
+size_t p2l_attn_bwd_qk_ws_bytes(const P2LAttn* d);
+int p2l_attn_bwd_qk(const P2LAttn* d, const float* q, const float* k, const float* v,
+                    const float* out, const float* dout, const float* lse, float* dst, float* dq,
+                    float* dk, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Small dense layers on the conditioning vector (gen_z, CBN gain/bias).     */

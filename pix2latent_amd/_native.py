@@ -186,7 +186,7 @@ EXPORTS = [
     'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode', 'p2l_set_wino_block', 'p2l_wino_set_trace',
     'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_attn_supported', 'p2l_attn_fwd_ws_bytes', 'p2l_attn_fwd', 'p2l_attn_bwd_dv_ws_bytes',
-    'p2l_attn_bwd_dv',
+    'p2l_attn_bwd_dv', 'p2l_attn_bwd_qk_ws_bytes', 'p2l_attn_bwd_qk',
     'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
@@ -235,7 +235,7 @@ def lib():
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
                      'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes',
                      'p2l_packed_weight_floats', 'p2l_attn_fwd_ws_bytes',
-                     'p2l_attn_bwd_dv_ws_bytes'):
+                     'p2l_attn_bwd_dv_ws_bytes', 'p2l_attn_bwd_qk_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

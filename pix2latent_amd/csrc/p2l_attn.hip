@@ -284,6 +284,284 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const AttnK a) {
   }
 }
 
+// ==========================================================================================
+// Backward: d S^T[k][q] = P[q][k] (dP[q][k] - D[q]),  P = exp(q.k - lse[q]),  dP = d(o) g^T,
+// D[q] = d(o)[q] . o[q].  The 256-channel contraction of dP pairs every query row with every
+// key row, so neither side can live in a wave's registers (32 x 256 x 3 pieces = 192 VGPR):
+// this part is a tiled GEMM with BOTH operands streamed through LDS, two products into two
+// accumulator sets (S over 4 chunks of 16 channels, dP over 16) and the elementwise epilogue
+// above.  P and dP are never stored; d S^T is, once (it is the operand of the two remaining,
+// memory-bound products d theta = dS phi and d phi = dS^T theta: attn_apply_kernel).
+//   * block = 128 keys x 256 queries, 8 waves as 2 x 4, wave tile 64 x 64: 2 x (2 x 2 x 16)
+//     accumulator registers; transposed (keys = MFMA rows) so that a lane owns one query and
+//     lse / D are per-lane scalars;
+//   * operands are bf16x3 "row images" [32-row tile][16-channel chunk][piece][lane] made once
+//     per call (attn_rows_prep_kernel); a chunk stage is 36 KB (4 + 8 row tiles), LDS DMA,
+//     double buffered, one barrier per chunk (24 MFMAs per wave).
+constexpr int AX_STAGE_U = 12 * 192;                     // 4 key tiles + 8 query tiles, 3 KB each
+constexpr size_t AX_LDS_BYTES = (size_t)2 * AX_STAGE_U * 16;
+
+struct AttnX {
+  const f32x4 *kimg, *qimg, *vimg, *doimg;               // row images: 4 | 4 | 16 | 16 chunks
+  const float *lse, *dsum;                               // [B][Nq]
+  float* dst;                                            // d S^T [B][Nk][Nq]
+  int B, Nq, Nk;
+};
+
+// x [B][N][C] -> [b][tile][chunk][piece][lane]: lane (row l31, half lhi) = x[row][16 chunk + 8 lhi + e]
+__global__ __launch_bounds__(256) void attn_rows_prep_kernel(const float* __restrict__ x,
+                                                             f32x4* __restrict__ img, int N, int C,
+                                                             int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;        // (b, tile, chunk, lane)
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int q = idx >> 6;
+  const int nch = C >> 4;
+  const int chunk = q % nch; q /= nch;                   // q = b * NT + tile
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const float* src = x + ((size_t)q * 32 + l31) * C + chunk * 16 + lhi * 8;
+  bf16x4 h[2], m[2], l[2];
+  split3(*reinterpret_cast<const f32x4*>(src), h[0], m[0], l[0]);
+  split3(*reinterpret_cast<const f32x4*>(src + 4), h[1], m[1], l[1]);
+  f32x4* dst = img + ((size_t)q * nch + chunk) * 192 + lane;
+  dst[0] = __builtin_bit_cast(f32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  dst[64] = __builtin_bit_cast(f32x4, __builtin_shufflevector(m[0], m[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  dst[128] = __builtin_bit_cast(f32x4, __builtin_shufflevector(l[0], l[1], 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// D[b][q] = sum_c d(o)[q][c] o[q][c]; one wave per row
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ out, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const f32x4 x = reinterpret_cast<const f32x4*>(a + (size_t)row * AT_DV)[lane];
+  const f32x4 y = reinterpret_cast<const f32x4*>(b + (size_t)row * AT_DV)[lane];
+  const float s = wave_sum((x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w));
+  if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(512, 1) void attn_ds_kernel(const AttnX a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;               // key half | query quarter of the block tile
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int nkb = a.Nk >> 7, nqb = a.Nq >> 8;
+  const int kb = id % nkb; id /= nkb;
+  const int qb = id % nqb, b = id / nqb;
+  const int ktile0 = b * (a.Nk >> 5) + kb * 4, qtile0 = b * (a.Nq >> 5) + qb * 8;
+
+  // chunk c of 20: 0..3 = S (phi | theta images, 4 chunks per tile), 4..19 = dP (g | d(o), 16)
+  auto dma_chunk = [&](int c, int buf) {
+    const bool sp = c < 4;
+    const f32x4* ai = sp ? a.kimg : a.vimg;
+    const f32x4* bi = sp ? a.qimg : a.doimg;
+    const int nch = sp ? 4 : 16, ch = sp ? c : c - 4;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int ins = wave + 8 * i;                       // 36 wave-instructions of 1 KB
+      if (ins >= 36) continue;
+      const int slot = ins / 3, piece = ins - slot * 3;   // slots 0..3 key tiles, 4..11 query tiles
+      const f32x4* g = (slot < 4 ? ai + ((size_t)(ktile0 + slot) * nch + ch) * 192
+                                 : bi + ((size_t)(qtile0 + slot - 4) * nch + ch) * 192) + piece * 64 + lane;
+      const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+          (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + ((size_t)buf * AX_STAGE_U + ins * 64) * 4));
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(g), "s"(lds_base) : "memory");
+    }
+  };
+
+  f32x16 accS[2][2], accP[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accS[mi][ni][r] = 0.f; accP[mi][ni][r] = 0.f; }
+
+  auto compute = [&](int buf, f32x16 (&acc)[2][2]) {
+    const f32x4* st = reinterpret_cast<const f32x4*>(smem) + (size_t)buf * AX_STAGE_U;
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = __builtin_bit_cast(bf16x8, st[((2 * wm + i) * 3 + p) * 64 + lane]);
+        fb[i][p] = __builtin_bit_cast(bf16x8, st[((4 + 2 * wn + i) * 3 + p) * 64 + lane]);
+      }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma6(fa[mi], fb[ni], acc[mi][ni]);
+  };
+
+  dma_chunk(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < 20; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < 20) dma_chunk(c + 1, buf ^ 1);
+    if (c < 4) compute(buf, accS); else compute(buf, accP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- d S^T = exp(S - lse) (dP - D), rows = keys, lanes = queries ---------------------------
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qb * 256 + wn * 64 + ni * 32 + l31;
+    const float ls = a.lse[(size_t)b * a.Nq + q], dd = a.dsum[(size_t)b * a.Nq + q];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float* o = a.dst + ((size_t)b * a.Nk + kb * 128 + wm * 64 + mi * 32 + 4 * lhi) * a.Nq + q;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f((accS[mi][ni][r] - ls) * AT_LOG2E);
+        o[(size_t)((r & 3) + 8 * (r >> 2)) * a.Nq] = p * (accP[mi][ni][r] - dd);
+      }
+    }
+  }
+}
+
+// O[r][0..63] = sum_t P'[t][r] W[t][0..63] for a STORED weight matrix M (the d S^T above):
+//   TMAJ = true : P'[t][r] = M[t][r]   (rows of M = streamed index: lanes read consecutive r)
+//   TMAJ = false: P'[t][r] = M[r][t]   (rows of M = private index: 16-byte reads along t)
+// Same register layout trick as attn_core_kernel: the 32 x 32 tile of M is loaded straight into
+// the MFMA C layout, split, and used as the B operand; W (64 channels) comes as the permuted
+// fragment image [tile][j 0..1][u 0..1][piece][lane] (attn_wprep_kernel), 12 KB per tile, DMA.
+constexpr int AP_TILE_U = 2 * 2 * 192;                   // 768 units = 12 KB
+
+struct AttnP {
+  const float* m;          // stored weights, row pitch ldm, sample stride sm
+  const f32x4* wimg;       // [B][NT][AP_TILE_U]
+  float* out;              // [tsplit][B][NR][64]
+  int B, NR, NT, tsplit, ldm;
+  size_t sm;
+};
+
+__global__ __launch_bounds__(256) void attn_wprep_kernel(const float* __restrict__ w,
+                                                         f32x4* __restrict__ img, int N, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;        // (b, tile, f = j*2+u, lane)
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  int q = idx >> 6;
+  const int f = q & 3; q >>= 2;                          // q = b * NT + tile
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int u = f & 1, ch = (f >> 1) * 32 + l31;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int row = 16 * u + 8 * (e >> 2) + 4 * lhi + (e & 3);
+    v[e] = w[((size_t)q * 32 + row) * AT_D + ch];
+  }
+  bf16x4 h[2], m[2], l[2];
+  split3(f32x4{v[0], v[1], v[2], v[3]}, h[0], m[0], l[0]);
+  split3(f32x4{v[4], v[5], v[6], v[7]}, h[1], m[1], l[1]);
+  f32x4* dst = img + (size_t)q * AP_TILE_U + f * 192 + lane;
+  dst[0] = __builtin_bit_cast(f32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  dst[64] = __builtin_bit_cast(f32x4, __builtin_shufflevector(m[0], m[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  dst[128] = __builtin_bit_cast(f32x4, __builtin_shufflevector(l[0], l[1], 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool TMAJ>
+__global__ __launch_bounds__(256, 3) void attn_apply_kernel(const AttnP a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int id = blockIdx.x;
+  const int ts = id % a.tsplit; id /= a.tsplit;
+  const int nrb = a.NR >> 7;
+  const int rb = id % nrb, b = id / nrb;
+  const int t_per = a.NT / a.tsplit, t0 = ts * t_per;
+  const int r0 = rb * 128 + wave * 32;
+  const float* mb = a.m + (size_t)b * a.sm;
+
+  const f32x4* img_b = a.wimg + (size_t)b * a.NT * AP_TILE_U;
+  auto dma_tile = [&](int tile, int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ins = wave + 4 * i;                       // 12 wave-instructions
+      const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+          (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + ((size_t)buf * AP_TILE_U + ins * 64) * 4));
+      const f32x4* g = img_b + (size_t)tile * AP_TILE_U + ins * 64 + lane;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"(g), "s"(lds_base) : "memory");
+    }
+  };
+  // the 32 x 32 tile of M for tile t, in C-layout order: register 4g+i <-> streamed row 8g+4lhi+i
+  f32x16 pm;
+  auto load_m = [&](int tile) {
+    if (TMAJ) {
+      const float* p = mb + (size_t)(tile * 32 + 4 * lhi) * a.ldm + r0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pm[r] = p[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldm];
+    } else {
+      const float* p = mb + (size_t)(r0 + l31) * a.ldm + tile * 32 + 4 * lhi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 8 * g);
+        pm[4 * g] = v.x; pm[4 * g + 1] = v.y; pm[4 * g + 2] = v.z; pm[4 * g + 3] = v.w;
+      }
+    }
+  };
+
+  f32x16 O[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[j][r] = 0.f;
+
+  load_m(t0);
+  dma_tile(t0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; it < t_per; ++it) {
+    const int buf = it & 1;
+    bf16x8 pf[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x4 hh[2], mm[2], ll[2];
+      split3(f32x4{pm[8 * u + 0], pm[8 * u + 1], pm[8 * u + 2], pm[8 * u + 3]}, hh[0], mm[0], ll[0]);
+      split3(f32x4{pm[8 * u + 4], pm[8 * u + 5], pm[8 * u + 6], pm[8 * u + 7]}, hh[1], mm[1], ll[1]);
+      pf[u][0] = __builtin_shufflevector(hh[0], hh[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      pf[u][1] = __builtin_shufflevector(mm[0], mm[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      pf[u][2] = __builtin_shufflevector(ll[0], ll[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    if (it + 1 < t_per) { load_m(t0 + it + 1); dma_tile(t0 + it + 1, buf ^ 1); }
+    const f32x4* Wb = reinterpret_cast<const f32x4*>(smem) + (size_t)buf * AP_TILE_U;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 wa[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          wa[p] = __builtin_bit_cast(bf16x8, Wb[((j * 2 + u) * 3 + p) * 64 + lane]);
+        O[j] = mfma6(wa, pf[u], O[j]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // O^T[channel][r] -> out[r][64]
+  constexpr int DP = 65;
+  float* dump = smem + wave * 32 * DP;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dump[l31 * DP + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi] = O[j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float* ob = a.out + (((size_t)ts * a.B + b) * a.NR + r0) * AT_D;
+#pragma unroll 4
+  for (int rr = 0; rr < 32; ++rr) ob[(size_t)rr * AT_D + lane] = dump[rr * DP + lane];
+}
+
 // out[i] = sum_s part[s][i] in slice order (deterministic)
 __global__ __launch_bounds__(256) void attn_reduce_kernel(const float* __restrict__ part,
                                                           float* __restrict__ out, size_t n4,
@@ -330,6 +608,45 @@ int dv_tsplit(const P2LAttn* d) {
   while (s < 8 && (long)d->B * (d->Nk >> 7) * 2 * s < 1024 && (d->Nq >> 5) % (2 * s) == 0) s *= 2;
   return s;
 }
+
+// slices of the streamed range when 128-row blocks alone do not fill the chip
+int apply_tsplit(int B, int NR, int NT) {
+  int s = 1;
+  while (s < 8 && (long)B * (NR >> 7) * s < 1024 && NT % (2 * s) == 0) s *= 2;
+  return s;
+}
+
+// O[r][64] = sum_t P'[t][r] W[t][64] with the stored matrix m (see attn_apply_kernel)
+int run_apply(bool tmaj, const float* m, int ldm, size_t sm, const float* w, float* out, int B,
+              int NR, int Nt, f32x4* wimg, float* part, hipStream_t st) {
+  const int NT = Nt >> 5;
+  const int total = B * NT * 4 * 64;
+  hipLaunchKernelGGL(attn_wprep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wimg, Nt, total);
+  int rc = p2l_check_launch();
+  if (rc) return rc;
+  const int s = apply_tsplit(B, NR, NT);
+  AttnP a{};
+  a.m = m; a.wimg = wimg; a.out = s > 1 ? part : out;
+  a.B = B; a.NR = NR; a.NT = NT; a.tsplit = s; a.ldm = ldm; a.sm = sm;
+  dim3 grid(B * (NR >> 7) * s), block(256);
+  const size_t lds = (size_t)2 * AP_TILE_U * 16 > (size_t)4 * 32 * 65 * 4 ? (size_t)2 * AP_TILE_U * 16
+                                                                          : (size_t)4 * 32 * 65 * 4;
+  if (tmaj) hipLaunchKernelGGL(attn_apply_kernel<true>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(attn_apply_kernel<false>, grid, block, lds, st, a);
+  rc = p2l_check_launch();
+  if (rc || s == 1) return rc;
+  const size_t n4 = (size_t)B * NR * AT_D / 4;
+  hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, part, out, n4, s);
+  return p2l_check_launch();
+}
+
+size_t apply_part_bytes(const P2LAttn* d) {
+  const size_t a = (size_t)apply_tsplit(d->B, d->Nq, d->Nk >> 5) * d->B * d->Nq;
+  const size_t b = (size_t)apply_tsplit(d->B, d->Nk, d->Nq >> 5) * d->B * d->Nk;
+  return ((a > b ? a : b) * AT_D * sizeof(float) + 255) & ~(size_t)255;
+}
+size_t rows_img_bytes(int B, int N, int C) { return (size_t)B * (N >> 5) * (C >> 4) * 192 * 16; }
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -378,4 +695,65 @@ extern "C" int p2l_attn_bwd_dv(const P2LAttn* d, const float* q, const float* k,
   const size_t n4 = (size_t)d->B * d->Nk * AT_DV / 4;
   hipLaunchKernelGGL(attn_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, st, part, dv, n4, s);
   return p2l_check_launch();
+}
+
+// ---- d theta, d phi --------------------------------------------------------------------------
+// workspace: row images of phi, theta, g, d(o) | D | value images / partial sums of the two
+// apply passes (sized for the larger) ; `dst` (B * Nk * Nq floats) receives d S^T
+extern "C" size_t p2l_attn_bwd_qk_ws_bytes(const P2LAttn* d) {
+  if (!attn_shape_ok(d)) return 0;
+  size_t n = align256(rows_img_bytes(d->B, d->Nk, AT_D)) + align256(rows_img_bytes(d->B, d->Nq, AT_D)) +
+             align256(rows_img_bytes(d->B, d->Nk, AT_DV)) + align256(rows_img_bytes(d->B, d->Nq, AT_DV)) +
+             align256((size_t)d->B * d->Nq * sizeof(float));
+  const size_t wimg = align256((size_t)d->B * ((d->Nq > d->Nk ? d->Nq : d->Nk) >> 5) * AP_TILE_U * 16);
+  return n + wimg + apply_part_bytes(d);
+}
+
+extern "C" int p2l_attn_bwd_qk(const P2LAttn* d, const float* q, const float* k, const float* v,
+                               const float* out, const float* dout, const float* lse, float* dst,
+                               float* dq, float* dk, void* ws, size_t ws_bytes, void* stream) {
+  if (!attn_shape_ok(d) || d->Nq % 256) return P2L_EUNSUP;
+  if (!q || !k || !v || !out || !dout || !lse || !dst || !dq || !dk) return P2L_EINVAL;
+  if (!ws || ws_bytes < p2l_attn_bwd_qk_ws_bytes(d)) return P2L_EWS;
+  hipStream_t st = (hipStream_t)stream;
+  char* p = reinterpret_cast<char*>(ws);
+  f32x4* kimg = (f32x4*)p; p += align256(rows_img_bytes(d->B, d->Nk, AT_D));
+  f32x4* qimg = (f32x4*)p; p += align256(rows_img_bytes(d->B, d->Nq, AT_D));
+  f32x4* vimg = (f32x4*)p; p += align256(rows_img_bytes(d->B, d->Nk, AT_DV));
+  f32x4* doimg = (f32x4*)p; p += align256(rows_img_bytes(d->B, d->Nq, AT_DV));
+  float* dsum = (float*)p; p += align256((size_t)d->B * d->Nq * sizeof(float));
+  f32x4* wimg = (f32x4*)p; p += align256((size_t)d->B * ((d->Nq > d->Nk ? d->Nq : d->Nk) >> 5) * AP_TILE_U * 16);
+  float* part = (float*)p;
+  auto rows_prep = [&](const float* x, f32x4* img, int N, int C) {
+    const int total = d->B * (N >> 5) * (C >> 4) * 64;
+    hipLaunchKernelGGL(attn_rows_prep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, img, N, C, total);
+    return p2l_check_launch();
+  };
+  int rc;
+  if ((rc = rows_prep(k, kimg, d->Nk, AT_D))) return rc;
+  if ((rc = rows_prep(q, qimg, d->Nq, AT_D))) return rc;
+  if ((rc = rows_prep(v, vimg, d->Nk, AT_DV))) return rc;
+  if ((rc = rows_prep(dout, doimg, d->Nq, AT_DV))) return rc;
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3(cdiv((size_t)d->B * d->Nq, 4)), dim3(256), 0, st, dout,
+                     out, dsum, d->B * d->Nq);
+  if ((rc = p2l_check_launch())) return rc;
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr_set = true;
+    }
+    AttnX a{};
+    a.kimg = kimg; a.qimg = qimg; a.vimg = vimg; a.doimg = doimg; a.lse = lse; a.dsum = dsum;
+    a.dst = dst; a.B = d->B; a.Nq = d->Nq; a.Nk = d->Nk;
+    hipLaunchKernelGGL(attn_ds_kernel, dim3(d->B * (d->Nk >> 7) * (d->Nq >> 8)), dim3(512),
+                       AX_LDS_BYTES, st, a);
+    if ((rc = p2l_check_launch())) return rc;
+  }
+  const size_t sm = (size_t)d->Nk * d->Nq;
+  // d theta[q] = sum_k dS^T[k][q] phi[k]   (private rows = queries, M rows = streamed keys)
+  if ((rc = run_apply(true, dst, d->Nq, sm, k, dq, d->B, d->Nq, d->Nk, wimg, part, st))) return rc;
+  // d phi[k] = sum_q dS^T[k][q] theta[q]   (private rows = keys = rows of M)
+  return run_apply(false, dst, d->Nq, sm, q, dk, d->B, d->Nk, d->Nq, wimg, part, st);
 }

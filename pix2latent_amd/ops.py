@@ -124,6 +124,19 @@ def attn_bwd_dv(q, k, dout, lse):
     return dv
 
 
+def attn_bwd_qk(q, k, v, out, dout, lse):
+    """d q, d k of the fused attention (p2l_attn_bwd_qk); also returns the dS^T scratch"""
+    d = _attn_desc(q, k, v)
+    wsb = _lib().p2l_attn_bwd_qk_ws_bytes(C.byref(d))
+    ws = torch.empty(wsb // 4, device=q.device)
+    dst = torch.empty(d.B, d.Nk, d.Nq, device=q.device)
+    dq, dk = torch.empty_like(q), torch.empty_like(k)
+    N.check(_lib().p2l_attn_bwd_qk(C.byref(d), N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), N.ptr(dout),
+                                   N.ptr(lse), N.ptr(dst), N.ptr(dq), N.ptr(dk), N.ptr(ws),
+                                   C.c_size_t(wsb), N.stream()), 'attn_bwd_qk')
+    return dq, dk, dst
+
+
 def linear_fwd(x, W, bias=None):
     Bn, K = x.shape
     Nn = W.shape[1]

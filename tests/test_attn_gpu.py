@@ -52,6 +52,26 @@ def test_attn_forward_and_value_gradient(dev, O, B, Nq, Nk, scale):
     assert relerr(dv.cpu(), P.transpose(1, 2) @ do.double()) < 2e-5
 
 
+@pytest.mark.parametrize('B,Nq,Nk,scale', [(2, 256, 128, 0.3), (1, 512, 256, 0.8), (2, 4096, 1024, 0.4)],
+                         ids=['small', 'sharp-rows', 'biggan256'])
+def test_attn_query_key_gradients(dev, O, B, Nq, Nk, scale):
+    """d q, d k against fp64 autograd through softmax(q k^T) v; P and dP are recomputed inside
+    the kernels, only dS^T is stored (checked too)"""
+    q, k, v, do = _inputs(B, Nq, Nk, 9, scale)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    P = torch.softmax(qd @ kd.transpose(1, 2), dim=-1)
+    out_ref = P @ vd
+    out_ref.backward(do.double())
+    out, lse = O.attn_fwd(q.to(dev), k.to(dev), v.to(dev))
+    dq, dk, dst = O.attn_bwd_qk(q.to(dev), k.to(dev), v.to(dev), out, do.to(dev), lse)
+    torch.cuda.synchronize()
+    dP = do.double() @ v.double().transpose(1, 2)
+    dS = P.detach() * (dP - (do.double() * out_ref.detach()).sum(-1, keepdim=True))
+    assert relerr(dst.cpu(), dS.transpose(1, 2)) < 2e-5
+    assert relerr(dq.cpu(), qd.grad) < 2e-5
+    assert relerr(dk.cpu(), kd.grad) < 2e-5
+
+
 def test_attn_is_deterministic_and_batch_independent(dev, O):
     q, k, v, do = _inputs(3, 256, 128, 7, 0.5)
     a, la = O.attn_fwd(q.to(dev), k.to(dev), v.to(dev))
