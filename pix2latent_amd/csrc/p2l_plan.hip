@@ -131,6 +131,8 @@ struct BGLayout {
   BGBlockOff blk[P2L_MAX_BLOCKS];
   // attention
   size_t att_theta, att_phi, att_phi_p, att_g, att_g_p, att_P, att_ag, att_y;
+  size_t att_lse, att_ws, att_ws_floats;   // fused attention (p2l_attn.hip): row statistic, images
+  int att_fused;
   int att_H;
   // backward temporaries
   size_t g_a, g_b, g_c, g_d;  // gradient scratch buffers (max activation size)
@@ -177,7 +179,25 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
       L.att_phi_p = a.take(B * (P / 4) * (C / 8));
       L.att_g = a.take(B * P * (C / 2));
       L.att_g_p = a.take(B * (P / 4) * (C / 2));
-      L.att_P = a.take(B * P * (P / 4));
+      {
+        // fused form (p2l_attn.hip): the P x P/4 matrix is never stored; shapes it does not
+        // take keep the GEMM + softmax sequence and its matrix
+        P2LAttn ad{B, (int)P, (int)(P / 4), C / 8, C / 2};
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("P2L_ATTN"); on = e ? atoi(e) : 1; }
+        L.att_fused = on && p2l_attn_supported(&ad) && (P % 256 == 0);
+        if (L.att_fused) {
+          size_t wsb = p2l_attn_fwd_ws_bytes(&ad);
+          if (p2l_attn_bwd_dv_ws_bytes(&ad) > wsb) wsb = p2l_attn_bwd_dv_ws_bytes(&ad);
+          if (p2l_attn_bwd_qk_ws_bytes(&ad) > wsb) wsb = p2l_attn_bwd_qk_ws_bytes(&ad);
+          L.att_ws_floats = (wsb + 3) / 4;
+          L.att_ws = a.take(L.att_ws_floats);
+          L.att_lse = a.take(B * P);
+          L.att_P = 0;
+        } else {
+          L.att_P = a.take(B * P * (P / 4));
+        }
+      }
       L.att_ag = a.take(B * P * (C / 2));
       L.att_y = a.take(B * P * C);
       L.d_theta = a.take(B * P * (C / 8));
@@ -356,23 +376,30 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
       gg.x = x; gg.w = m->att_w[2]; gg.y = W + L.att_g; gg.yp = W + L.att_g_p;
       gg.d.pool = P2L_POOL_MAX;
       RET_IF(run_conv(gg, skws, L.skws_floats, st));
+      if (L.att_fused) {
+        // attn_g = softmax(theta phi_p^T) g_p, fused; lse = row statistic for the backward pass
+        P2LAttn ad{B, P, P / 4, C / 8, C / 2};
+        RET_IF(p2l_attn_fwd(&ad, W + L.att_theta, W + L.att_phi_p, W + L.att_g_p, W + L.att_ag,
+                            W + L.att_lse, W + L.att_ws, L.att_ws_floats * sizeof(float), st));
+      } else {
       // S = theta^T phi  -> [B, P, P/4]
-      P2LGemm g1{};
-      g1.batch = B; g1.M = P; g1.N = P / 4; g1.K = C / 8;
-      g1.lda = C / 8; g1.ldb = C / 8; g1.ldc = P / 4;
-      g1.stride_a = (int64_t)P * (C / 8); g1.stride_b = (int64_t)(P / 4) * (C / 8);
-      g1.stride_c = (int64_t)P * (P / 4);
-      g1.a_kmajor = 0; g1.b_kmajor = 0; g1.alpha = 1.f; g1.accumulate = 0;
-      RET_IF(p2l_gemm_ws(&g1, W + L.att_theta, W + L.att_phi_p, W + L.att_P, skws, L.skws_floats * sizeof(float), st));
-      RET_IF(p2l_softmax_fwd(W + L.att_P, W + L.att_P, (int64_t)B * P, P / 4, st));
-      // attn_g[p, :] = sum_k P[p,k] g[k, :]
-      P2LGemm g2{};
-      g2.batch = B; g2.M = P; g2.N = C / 2; g2.K = P / 4;
-      g2.lda = P / 4; g2.ldb = C / 2; g2.ldc = C / 2;
-      g2.stride_a = (int64_t)P * (P / 4); g2.stride_b = (int64_t)(P / 4) * (C / 2);
-      g2.stride_c = (int64_t)P * (C / 2);
-      g2.a_kmajor = 0; g2.b_kmajor = 1; g2.alpha = 1.f; g2.accumulate = 0;
-      RET_IF(p2l_gemm_ws(&g2, W + L.att_P, W + L.att_g_p, W + L.att_ag, skws, L.skws_floats * sizeof(float), st));
+        P2LGemm g1{};
+        g1.batch = B; g1.M = P; g1.N = P / 4; g1.K = C / 8;
+        g1.lda = C / 8; g1.ldb = C / 8; g1.ldc = P / 4;
+        g1.stride_a = (int64_t)P * (C / 8); g1.stride_b = (int64_t)(P / 4) * (C / 8);
+        g1.stride_c = (int64_t)P * (P / 4);
+        g1.a_kmajor = 0; g1.b_kmajor = 0; g1.alpha = 1.f; g1.accumulate = 0;
+        RET_IF(p2l_gemm_ws(&g1, W + L.att_theta, W + L.att_phi_p, W + L.att_P, skws, L.skws_floats * sizeof(float), st));
+        RET_IF(p2l_softmax_fwd(W + L.att_P, W + L.att_P, (int64_t)B * P, P / 4, st));
+        // attn_g[p, :] = sum_k P[p,k] g[k, :]
+        P2LGemm g2{};
+        g2.batch = B; g2.M = P; g2.N = C / 2; g2.K = P / 4;
+        g2.lda = P / 4; g2.ldb = C / 2; g2.ldc = C / 2;
+        g2.stride_a = (int64_t)P * (P / 4); g2.stride_b = (int64_t)(P / 4) * (C / 2);
+        g2.stride_c = (int64_t)P * (C / 2);
+        g2.a_kmajor = 0; g2.b_kmajor = 1; g2.alpha = 1.f; g2.accumulate = 0;
+        RET_IF(p2l_gemm_ws(&g2, W + L.att_P, W + L.att_g_p, W + L.att_ag, skws, L.skws_floats * sizeof(float), st));
+      }
       ConvCall oc = mk_conv(B, H, H, C / 2, C, 1);
       oc.x = W + L.att_ag; oc.w = m->att_w[3]; oc.y = W + L.att_y;
       oc.d.alpha = m->gamma; oc.res = x; oc.d.res_ld = C;
@@ -511,40 +538,51 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       ConvCall dob = mk_conv(B, H, H, C, C / 2, 1);
       dob.x = ga; dob.w = m->att_wt[3]; dob.y = W + L.d_ag; dob.d.alpha = m->gamma;
       RET_IF(run_conv(dob, skws, L.skws_floats, st));
+      if (L.att_fused) {
+        // d g_p = P^T d_ag with P recomputed from lse; then d theta, d phi_p: P and dP are
+        // recomputed tile by tile, dS^T goes once through the scratch buffer gb
+        P2LAttn ad{B, P, P / 4, C / 8, C / 2};
+        RET_IF(p2l_attn_bwd_dv(&ad, W + L.att_theta, W + L.att_phi_p, W + L.d_ag, W + L.att_lse,
+                               W + L.d_g_p, W + L.att_ws, L.att_ws_floats * sizeof(float), st));
+        RET_IF(p2l_attn_bwd_qk(&ad, W + L.att_theta, W + L.att_phi_p, W + L.att_g_p, W + L.att_ag,
+                               W + L.d_ag, W + L.att_lse, gb, W + L.d_theta, W + L.d_phi_p,
+                               W + L.att_ws, L.att_ws_floats * sizeof(float), st));
+      } else {
       // dP[p,k] = sum_c d_ag[p,c] g_p[k,c]
-      P2LGemm q1{};
-      q1.batch = B; q1.M = P; q1.N = P / 4; q1.K = C / 2;
-      q1.lda = C / 2; q1.ldb = C / 2; q1.ldc = P / 4;
-      q1.stride_a = (int64_t)P * (C / 2); q1.stride_b = (int64_t)(P / 4) * (C / 2);
-      q1.stride_c = (int64_t)P * (P / 4);
-      q1.alpha = 1.f;
-      RET_IF(p2l_gemm_ws(&q1, W + L.d_ag, W + L.att_g_p, gb, skws, L.skws_floats * sizeof(float), st));
-      // d g_p[k,c] = sum_p P[p,k] d_ag[p,c]
-      P2LGemm q2{};
-      q2.batch = B; q2.M = P / 4; q2.N = C / 2; q2.K = P;
-      q2.lda = P / 4; q2.ldb = C / 2; q2.ldc = C / 2;
-      q2.stride_a = (int64_t)P * (P / 4); q2.stride_b = (int64_t)P * (C / 2);
-      q2.stride_c = (int64_t)(P / 4) * (C / 2);
-      q2.a_kmajor = 1; q2.b_kmajor = 1; q2.alpha = 1.f;
-      RET_IF(p2l_gemm_ws(&q2, W + L.att_P, W + L.d_ag, W + L.d_g_p, skws, L.skws_floats * sizeof(float), st));
-      // dS = softmax backward (in place in gb)
-      RET_IF(p2l_softmax_bwd(W + L.att_P, gb, gb, (int64_t)B * P, P / 4, st));
-      // d theta[p,d] = sum_k dS[p,k] phi_p[k,d]
-      P2LGemm q3{};
-      q3.batch = B; q3.M = P; q3.N = C / 8; q3.K = P / 4;
-      q3.lda = P / 4; q3.ldb = C / 8; q3.ldc = C / 8;
-      q3.stride_a = (int64_t)P * (P / 4); q3.stride_b = (int64_t)(P / 4) * (C / 8);
-      q3.stride_c = (int64_t)P * (C / 8);
-      q3.b_kmajor = 1; q3.alpha = 1.f;
-      RET_IF(p2l_gemm_ws(&q3, gb, W + L.att_phi_p, W + L.d_theta, skws, L.skws_floats * sizeof(float), st));
-      // d phi_p[k,d] = sum_p dS[p,k] theta[p,d]
-      P2LGemm q4{};
-      q4.batch = B; q4.M = P / 4; q4.N = C / 8; q4.K = P;
-      q4.lda = P / 4; q4.ldb = C / 8; q4.ldc = C / 8;
-      q4.stride_a = (int64_t)P * (P / 4); q4.stride_b = (int64_t)P * (C / 8);
-      q4.stride_c = (int64_t)(P / 4) * (C / 8);
-      q4.a_kmajor = 1; q4.b_kmajor = 1; q4.alpha = 1.f;
-      RET_IF(p2l_gemm_ws(&q4, gb, W + L.att_theta, W + L.d_phi_p, skws, L.skws_floats * sizeof(float), st));
+        P2LGemm q1{};
+        q1.batch = B; q1.M = P; q1.N = P / 4; q1.K = C / 2;
+        q1.lda = C / 2; q1.ldb = C / 2; q1.ldc = P / 4;
+        q1.stride_a = (int64_t)P * (C / 2); q1.stride_b = (int64_t)(P / 4) * (C / 2);
+        q1.stride_c = (int64_t)P * (P / 4);
+        q1.alpha = 1.f;
+        RET_IF(p2l_gemm_ws(&q1, W + L.d_ag, W + L.att_g_p, gb, skws, L.skws_floats * sizeof(float), st));
+        // d g_p[k,c] = sum_p P[p,k] d_ag[p,c]
+        P2LGemm q2{};
+        q2.batch = B; q2.M = P / 4; q2.N = C / 2; q2.K = P;
+        q2.lda = P / 4; q2.ldb = C / 2; q2.ldc = C / 2;
+        q2.stride_a = (int64_t)P * (P / 4); q2.stride_b = (int64_t)P * (C / 2);
+        q2.stride_c = (int64_t)(P / 4) * (C / 2);
+        q2.a_kmajor = 1; q2.b_kmajor = 1; q2.alpha = 1.f;
+        RET_IF(p2l_gemm_ws(&q2, W + L.att_P, W + L.d_ag, W + L.d_g_p, skws, L.skws_floats * sizeof(float), st));
+        // dS = softmax backward (in place in gb)
+        RET_IF(p2l_softmax_bwd(W + L.att_P, gb, gb, (int64_t)B * P, P / 4, st));
+        // d theta[p,d] = sum_k dS[p,k] phi_p[k,d]
+        P2LGemm q3{};
+        q3.batch = B; q3.M = P; q3.N = C / 8; q3.K = P / 4;
+        q3.lda = P / 4; q3.ldb = C / 8; q3.ldc = C / 8;
+        q3.stride_a = (int64_t)P * (P / 4); q3.stride_b = (int64_t)(P / 4) * (C / 8);
+        q3.stride_c = (int64_t)P * (C / 8);
+        q3.b_kmajor = 1; q3.alpha = 1.f;
+        RET_IF(p2l_gemm_ws(&q3, gb, W + L.att_phi_p, W + L.d_theta, skws, L.skws_floats * sizeof(float), st));
+        // d phi_p[k,d] = sum_p dS[p,k] theta[p,d]
+        P2LGemm q4{};
+        q4.batch = B; q4.M = P / 4; q4.N = C / 8; q4.K = P;
+        q4.lda = P / 4; q4.ldb = C / 8; q4.ldc = C / 8;
+        q4.stride_a = (int64_t)P * (P / 4); q4.stride_b = (int64_t)P * (C / 8);
+        q4.stride_c = (int64_t)(P / 4) * (C / 8);
+        q4.a_kmajor = 1; q4.b_kmajor = 1; q4.alpha = 1.f;
+        RET_IF(p2l_gemm_ws(&q4, gb, W + L.att_theta, W + L.d_phi_p, skws, L.skws_floats * sizeof(float), st));
+      }
       // max-pool backward for phi and g
       RET_IF(p2l_maxpool2_bwd(W + L.att_phi, C / 8, W + L.d_phi_p, C / 8, nullptr, 0,
                               W + L.d_phi, C / 8, B, H, H, C / 8, 0, st));

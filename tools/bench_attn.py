@@ -30,3 +30,12 @@ print('d values: materialised %.3f ms   fused %.3f ms' % (
 fl = 2.0 * B * Nq * Nk * (64 + 256)
 t = timed(lambda: O.attn_fwd(q, k, v), 20)
 print('fused forward: %.1f TFLOP/s algorithmic' % (fl / t / 1e9))
+dP = O.gemm(do, v, B, Nq, Nk, 256)
+def old_qk():
+    dPm = O.gemm(do, v, B, Nq, Nk, 256)
+    dS = O.softmax_bwd(P.view(B * Nq, Nk), dPm.view(B * Nq, Nk)).view(B, Nq, Nk)
+    dq = O.gemm(dS, k, B, Nq, 64, Nk, b_kmajor=True)
+    dk = O.gemm(dS, q, B, Nk, 64, Nq, a_kmajor=True, b_kmajor=True)
+    return dq, dk
+print('d q, d k: materialised %.3f ms (+ S, softmax recompute)   fused %.3f ms' % (
+    timed(old_qk), timed(lambda: O.attn_bwd_qk(q, k, v, out, do, lse))))
