@@ -213,10 +213,12 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const AttnK a) {
       rs += __shfl_xor(rs, 32, 64);
       l_run = l_run * alpha + rs;
       m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {      // (rare after the first tiles)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[j][r] *= alpha;
+          for (int r = 0; r < 16; ++r) O[j][r] *= alpha;
+      }
     } else {
       const float* st = reinterpret_cast<const float*>(Wb + AT_WU);
 #pragma unroll
@@ -296,9 +298,9 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const AttnK a) {
 //     accumulator registers; transposed (keys = MFMA rows) so that a lane owns one query and
 //     lse / D are per-lane scalars;
 //   * operands are bf16x3 "row images" [32-row tile][16-channel chunk][piece][lane] made once
-//     per call (attn_rows_prep_kernel); a chunk stage is 36 KB (4 + 8 row tiles), LDS DMA,
-//     double buffered, one barrier per chunk (24 MFMAs per wave).
-constexpr int AX_STAGE_U = 12 * 192;                     // 4 key tiles + 8 query tiles, 3 KB each
+//     per call (attn_rows_prep_kernel); a stage is two chunks = 72 KB (4 + 8 row tiles each),
+//     LDS DMA, double buffered, one barrier per stage (48 MFMAs per wave).
+constexpr int AX_STAGE_U = 2 * 12 * 192;                 // 2 chunks x (4 key tiles + 8 query tiles), 3 KB each
 constexpr size_t AX_LDS_BYTES = (size_t)2 * AX_STAGE_U * 16;
 
 struct AttnX {
@@ -354,19 +356,20 @@ __global__ __launch_bounds__(512, 1) void attn_ds_kernel(const AttnX a) {
   const int qb = id % nqb, b = id / nqb;
   const int ktile0 = b * (a.Nk >> 5) + kb * 4, qtile0 = b * (a.Nq >> 5) + qb * 8;
 
-  // chunk c of 20: 0..3 = S (phi | theta images, 4 chunks per tile), 4..19 = dP (g | d(o), 16)
-  auto dma_chunk = [&](int c, int buf) {
-    const bool sp = c < 4;
+  // stage s of 10 = two 16-channel chunks: 0..1 = S (phi | theta images, 4 chunks per tile),
+  // 2..9 = dP (g | d(o), 16 chunks per tile)
+  auto dma_stage = [&](int sidx, int buf) {
+    const bool sp = sidx < 2;
     const f32x4* ai = sp ? a.kimg : a.vimg;
     const f32x4* bi = sp ? a.qimg : a.doimg;
-    const int nch = sp ? 4 : 16, ch = sp ? c : c - 4;
+    const int nch = sp ? 4 : 16, ch0 = sp ? 2 * sidx : 2 * (sidx - 2);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int ins = wave + 8 * i;                       // 36 wave-instructions of 1 KB
-      if (ins >= 36) continue;
-      const int slot = ins / 3, piece = ins - slot * 3;   // slots 0..3 key tiles, 4..11 query tiles
-      const f32x4* g = (slot < 4 ? ai + ((size_t)(ktile0 + slot) * nch + ch) * 192
-                                 : bi + ((size_t)(qtile0 + slot - 4) * nch + ch) * 192) + piece * 64 + lane;
+    for (int i = 0; i < 9; ++i) {
+      const int ins = wave + 8 * i;                       // 72 wave-instructions of 1 KB
+      const int half = ins / 36, in2 = ins - half * 36;
+      const int slot = in2 / 3, piece = in2 - slot * 3;   // slots 0..3 key tiles, 4..11 query tiles
+      const f32x4* g = (slot < 4 ? ai + ((size_t)(ktile0 + slot) * nch + ch0 + half) * 192
+                                 : bi + ((size_t)(qtile0 + slot - 4) * nch + ch0 + half) * 192) + piece * 64 + lane;
       const unsigned lds_base = __builtin_amdgcn_readfirstlane(
           (unsigned)(size_t)(__attribute__((address_space(3))) float*)(smem + ((size_t)buf * AX_STAGE_U + ins * 64) * 4));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
@@ -383,28 +386,38 @@ __global__ __launch_bounds__(512, 1) void attn_ds_kernel(const AttnX a) {
       for (int r = 0; r < 16; ++r) { accS[mi][ni][r] = 0.f; accP[mi][ni][r] = 0.f; }
 
   auto compute = [&](int buf, f32x16 (&acc)[2][2]) {
-    const f32x4* st = reinterpret_cast<const f32x4*>(smem) + (size_t)buf * AX_STAGE_U;
-    bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int half = 0; half < 2; ++half) {
+      const f32x4* st = reinterpret_cast<const f32x4*>(smem) + (size_t)buf * AX_STAGE_U + half * 12 * 192;
+      bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        fa[i][p] = __builtin_bit_cast(bf16x8, st[((2 * wm + i) * 3 + p) * 64 + lane]);
-        fb[i][p] = __builtin_bit_cast(bf16x8, st[((4 + 2 * wn + i) * 3 + p) * 64 + lane]);
-      }
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int p = 0; p < 3; ++p) {
+          fa[i][p] = __builtin_bit_cast(bf16x8, st[((2 * wm + i) * 3 + p) * 64 + lane]);
+          fb[i][p] = __builtin_bit_cast(bf16x8, st[((4 + 2 * wn + i) * 3 + p) * 64 + lane]);
+        }
+      // the six terms of a product stay in their order per accumulator; consecutive MFMAs go
+      // to different accumulators (no back-to-back dependence on the matrix pipe)
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma6(fa[mi], fb[ni], acc[mi][ni]);
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t6]], fb[ni][TB[t6]],
+                                                                  acc[mi][ni], 0, 0, 0);
+    }
   };
 
-  dma_chunk(0, 0);
+  dma_stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int c = 0; c < 20; ++c) {
+  for (int c = 0; c < 10; ++c) {
     const int buf = c & 1;
-    if (c + 1 < 20) dma_chunk(c + 1, buf ^ 1);
-    if (c < 4) compute(buf, accS); else compute(buf, accP);
+    if (c + 1 < 10) dma_stage(c + 1, buf ^ 1);
+    if (c < 2) compute(buf, accS); else compute(buf, accP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
