@@ -217,7 +217,14 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *   Model structs (P2LBigGAN.wfmt ...) hold the 3x3 format in bits 0-3 and P2L_WFMT_FLAG_PW when
  *   their 1x1 weight buffers are P2L_WFMT_PW buffers. */
 enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2, P2L_WFMT_PW = 3,
-       P2L_WFMT_FLAG_PW = 0x10 };
+       P2L_WFMT_BF16X3T = 4, P2L_WFMT_FLAG_PW = 0x10, P2L_WFMT_FLAG_THIN = 0x20 };
+/* P2L_WFMT_BF16X3T (3x3 convs with THREE real channels on one side, padded to N_pad == 32 or
+ * K_pad == 16: conv_to_rgb, the first VGG conv and their input gradients): the BF16X3 image
+ * followed by the image of p2l_thin.hip's kernels (27 tap-channel products as one K dimension
+ * | a pointwise product onto 27 columns + 9-tap gather).  P2L_WFMT_FLAG_THIN in a MODEL
+ * descriptor's wfmt says its image-end weights were packed this way. */
+int p2l_pack_conv_weight_bf3t(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                              int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_pad, int K_pad,
                             int transpose_flip, float* w_packed, void* stream);
 size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt);

@@ -122,8 +122,8 @@ class P2LLossCache(C.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
-WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW = 0, 1, 2, 3
-WFMT_FLAG_PW = 0x10
+WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW, WFMT_BF16X3T = 0, 1, 2, 3, 4
+WFMT_FLAG_PW, WFMT_FLAG_THIN = 0x10, 0x20
 
 
 def default_wfmt():
@@ -139,6 +139,12 @@ def default_wfmt():
     if v in ('bf16x3', 'bf3', 'bf16x3w', '2'):
         return WFMT_BF16X3W
     raise ValueError('P2L_CONV_WFMT=%r (expected f32, bf16x3 or bf16x3-direct)' % v)
+
+
+def default_thin():
+    """3-channel image convs (conv_to_rgb, first VGG conv and their input gradients) on the
+    kernels of csrc/p2l_thin.hip unless P2L_THIN=0 or the exact-fp32 MFMA was asked for"""
+    return os.environ.get('P2L_THIN', '1') != '0' and default_wfmt() != WFMT_F32
 
 
 def default_pw():
@@ -170,6 +176,10 @@ def pack_conv_weight(src, taps, n_pad, k_pad, flip, wfmt, subpix_mode=None):
         return dst
     n = L.p2l_packed_weight_floats(taps, n_pad, k_pad, wfmt)
     dst = torch.empty(n, device=src.device, dtype=torch.float32)
+    if wfmt == WFMT_BF16X3T:
+        check(L.p2l_pack_conv_weight_bf3t(ptr(src), O, I, n_pad, k_pad, int(flip), ptr(dst), stream()),
+              'p2l_pack_conv_weight_bf3t')
+        return dst
     fn = {WFMT_F32: L.p2l_pack_conv_weight, WFMT_BF16X3: L.p2l_pack_conv_weight_bf3,
           WFMT_BF16X3W: L.p2l_pack_conv_weight_bf3w}[wfmt]
     check(fn(ptr(src), O, I, taps, n_pad, k_pad, int(flip), ptr(dst), stream()),
@@ -184,6 +194,7 @@ EXPORTS = [
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
     'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode', 'p2l_set_wino_block', 'p2l_wino_set_trace',
+    'p2l_pack_conv_weight_bf3t',
     'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_attn_supported', 'p2l_attn_fwd_ws_bytes', 'p2l_attn_fwd', 'p2l_attn_bwd_dv_ws_bytes',
     'p2l_attn_bwd_dv', 'p2l_attn_bwd_qk_ws_bytes', 'p2l_attn_bwd_qk',

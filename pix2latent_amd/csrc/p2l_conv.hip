@@ -940,8 +940,17 @@ static bool pws_shape(const P2LConv* d) {
     return false;
   return d->H * d->W >= 1024 && d->Cout >= d->Cin;
 }
+// 3-channel image convs (p2l_thin.hip): 0 thin output, 1 thin input, -1 the generic kernel.
+// Shape + format only (the epilogue conditions are checked at the launch).
+static int thin_shape(const P2LConv* d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("P2L_THIN"); on = e ? atoi(e) : 1; }
+  if (!on || d->wfmt != P2L_WFMT_BF16X3T || d->taps != 9 || d->ups != 0) return -1;
+  if (d->H % 8 || d->W % 16 || d->x_ld % 4 || d->Cin % 16) return -1;
+  return p2l_thin_mode(d->Cout, d->Cin);
+}
 // either bf16x3 pointwise kernel: no split-K
-static bool pw_any(const P2LConv* d) { return pw_shape(d) || pws_shape(d); }
+static bool pw_any(const P2LConv* d) { return pw_shape(d) || pws_shape(d) || thin_shape(d) >= 0; }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
@@ -1044,7 +1053,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (!y && !yp) return P2L_EINVAL;
   if (d->ups && d->taps != 9) return P2L_EUNSUP;
   if (d->taps == 9 && d->wfmt != P2L_WFMT_F32 && d->wfmt != P2L_WFMT_BF16X3 &&
-      d->wfmt != P2L_WFMT_BF16X3W)
+      d->wfmt != P2L_WFMT_BF16X3W && d->wfmt != P2L_WFMT_BF16X3T)
     return P2L_EUNSUP;
   if (d->taps == 1 && d->wfmt != P2L_WFMT_F32 && d->wfmt != P2L_WFMT_PW) return P2L_EUNSUP;
   if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
@@ -1162,6 +1171,28 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     rc = p2l_pw_launch(kp, d->pro, st);
     if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     return rc;
+  }
+  // ---- 3-channel image convs ----
+  {
+    const int tm = thin_shape(d);
+    const bool geom = k.tw_log == 4 && k.th_log == 3 && k.tb_log == 0 && !k.partial && !ex;
+    if (tm == 1 && geom) {
+      ConvK kt = k;
+      kt.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
+      kt.splitk = 1;
+      rc = p2l_thinin_launch(kt, d->pro, st);
+      if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      return rc;
+    }
+    if (tm == 0 && geom && !arb && !res && !mask && d->pool == P2L_POOL_NONE && y) {
+      ConvK kt = k;
+      kt.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
+      kt.nchunks = d->Cin / 16;
+      kt.splitk = 1;
+      rc = p2l_thinout_launch(kt, d->pro, st);
+      if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      return rc;
+    }
   }
   // (forward layers only: with the fused activation backward the in-step time was 0.86x the
   //  exact-fp32 kernel's -- its x / shortcut loads sit behind the MFMAs of a 2-wave-per-SIMD
@@ -1471,6 +1502,7 @@ extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int w
   size_t n = direct * 3 / 2;
   if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
     n += p2l_wino_weight_floats(N_pad, K_pad);
+  if (wfmt == P2L_WFMT_BF16X3T && taps == 9) n += p2l_thin_weight_floats(N_pad, K_pad);
   return n;
 }
 
@@ -1485,6 +1517,16 @@ extern "C" int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_
                      (hipStream_t)stream, w_oihw, w_packed + total, O, I, 1, N_pad, K_pad, 16,
                      transpose_flip, 1);
   return p2l_check_launch();
+}
+
+// P2L_WFMT_BF16X3T: the direct bf16x3 image followed by the thin image of a conv with three real
+// channels on one side (p2l_thin.hip); N_pad == 32 (3 outputs) or K_pad == 16 (3 inputs)
+extern "C" int p2l_pack_conv_weight_bf3t(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                                         int transpose_flip, float* w_packed, void* stream) {
+  int rc = p2l_pack_conv_weight_bf3(w_oihw, O, I, 9, N_pad, K_pad, transpose_flip, w_packed, stream);
+  if (rc) return rc;
+  return p2l_thin_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip,
+                       w_packed + (size_t)9 * N_pad * K_pad * 3 / 2, (hipStream_t)stream);
 }
 
 extern "C" int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,

@@ -363,6 +363,14 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 int p2l_pw_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
 int p2l_pws_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);   // 64 / 128 input channels
 
+// 3-channel image ends of the pipeline (p2l_thin.hip)
+size_t p2l_thin_weight_floats(int N_pad, int K_pad);
+int p2l_thin_mode(int N_pad, int K_pad);
+int p2l_thin_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int flip, float* dst,
+                  hipStream_t st);
+int p2l_thinin_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
+int p2l_thinout_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
+
 // Winograd F(2x2,3x3) form of the bf16x3 3x3 conv (p2l_wino.hip)
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);
 extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad);

@@ -445,6 +445,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
   rc.d.pro = P2L_PRO_AFFINE_RELU; rc.d.pro_bstride = 0; rc.ps = m->tail_s; rc.pt = m->tail_t;
   rc.d.act = P2L_ACT_TANH; rc.d.y_ld = 16; rc.d.n_store = 16;
   rc.d.algo_flops = 2.0 * B * L.out_res * L.out_res * (double)m->ch * 3 * 9;
+  if (g_plan_wfmt & P2L_WFMT_FLAG_THIN) rc.d.wfmt = P2L_WFMT_BF16X3T;
   RET_IF(run_conv(rc, skws, L.skws_floats, st));
   return P2L_OK;
 }
@@ -479,6 +480,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     ConvCall c = mk_conv(B, R, R, 16, m->ch, 9);
     c.x = dimg16; c.w = m->rgb_wt;
     c.d.algo_flops = 2.0 * B * R * R * (double)m->ch * 3 * 9;
+    if (g_plan_wfmt & P2L_WFMT_FLAG_THIN) c.d.wfmt = P2L_WFMT_BF16X3T;
     const float* xlast = W + L.blk[m->n_blocks - 1].y;
     // ds/dt of the tail BN feed nothing (no conditioning): park them in `draw`.
     ArbArgs a{xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr, 0, 0, 0, W + L.draw,
@@ -691,6 +693,7 @@ int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, f
     if (i == 0) {
       c.d.pro = P2L_PRO_AFFINE; c.d.pro_bstride = 0; c.ps = v->in_s; c.pt = v->in_t;
       c.d.algo_flops = 2.0 * B * h * w * 3.0 * kVggCout[0] * 9;
+      if (g_plan_wfmt & P2L_WFMT_FLAG_THIN) c.d.wfmt = P2L_WFMT_BF16X3T;
     }
     if (vgg_pool_after(i)) {
       c.d.pool = P2L_POOL_MAX; c.yp = Wk + L.yp[pi];
@@ -846,6 +849,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
     ConvCall c = mk_conv(B, H, W, 64, 32, 9);
     c.x = ga; c.w = v->wt[0]; c.y = dimg16; c.d.y_ld = 16; c.d.n_store = 16;
     c.d.algo_flops = 2.0 * B * H * W * 3.0 * 64 * 9;
+    if (g_plan_wfmt & P2L_WFMT_FLAG_THIN) c.d.wfmt = P2L_WFMT_BF16X3T;
     RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
   }
   if (use_lpips == 2) return P2L_OK;   // PerceptualLoss on its own: no L1 term

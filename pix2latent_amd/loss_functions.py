@@ -102,14 +102,16 @@ class _VggLpipsParams(object):
         self.keep = []
         self.desc = N.P2LVggLpips()
         self.wfmt = N.default_wfmt()       # all 13 convs are 3x3
-        self.desc.wfmt = self.wfmt
+        thin = N.default_thin() and self.wfmt != N.WFMT_F32    # first conv: 3 real input channels
+        self.desc.wfmt = self.wfmt | (N.WFMT_FLAG_THIN if thin else 0)
         inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
         for i, (cin, cout) in enumerate(synthetic.VGG_CONVS):
             w = weights['vgg.conv%d.weight' % i].float()
             if i == 0:
-                self.desc.w[i] = self._pack(w, 9, cout, 16, False)
+                f0 = N.WFMT_BF16X3T if thin else None
+                self.desc.w[i] = self._pack(w, 9, cout, 16, False, f0)
                 # d scaled / d img = 1/scale per input channel: fold into the dgrad copy
-                self.desc.wt[i] = self._pack(w * inv_scale.view(1, 3, 1, 1), 9, 32, cout, True)
+                self.desc.wt[i] = self._pack(w * inv_scale.view(1, 3, 1, 1), 9, 32, cout, True, f0)
             else:
                 self.desc.w[i] = self._pack(w, 9, cout, cin, False)
                 self.desc.wt[i] = self._pack(w, 9, cin, cout, True)
@@ -128,9 +130,10 @@ class _VggLpipsParams(object):
         self.keep.append(t)
         return t.data_ptr()
 
-    def _pack(self, w, taps, n_pad, k_pad, flip):
-        dst = N.pack_conv_weight(w.detach().to(self.dev, torch.float32), taps, n_pad, k_pad, flip,
-                                 getattr(self, 'wfmt', N.WFMT_F32) if taps == 9 else N.WFMT_F32)
+    def _pack(self, w, taps, n_pad, k_pad, flip, fmt=None):
+        if fmt is None:
+            fmt = getattr(self, 'wfmt', N.WFMT_F32) if taps == 9 else N.WFMT_F32
+        dst = N.pack_conv_weight(w.detach().to(self.dev, torch.float32), taps, n_pad, k_pad, flip, fmt)
         torch.cuda.current_stream().synchronize()
         self.keep.append(dst)
         return dst.data_ptr()

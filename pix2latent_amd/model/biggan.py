@@ -121,7 +121,10 @@ class BigGAN(nn.Module):
         self._wfmt = N.default_wfmt() if wfmt is None else wfmt
         # 1x1 convs: same arithmetic on the bf16 pipe (their buffers then carry the pre-split image)
         self._pw = N.default_pw() and self._wfmt != N.WFMT_F32
-        self._desc.wfmt = self._wfmt | (N.WFMT_FLAG_PW if self._pw else 0)
+        # conv_to_rgb and its input gradient: three real channels on one side (csrc/p2l_thin.hip)
+        self._thin = N.default_thin() and self._wfmt != N.WFMT_F32
+        self._desc.wfmt = (self._wfmt | (N.WFMT_FLAG_PW if self._pw else 0) |
+                           (N.WFMT_FLAG_THIN if self._thin else 0))
         self._ws = None
         self._ws_B = -1
         self._ticket = 0
@@ -135,8 +138,10 @@ class BigGAN(nn.Module):
         self._keep.append(t)
         return t
 
-    def _pack_conv(self, w, taps, n_pad, k_pad, flip):
+    def _pack_conv(self, w, taps, n_pad, k_pad, flip, thin=False):
         fmt = self._wfmt if taps == 9 else (N.WFMT_PW if self._pw else N.WFMT_F32)
+        if thin and self._thin:
+            fmt = N.WFMT_BF16X3T
         dst = N.pack_conv_weight(w.detach().to(self._dev, torch.float32), taps, n_pad, k_pad, flip, fmt)
         torch.cuda.current_stream().synchronize()
         self._keep.append(dst)
@@ -206,8 +211,8 @@ class BigGAN(nn.Module):
         d.gamma = float(W[ap + '.gamma'].reshape(-1)[0])
         # tail
         wrgb = W['generator.conv_to_rgb.weight'][:3]
-        d.rgb_w = self._pack_conv(wrgb, 9, 32, self.ch, False).data_ptr()
-        d.rgb_wt = self._pack_conv(wrgb, 9, self.ch, 16, True).data_ptr()
+        d.rgb_w = self._pack_conv(wrgb, 9, 32, self.ch, False, thin=True).data_ptr()
+        d.rgb_wt = self._pack_conv(wrgb, 9, self.ch, 16, True, thin=True).data_ptr()
         brgb = torch.zeros(32)
         brgb[:3] = W['generator.conv_to_rgb.bias'][:3]
         d.rgb_b = self._dev_t(brgb).data_ptr()

@@ -666,3 +666,95 @@ def test_transposed_conv_subpixel(dev, O, h, Cin, Cout):
     dx, _ = O.conv(nhwc(dup, dev), wtsp, B, H, H, Cout, Cin, 9, ups=3, ext=1, splitk=1)
     torch.cuda.synchronize()
     assert relerr(nchw(dx), x.grad) < 2e-5
+
+
+# ---- 3-channel image convs (csrc/p2l_thin.hip, P2L_WFMT_BF16X3T) --------------------------------
+def _pad_c(x, C):
+    """[B,c,H,W] -> NHWC with the channels zero-padded to C"""
+    B, c, H, W = x.shape
+    out = torch.zeros(B, H, W, C)
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out
+
+
+@pytest.mark.parametrize('B,H,Cout', [(2, 32, 64), (3, 64, 128), (1, 16, 96)])
+def test_thin_input_conv(dev, O, B, H, Cout):
+    """first VGG conv form: 3 real input channels (stored as 16), LPIPS scaling layer as the
+    prologue, bias + ReLU + 2x2 max pool: 27 tap-channel products as one K dimension"""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, 3, H, H, generator=g)
+    w = torch.randn(Cout, 3, 3, 3, generator=g) / math.sqrt(27)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    s16, t16 = torch.zeros(16), torch.zeros(16)
+    s16[:3] = 0.5 + torch.rand(3, generator=g)
+    t16[:3] = torch.randn(3, generator=g) * 0.3
+    ref = F.relu(F.conv2d(x * s16[:3].view(1, 3, 1, 1) + t16[:3].view(1, 3, 1, 1), w, bias, padding=1))
+    wp = O.pack_conv_weight(w.to(dev), 9, Cout, 16, wfmt=4)
+    y, yp = O.conv(_pad_c(x, 16).to(dev), wp, B, H, H, 16, Cout, 9, wfmt=4, bias=bias.to(dev),
+                   pro=N.PRO_AFFINE, pro_s=s16.to(dev), pro_t=t16.to(dev), pro_bstride=0,
+                   act=N.ACT_RELU, pool=N.POOL_MAX)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), ref) < 2e-5
+    assert relerr(nchw(yp), F.max_pool2d(ref, 2, 2)) < 2e-5
+
+
+@pytest.mark.parametrize('skip', [None, 'same'])
+def test_thin_input_dgrad_fused_affine_relu_bwd(dev, O, skip):
+    """conv_to_rgb input gradient: dY has 3 real channels, the result 128, with the backward of
+    relu(x*s+t) fused into the epilogue (per-tile partial sums reduced across the 4 waves)"""
+    g = torch.Generator().manual_seed(32)
+    B, C, H = 2, 128, 32
+    x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+    s = (0.5 + torch.rand(B, C, generator=g)).requires_grad_(True)
+    t = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    w = torch.randn(3, C, 3, 3, generator=g) / math.sqrt(C * 9)
+    dy = torch.randn(B, 3, H, H, generator=g)
+    F.conv2d(F.relu(x * s.view(B, C, 1, 1) + t.view(B, C, 1, 1)), w, None, padding=1).backward(dy)
+    exp_dx = x.grad.clone()
+    sk_t, skip_C = None, 0
+    if skip == 'same':
+        sk = torch.randn(B, C, H, H, generator=g)
+        exp_dx = exp_dx + sk
+        sk_t, skip_C = nhwc(sk, dev), C
+    wt = O.pack_conv_weight(w.to(dev), 9, C, 16, flip=True, wfmt=4)
+    dx, ds, dt = O.conv_dgrad_arb(_pad_c(dy, 16).to(dev), wt, B, H, H, 16, C, 9, nhwc(x.detach(), dev),
+                                  s.detach().to(dev), t.detach().to(dev), C, wfmt=4, skip=sk_t,
+                                  skip_C=skip_C)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), exp_dx) < 2e-5
+    assert relerr(ds.cpu(), s.grad) < 5e-5
+    assert relerr(dt.cpu(), t.grad) < 5e-5
+
+
+@pytest.mark.parametrize('B,H,Cin', [(2, 32, 128), (3, 64, 64), (1, 16, 48)])
+def test_thin_output_conv_and_dgrad(dev, O, B, H, Cin):
+    """conv_to_rgb form (CBN+ReLU prologue, bias, tanh, 3 of 16 stored channels) and the first
+    VGG conv's input gradient (64 -> 3): pointwise product onto 27 columns + 9-tap gather"""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(3, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b32 = torch.zeros(32)
+    b32[:3] = torch.randn(3, generator=g) * 0.1
+    s = 0.5 + torch.rand(B, Cin, generator=g)
+    t = torch.randn(B, Cin, generator=g) * 0.3
+    a = F.relu(x * s.view(B, Cin, 1, 1) + t.view(B, Cin, 1, 1))
+    ref = torch.tanh(F.conv2d(a, w, None, padding=1) * 0.7 + b32[:3].view(1, 3, 1, 1))
+    wp = O.pack_conv_weight(w.to(dev), 9, 32, Cin, wfmt=4)
+    y, _ = O.conv(nhwc(x, dev), wp, B, H, H, Cin, 32, 9, wfmt=4, bias=b32.to(dev), alpha=0.7,
+                  pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin,
+                  act=N.ACT_TANH, n_store=16, y_ld=16)
+    torch.cuda.synchronize()
+    got = nchw(y)
+    assert relerr(got[:, :3], ref) < 2e-5
+    assert got[:, 3:].abs().max().item() == 0.0
+    # input gradient of a conv 3 -> Cin: dY [B,Cin,H,H] -> d img [B,3,H,H]
+    wf = torch.randn(Cin, 3, 3, 3, generator=g) / math.sqrt(27)
+    img = torch.randn(B, 3, H, H, generator=g, requires_grad=True)
+    dy = torch.randn(B, Cin, H, H, generator=g)
+    F.conv2d(img, wf, None, padding=1).backward(dy)
+    wt = O.pack_conv_weight(wf.to(dev), 9, 32, Cin, flip=True, wfmt=4)
+    di, _ = O.conv(nhwc(dy, dev), wt, B, H, H, Cin, 32, 9, wfmt=4, n_store=16, y_ld=16)
+    torch.cuda.synchronize()
+    assert relerr(nchw(di)[:, :3], img.grad) < 2e-5
