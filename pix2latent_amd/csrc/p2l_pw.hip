@@ -24,15 +24,21 @@
 //     copied global -> registers -> LDS as an image.
 #include "p2l_conv_k.h"
 
+#include <cstdlib>
+
 using namespace p2lconv;
 
 namespace {
 
-constexpr int PW_KS = 64;                               // channels per stage
-constexpr int PW_SUB = PW_KS / 16;                      // 16-channel sub-chunks per stage
-constexpr int PW_A_FLOATS = PW_SUB * 128 * 24;          // [sub][128 rows][96 B]
-constexpr int PW_B_FLOATS = PW_SUB * 64 * 24;           // [sub][2 N-tiles x 32 rows][96 B]
-constexpr size_t PW_LDS_BYTES = (size_t)(PW_A_FLOATS + PW_B_FLOATS) * sizeof(float);
+// KS = channels per stage: 64 (72 KB of LDS, two blocks per CU) or 32 (36 KB: three -- a block
+// is one load -> split -> multiply -> store latency chain, and layers with 256 input channels
+// have only 4 / 8 stages to amortise it over: more chains in flight beat fewer barriers)
+template <int KS> struct PwCfg {
+  static constexpr int SUB = KS / 16;                   // 16-channel sub-chunks per stage
+  static constexpr int A_FLOATS = SUB * 128 * 24;       // [sub][128 rows][96 B]
+  static constexpr int B_FLOATS = SUB * 64 * 24;        // [sub][2 N-tiles x 32 rows][96 B]
+  static constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+};
 
 __device__ __forceinline__ void pw_store_split(float* As, int row, int q4, const f32x4 x) {
   bf16x4 ph, pm, pl;
@@ -44,8 +50,10 @@ __device__ __forceinline__ void pw_store_split(float* As, int row, int q4, const
   *reinterpret_cast<bf16x4*>(rq + 64) = pl;
 }
 
-template <int PRO>
-__global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
+template <int PRO, int KS>
+__global__ __launch_bounds__(256, KS == 64 ? 2 : 4) void pw_bf3_kernel(const ConvK k) {
+  constexpr int PW_KS = KS, PW_SUB = PwCfg<KS>::SUB, PW_A_FLOATS = PwCfg<KS>::A_FLOATS;
+  constexpr int VPP = KS / 4;                            // float4 per pixel and stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + PW_A_FLOATS;
@@ -66,12 +74,12 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
 
   // ---- A staging: 128 pixels x 16 float4 per stage = 8 items per thread; item j = tid + 256*it
   // covers pixel j >> 4, float4 (tid & 15) of the stage: sub-chunk (tid & 15) >> 2, quarter & 3
-  constexpr int A_ITERS = 8;
-  const int av = tid & 15;
+  constexpr int A_ITERS = 128 * VPP / 256;
+  const int av = tid & (VPP - 1);
   int a_goff[A_ITERS];
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
-    const int p = (tid + 256 * it) >> 4;
+    const int p = (tid + 256 * it) / VPP;
     const int Q = p >> 2, s = p & 3;
     const int qx = Q & ((TW >> 1) - 1);
     const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
   const int s_off = b0 * k.pro_bstride + av * 4;
   // ---- B staging: [sub][64 rows][6 x 16 B] = 1536 items per stage, 6 per thread; the packed
   // image is [chunk][32-channel tile][32 rows][96 B]: the 2 tiles of this block are one 6 KB run
-  constexpr int B_ITERS = 6;
+  constexpr int B_ITERS = PW_SUB * 384 / 256;
   int b_goff[B_ITERS];
 #pragma unroll
   for (int it = 0; it < B_ITERS; ++it) {
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
     const int sub = j / 384, within = j - sub * 384;
     b_goff[it] = (sub * (k.Cout >> 5) + (n0 >> 5)) * 32 * 24 + within * 4;
   }
-  const int b_stage = 4 * (k.Cout >> 5) * 32 * 24;       // floats per stage of the image
+  const int b_stage = PW_SUB * (k.Cout >> 5) * 32 * 24;  // floats per stage of the image
 
   f32x4 xr[A_ITERS], wr[B_ITERS], sr, tr;
   auto load_regs = [&](int st) {
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
           v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
       }
-      const int p = (tid + 256 * it) >> 4;
+      const int p = (tid + 256 * it) / VPP;
       pw_store_split(As + (av >> 2) * (128 * 24), p, av & 3, v);
     }
 #pragma unroll
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void pw_bf3_kernel(const ConvK k) {
 
   const int a_row = wave * 32 + l31;
   const int a_c = bf3_chunk(lhi, a_row) * 4, b_c = bf3_chunk(lhi, l31) * 4;
-  const int nstages = k.nchunks;                         // = Cin / 64
+  const int nstages = k.Cin / KS;
   load_regs(0);
   write_lds();
   __syncthreads();
@@ -303,19 +311,23 @@ __global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
 
 int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles), block(256);
-#define P2L_PW(PRO)                                                                          \
+  static int ks_env = -1;                                // $P2L_PW_KS = 64 | 32 (default 32)
+  if (ks_env < 0) { const char* e = getenv("P2L_PW_KS"); ks_env = e ? atoi(e) : 32; }
+#define P2L_PW(PRO, KSV)                                                                     \
   do {                                                                                       \
     static bool attr_set = false;                                                            \
     if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)pw_bf3_kernel<PRO>,                             \
+      (void)hipFuncSetAttribute((const void*)pw_bf3_kernel<PRO, KSV>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
-    hipLaunchKernelGGL(pw_bf3_kernel<PRO>, grid, block, PW_LDS_BYTES, st, k);                \
+    hipLaunchKernelGGL((pw_bf3_kernel<PRO, KSV>), grid, block, PwCfg<KSV>::LDS_BYTES, st, k); \
   } while (0)
-  if (pro == P2L_PRO_NONE) P2L_PW(P2L_PRO_NONE);
-  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW(P2L_PRO_AFFINE_RELU);
-  else P2L_PW(P2L_PRO_AFFINE);
+#define P2L_PW_K(PRO) do { if (ks_env == 64) P2L_PW(PRO, 64); else P2L_PW(PRO, 32); } while (0)
+  if (pro == P2L_PRO_NONE) P2L_PW_K(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW_K(P2L_PRO_AFFINE_RELU);
+  else P2L_PW_K(P2L_PRO_AFFINE);
+#undef P2L_PW_K
 #undef P2L_PW
   return p2l_check_launch();
 }
