@@ -402,8 +402,11 @@ def main():
                 'last_losses': [round(x, 6) for x in last_loss],
             },
             'roofline': {
-                'kernel': ('conv_mfma_kernel<TAPS=9,BF3> (3x3 implicit GEMM, 6 x '
-                           'v_mfma_f32_32x32x16_bf16 per 16 channels on 3-way split fp32 operands)'
+                'kernel': ('every 3x3 conv launch of the step, bf16x3 arithmetic (6 x '
+                           'v_mfma_f32_32x32x16_bf16 per 16 channels on 3-way split fp32 operands): '
+                           'wino16_conv_kernel / wino_conv_kernel (Winograd F(2x2,3x3), 16x16 | 8x16 '
+                           'pixel blocks), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel), '
+                           'conv_thinin/thinout_kernel (3-channel image convs)'
                            if bf3 else
                            'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                 'bound': 'mfma',

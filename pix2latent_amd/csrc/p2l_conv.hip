@@ -1181,7 +1181,10 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       kt.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
       kt.splitk = 1;
       rc = p2l_thinin_launch(kt, d->pro, st);
-      if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      if (prof_slot >= 0) {
+        g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * 32.0 * d->Cout;    // K = 27 -> 32
+        (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      }
       return rc;
     }
     if (tm == 0 && geom && !arb && !res && !mask && d->pool == P2L_POOL_NONE && y) {
@@ -1190,7 +1193,11 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       kt.nchunks = d->Cin / 16;
       kt.splitk = 1;
       rc = p2l_thinout_launch(kt, d->pro, st);
-      if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      if (prof_slot >= 0) {
+        // pointwise product onto 32 columns for the 8x16 pixels + halo (192 rows per 128)
+        g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * 1.5 * d->Cin * 32.0;
+        (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      }
       return rc;
     }
   }
