@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(f)))
 by = collections.OrderedDict()
 for r in rows:
     n = r['Kernel_Name']
-    if 'conv_mfma' not in n and 'wino_conv' not in n: continue
+    if 'conv_mfma' not in n and 'wino' not in n: continue
     key = (int(r['Dispatch_Id']), ('wino16' if 'wino16' in n else 'wino8' if 'wino' in n else 'direct'), r['Grid_Size'])
     by.setdefault(key, {})[r['Counter_Name']] = float(r['Counter_Value'])
 print('disp kind grid  mfma_busy parked issue_stall issuing valu_share lds_busy lds_conf clk(GUI cycles)')
