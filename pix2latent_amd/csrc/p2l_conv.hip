@@ -921,25 +921,14 @@ static bool pw_shape(const P2LConv* d) {
   if (on < 0) { const char* e = getenv("P2L_PW"); on = e ? atoi(e) : 1; }
   if (!on || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
   if (d->Cin % 64 || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16) return false;
-  // measured per layer inside the bench step (profiles/round2_layers_pointwise.txt): 1.1-1.4x
-  // the exact-fp32 kernel from 256 input channels up; with 64 / 128 input channels (one or two
-  // stages, nothing to overlap the split with, HBM-bound anyway) 0.8-0.9x
+  // measured per layer inside the bench step: 1.2-1.9x the exact-fp32 kernel from 256 input
+  // channels up, 1.07-1.39x with 64 / 128 (32-channel stages, four blocks per CU; the first
+  // 64-channel-stage form was 0.8-0.9x there, hence the switch)
   static int min_cin = -1;
-  if (min_cin < 0) { const char* e = getenv("P2L_PW_MIN_CIN"); min_cin = e ? atoi(e) : 256; }
+  if (min_cin < 0) { const char* e = getenv("P2L_PW_MIN_CIN"); min_cin = e ? atoi(e) : 64; }
   return d->H * d->W >= 1024 && d->Cin >= min_cin;
 }
 
-// streaming bf16x3 form of the 1x1 conv (pws_bf3_kernel): 64 / 128 input channels, at least as
-// many output channels -- the channel-expanding, HBM-bound layers.  Shape-only, like the
-// other kernel choices (results must not depend on the batch a candidate is evaluated in).
-static bool pws_shape(const P2LConv* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("P2L_PWS"); on = e ? atoi(e) : 1; }
-  if (!on || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
-  if ((d->Cin != 64 && d->Cin != 128) || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16)
-    return false;
-  return d->H * d->W >= 1024 && d->Cout >= d->Cin;
-}
 // 3-channel image convs (p2l_thin.hip): 0 thin output, 1 thin input, -1 the generic kernel.
 // Shape + format only (the epilogue conditions are checked at the launch).
 static int thin_shape(const P2LConv* d) {
@@ -950,7 +939,7 @@ static int thin_shape(const P2LConv* d) {
   return p2l_thin_mode(d->Cout, d->Cin);
 }
 // either bf16x3 pointwise kernel: no split-K
-static bool pw_any(const P2LConv* d) { return pw_shape(d) || pws_shape(d) || thin_shape(d) >= 0; }
+static bool pw_any(const P2LConv* d) { return pw_shape(d) || thin_shape(d) >= 0; }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
@@ -1200,18 +1189,6 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       }
       return rc;
     }
-  }
-  // (forward layers only: with the fused activation backward the in-step time was 0.86x the
-  //  exact-fp32 kernel's -- its x / shortcut loads sit behind the MFMAs of a 2-wave-per-SIMD
-  //  kernel -- so those launches stay where they were)
-  if (pws_shape(d) && !arb) {
-    ConvK kp = k;
-    kp.w = w + (size_t)d->Cout * d->Cin;
-    kp.nchunks = d->Cin / 16;
-    kp.splitk = 1;
-    rc = p2l_pws_launch(kp, d->pro, st);
-    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
-    return rc;
   }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
   if (d->ups >= 2) {

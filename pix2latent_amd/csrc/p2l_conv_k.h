@@ -361,7 +361,6 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 
 // bf16x3 form of the 1x1 conv (p2l_pw.hip)
 int p2l_pw_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
-int p2l_pws_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);   // 64 / 128 input channels
 
 // 3-channel image ends of the pipeline (p2l_thin.hip)
 size_t p2l_thin_weight_floats(int N_pad, int K_pad);

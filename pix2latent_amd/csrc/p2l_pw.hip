@@ -9,11 +9,15 @@
 // 8 x 64.
 //
 // Why this works for ONE tap where the 3x3 kernel's per-chunk structure did not (round 1
-// measured 0.62-0.93x with it): the split costs ~40 VALU cycles per activation value, and a
-// 16-channel chunk of a 1x1 conv has only 12 MFMAs per wave to hide it behind plus two
-// barriers.  Here a stage is 64 channels: every thread splits 32 values (8 float4) while the
-// previous stage's 48 MFMAs per wave run, one barrier pair per 64 channels, two blocks per CU
-// (72 KB of LDS each) overlap one block's split with the other's multiply.
+// measured 0.62-0.93x with it): a 16-channel chunk of a 1x1 conv has only 12 MFMAs per wave to
+// hide the operand split behind plus two barriers.  Here a stage is several chunks: every thread
+// splits its values while the previous stage's MFMAs run, one barrier pair per stage.  A block
+// is ONE load -> split -> multiply -> store latency chain and these layers have few stages, so
+// what counts is how many chains a CU has in flight: 32-channel stages (36 KB of LDS, <= 118
+// VGPR: four blocks per CU) beat the first 64-channel form (72 KB, two blocks) by 1.14-1.40x
+// and now also win on the 64 / 128-input-channel layers (a streaming kernel written for those
+// -- 32-pixel blocks, A fragments in registers, waves sweeping different output tiles -- was
+// 1.05-1.13x the fp32 kernel and is gone: this one is 1.2-1.4x).
 //
 //   * block = the 128-pixel quad-ordered tile of the direct kernel (same epilogue: residual,
 //     nearest-x2 shortcut, pooling, fused activation backward) x 64 output channels;
@@ -176,137 +180,6 @@ __global__ __launch_bounds__(256, KS == 64 ? 2 : 4) void pw_bf3_kernel(const Con
 }
 
 
-// ---- streaming form for 64 / 128 input channels --------------------------------------------
-// The layers that EXPAND channels (BigGAN-deep conv_3 forward, conv_0 input-gradient:
-// 64->256 at 128^2, 128->512 at 64^2, 64->128 at 256^2 ...) move 4-9x more output than input
-// bytes and are HBM-bound: 75-980 MB per launch against 10 GFLOP.  What matters is HOW the
-// output rows (1-2 KB per pixel) reach DRAM.  A first version of this kernel gave a wave 32
-// pixels and let it walk over the channels 128 B at a time: every pixel row was visited 8-16
-// times, tens of microseconds apart, and the in-step time was 0.5-0.9x the exact-fp32 kernel
-// although an isolated (Infinity-Cache resident) benchmark showed 1.3-1.5x.  So:
-//
-//   * block = 32 pixels (2 image rows x 16), split ONCE into bf16x3 and staged in LDS (12 /
-//     24 KB); every wave pulls all A fragments into registers (48 / 96 VGPRs);
-//   * the 4 waves take DIFFERENT 32-channel output tiles (wave w: tiles w, w+4, ...): one
-//     sweep of the block writes 512 B contiguous per pixel, the whole row within 2-4 sweeps;
-//   * weights come straight from the packed image in L2 into B-fragment registers (the image
-//     rows ARE fragment rows), 4 sub-chunks ahead of their use; no barrier after the staging;
-//   * wave-private LDS transpose -> the shared epilogue item (16 B per lane).
-// Forward epilogues only (bias / residual / activation / mask / pooling).
-// Same products in the same order as pw_bf3_kernel: bit-identical results.
-constexpr int PWS_EP = 36;                                // dump pitch of one 32-column tile
-
-template <int PRO, int KSUB>
-__global__ __launch_bounds__(256, 2) void pws_bf3_kernel(const ConvK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                       // [KSUB][32 rows][96 B]
-  float* dump = smem + KSUB * 768;                        // [4 waves][32][PWS_EP]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx_n = k.W >> 4, per_image = tx_n * (k.H >> 1);
-  const int b0 = swz / per_image, t32 = swz - b0 * per_image;
-  const int ty = t32 / tx_n, tx = t32 - ty * tx_n;
-  const int y0 = ty * 2, x0 = tx * 16;
-
-  // ---- A: 32 pixels x Cin, quad order (row p = 4 * quad + sub-pixel), split once
-  {
-    constexpr int V4 = KSUB * 4, A_IT = 32 * V4 / 256;    // float4 per pixel; items per thread
-    f32x4 xr[A_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int j = tid + 256 * it;
-      const int p = j / V4, v4 = j - p * V4;
-      const int iy = y0 + ((p >> 1) & 1), ix = x0 + 2 * (p >> 2) + (p & 1);
-      xr[it] = *reinterpret_cast<const f32x4*>(
-          k.x + (size_t)((b0 * k.H + iy) * k.W + ix) * k.x_ld + v4 * 4);
-    }
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int j = tid + 256 * it;
-      const int p = j / V4, v4 = j - p * V4;
-      f32x4 v = xr[it];
-      if (PRO != P2L_PRO_NONE) {
-        const int so = b0 * k.pro_bstride + v4 * 4;
-        v = v * *reinterpret_cast<const f32x4*>(k.pro_s + so) +
-            *reinterpret_cast<const f32x4*>(k.pro_t + so);
-        if (PRO == P2L_PRO_AFFINE_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-      }
-      pw_store_split(As + (v4 >> 2) * 768, p, v4 & 3, v);
-    }
-  }
-  __syncthreads();
-  bf16x8 a[KSUB][3];
-#pragma unroll
-  for (int sub = 0; sub < KSUB; ++sub) {
-    const float* ar = As + (sub * 32 + l31) * 24 + bf3_chunk(lhi, l31) * 4;
-    a[sub][0] = *reinterpret_cast<const bf16x8*>(ar);
-    a[sub][1] = *reinterpret_cast<const bf16x8*>(ar + 8);
-    a[sub][2] = *reinterpret_cast<const bf16x8*>(ar + 16);
-  }
-
-  // ---- B fragments from the packed image [sub][Cout/32][32 rows][96 B], ring of 4 sub-chunks
-  const int ntiles = k.Cout >> 5;
-  const float* wl = k.w + l31 * 24 + bf3_chunk(lhi, l31) * 4;
-  bf16x8 bq[4][3];
-  auto ldb = [&](int nt, int sub, bf16x8 (&b)[3]) {
-    const float* bp = wl + (size_t)(sub * ntiles + nt) * 768;
-    b[0] = *reinterpret_cast<const bf16x8*>(bp);
-    b[1] = *reinterpret_cast<const bf16x8*>(bp + 8);
-    b[2] = *reinterpret_cast<const bf16x8*>(bp + 16);
-  };
-  float* tb = dump + wave * 32 * PWS_EP;
-  const int q = lane >> 3, c4 = lane & 7;                  // epilogue item: quad q, channels 4*c4..
-  const int ox0 = x0 + 2 * q;
-
-  int nt = wave;
-  if (nt < ntiles) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ldb(nt, s, bq[s]);
-  }
-  for (; nt < ntiles; nt += 4) {
-    const bool more = nt + 4 < ntiles;
-    const int n0 = nt * 32;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int sub = 0; sub < KSUB; ++sub) {
-      const bf16x8 (&b)[3] = bq[sub & 3];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][2], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][1], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][1], b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sub][0], b[0], acc, 0, 0, 0);
-      if (sub + 4 < KSUB) ldb(nt, sub + 4, bq[sub & 3]);
-      else if (more) ldb(nt + 4, sub + 4 - KSUB, bq[sub & 3]);
-    }
-    // wave-private transpose: C layout (lane = channel) -> lane = 2x2 quad x 4 channels
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * PWS_EP + l31] = acc[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    EpiSums S;
-    const int n = n0 + c4 * 4;
-    if (n < k.n_store) {
-      f32x4 v[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * PWS_EP + c4 * 4) * k.alpha;
-      epi_item<0>(k, v, b0, y0, ox0, n, 0, 0, 0, S);
-    }
-    __builtin_amdgcn_wave_barrier();          // (the next tile's dump follows the reads above)
-  }
-}
-
 }  // namespace
 
 int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
@@ -329,22 +202,5 @@ int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
   else P2L_PW_K(P2L_PRO_AFFINE);
 #undef P2L_PW_K
 #undef P2L_PW
-  return p2l_check_launch();
-}
-
-// streaming form: one block per 32 pixels (2 rows x 16)
-int p2l_pws_launch(const ConvK& k, int pro, hipStream_t st) {
-  dim3 grid(k.B * (k.H >> 1) * (k.W >> 4)), block(256);
-  const int ksub = k.Cin / 16;
-  const size_t lds = (size_t)(ksub * 768 + 4 * 32 * PWS_EP) * sizeof(float);
-#define P2L_PWS(PRO, KSUB) hipLaunchKernelGGL((pws_bf3_kernel<PRO, KSUB>), grid, block, lds, st, k)
-#define P2L_PWS_K(PRO) do { if (ksub == 4) P2L_PWS(PRO, 4); else P2L_PWS(PRO, 8); } while (0)
-  if (k.arb_x) return P2L_EUNSUP;
-  if (ksub != 4 && ksub != 8) return P2L_EUNSUP;
-  if (pro == P2L_PRO_NONE) P2L_PWS_K(P2L_PRO_NONE);
-  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWS_K(P2L_PRO_AFFINE_RELU);
-  else P2L_PWS_K(P2L_PRO_AFFINE);
-#undef P2L_PWS_K
-#undef P2L_PWS
   return p2l_check_launch();
 }

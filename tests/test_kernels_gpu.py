@@ -67,8 +67,7 @@ CONV_CASES = [
     dict(B=3, H=32, Cin=128, Cout=64, taps=1, res='ups', bias=True, pro='affine_relu'),
     dict(B=2, H=64, Cin=128, Cout=64, taps=1, act='relu', pool='max'),
     dict(B=2, H=32, Cin=64, Cout=128, taps=1, pool='sum', want_y=False, pro='affine'),
-    # channel-expanding 1x1 shapes (64 / 128 inputs): the streaming bf16x3 kernel, one to eight
-    # channel groups per pixel tile
+    # channel-expanding 1x1 shapes (64 / 128 inputs: one to four 32-channel stages)
     dict(B=2, H=32, Cin=128, Cout=256, taps=1, pro='affine_relu', bias=True, res='same', alpha=0.5),
     dict(B=3, H=32, Cin=64, Cout=256, taps=1, res='ups', bias=True, pro='affine_relu'),
     dict(B=1, H=64, Cin=128, Cout=512, taps=1, act='relu', pool='max', pro='affine'),
@@ -302,11 +301,11 @@ def test_conv_dgrad_fused_affine_relu_bwd(dev, O, taps, ups, skip, wfmt, splitk)
 
 
 @pytest.mark.parametrize('C,Co', [(128, 64), (256, 128), (512, 64), (64, 256)],
-                         ids=['64to128-stream', '128to256-stream', '64to512-stream-grouped', '256to64-staged'])
+                         ids=['64to128', '128to256', '64to512', '256to64'])
 @pytest.mark.parametrize('skip', [None, 'same', 'ups'])
 def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip, C, Co):
-    """the 1x1 input-gradient conv in the bf16x3 arithmetic (csrc/p2l_pw.hip, both kernels) with
-    the fused backward of relu(x*s+t) and the GenBlock shortcut gradient"""
+    """the 1x1 input-gradient conv in the bf16x3 arithmetic (csrc/p2l_pw.hip) with the fused
+    backward of relu(x*s+t) and the GenBlock shortcut gradient, 1 to 8 stages of 32 channels"""
     g = torch.Generator().manual_seed(14)
     B, H = 2, 32
     x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
