@@ -377,8 +377,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': ('f32 (3x3 convs: fp32-equivalent 3-way bf16 operand split on the bf16 MFMA '
-                      'pipe, 6 products, fp32 accumulate; everything else exact fp32)'
+            'dtype': ('f32 (convolutions >= 32x32 and the self-attention: fp32-equivalent 3-way bf16 '
+                      'operand split on the bf16 MFMA pipe, 6 products, fp32 accumulate; small '
+                      'layers, dense layers, reductions and elementwise work exact fp32)'
                       if bf3 else 'f32'),
             'data': 'synthetic',
             'config': {
