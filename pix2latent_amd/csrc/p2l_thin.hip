@@ -36,8 +36,8 @@ __device__ __forceinline__ void thin_store_split(float* As, int row, int q4, con
 // ------------------------------------------------------------------------------------------
 // thin input: block = 8x16 pixels (wave w: image rows 2w, 2w+1 = 8 quads), all output channels
 // ------------------------------------------------------------------------------------------
-template <int PRO>
-__global__ __launch_bounds__(256, 2) void conv_thinin_kernel(const ConvK k) {
+template <int PRO, bool ARB>
+__global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const ConvK k) {
   __shared__ __attribute__((aligned(16))) float patch[TH_PATCH * 4];      // [pixel][3 + pad]
   __shared__ __attribute__((aligned(16))) float dump[4 * 32 * 36];
   __shared__ float red[2 * 4 * 32];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_thinin_kernel(const ConvK k) {
   const int ntiles = k.Cout >> 5;
   float* tb = dump + wave * 32 * 36;
   const int q = lane >> 3, c4 = lane & 7;                  // epilogue item: quad q, channels 4*c4..
-  const bool arb = k.arb_x != nullptr;
+  constexpr bool arb = ARB;
   const size_t arb_slot = (size_t)b * k.arb_nblk + tile_in_image;
   f32x4 bw[2][3];
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_thinin_kernel(const ConvK k) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * 36 + c4 * 4) * k.alpha;
-      epi_item(k, v, b, y0 + 2 * wave, x0 + 2 * q, n, 0, 0, 0, S);
+      epi_item<ARB ? 1 : 0>(k, v, b, y0 + 2 * wave, x0 + 2 * q, n, 0, 0, 0, S);
     }
     __builtin_amdgcn_wave_barrier();
     if (arb) {                                            // (block-uniform)
@@ -377,9 +377,15 @@ int p2l_thin_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int f
 
 int p2l_thinin_launch(const ConvK& k, int pro, hipStream_t st) {
   dim3 grid(k.n_mtiles), block(256);
-  if (pro == P2L_PRO_NONE) hipLaunchKernelGGL(conv_thinin_kernel<P2L_PRO_NONE>, grid, block, 0, st, k);
-  else if (pro == P2L_PRO_AFFINE_RELU) hipLaunchKernelGGL(conv_thinin_kernel<P2L_PRO_AFFINE_RELU>, grid, block, 0, st, k);
-  else hipLaunchKernelGGL(conv_thinin_kernel<P2L_PRO_AFFINE>, grid, block, 0, st, k);
+#define P2L_TI(PRO)                                                                          \
+  do {                                                                                       \
+    if (k.arb_x) hipLaunchKernelGGL((conv_thinin_kernel<PRO, true>), grid, block, 0, st, k); \
+    else hipLaunchKernelGGL((conv_thinin_kernel<PRO, false>), grid, block, 0, st, k);        \
+  } while (0)
+  if (pro == P2L_PRO_NONE) P2L_TI(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_TI(P2L_PRO_AFFINE_RELU);
+  else P2L_TI(P2L_PRO_AFFINE);
+#undef P2L_TI
   return p2l_check_launch();
 }
 
