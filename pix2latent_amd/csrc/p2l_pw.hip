@@ -17,7 +17,9 @@
 // VGPR: four blocks per CU) beat the first 64-channel form (72 KB, two blocks) by 1.14-1.40x
 // and now also win on the 64 / 128-input-channel layers (a streaming kernel written for those
 // -- 32-pixel blocks, A fragments in registers, waves sweeping different output tiles -- was
-// 1.05-1.13x the fp32 kernel and is gone: this one is 1.2-1.4x).
+// 1.05-1.13x the fp32 kernel and is gone: this one is 1.2-1.4x).  Double-buffered stages (one
+// barrier per stage instead of two) were measured too: 32-channel stages x 2 buffers = two
+// blocks per CU again, 0.83x; 16-channel stages x 2 buffers (four blocks), 0.96x.
 //
 //   * block = the 128-pixel quad-ordered tile of the direct kernel (same epilogue: residual,
 //     nearest-x2 shortcut, pooling, fused activation backward) x 64 output channels;
