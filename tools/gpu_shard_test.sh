@@ -6,7 +6,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.
 tail -3 gpurun_out/shard2.err
 python - <<'PY'
 import json
-r=[json.loads(open('gpurun_out/shard%d.json'%n).read().strip().splitlines()[-1]) for n in (1,2,4)]
+r=[json.loads([l for l in open('gpurun_out/shard%d.json'%n).read().splitlines() if l.startswith('{"metric"')][-1]) for n in (1,2,4)]
 import numpy as np
 l=[np.array(x['config']['last_losses']) for x in r]
 print('evals/s', [x['value'] for x in r])
