@@ -305,6 +305,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The timed steps carry per-launch HIP-event pairs (roofline.achieved is measured live), which
+    # a captured graph cannot contain: the main loop runs eagerly at every N.  (With <= 6 local
+    # candidates the optimizers replay the step as a HIP graph by default; measured, the replay
+    # and the eager queue take the same time when the GPU is the bottleneck -- DESIGN section 7,
+    # profiles/round2_step_vs_batch.txt -- and config.extra carries a replayed configuration.)
+    opt.use_graph = False
     for i in range(args.warmup):
         opt.step(variables, optimize=True, transform=(i == 0))
     sync()
@@ -396,6 +402,7 @@ def main():
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                 'backend': (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
                 'loss_gather': 'one all-gather per generation (lazy); per step only when log=True',
+                'hip_graph_replay': False,
                 'gflop_per_eval_basis': gflop_eval,
                 'end_to_end_tflops': round(gflop_eval * evals / elapsed / 1e3, 2),
                 'fwd_only_rescore_evals_per_s': round(rescore_rate, 1),

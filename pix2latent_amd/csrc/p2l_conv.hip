@@ -1105,7 +1105,13 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   hipStream_t st = (hipStream_t)stream;
 
   int prof_slot = -1;
-  if (g_prof.on && g_prof.n < (int)g_prof.flops.size() &&
+  bool prof_ok = g_prof.on;
+  if (prof_ok) {
+    // an event pair recorded during stream capture becomes graph nodes and can never be read
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) prof_ok = false;
+  }
+  if (prof_ok && g_prof.n < (int)g_prof.flops.size() &&
       (g_prof.seq++ % g_prof.period) == g_prof.phase) {
     prof_slot = g_prof.n++;
     g_prof.flops[prof_slot] = d->algo_flops > 0.0

@@ -286,3 +286,28 @@ def test_random_hook_under_graph_replay_draws_fresh_noise(dev):
     assert not torch.equal(deltas[0], deltas[1]) and not torch.equal(deltas[1], deltas[2])
     assert all(abs(d.std().item() - 0.05) < 0.02 for d in deltas)
     assert seen[-1].abs().max() <= 2.0 + 1e-6
+
+
+def test_launch_profiler_survives_graph_capture(dev):
+    """bench.py's per-launch profiler next to the automatic HIP-graph execution of small local
+    batches (what one rank of a 4- or 8-GPU job runs): event pairs must not be recorded into a
+    capture -- they could never be read back and p2l_prof_end3 failed for every rank -- and the
+    eager steps before the capture are still timed"""
+    import ctypes as C
+    from pix2latent_amd import _native as N
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import GradientOptimizer
+    model, loss_fn, vm = _graph_problem(dev, hook.Clamp(2.0), 3)
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, use_graph=True)
+    variables = vm.initialize(num_samples=3)
+    lib = N.lib()
+    N.check(lib.p2l_prof_begin(4096), 'prof_begin')
+    for i in range(5):
+        lib.p2l_prof_step(i, 1)
+        opt.step(variables, optimize=True, transform=(i == 0))
+    torch.cuda.synchronize()
+    f, m, c, b, x = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
+                     (C.c_double * 2)())
+    N.check(lib.p2l_prof_end3(f, m, c, b, x), 'p2l_prof_end3')
+    assert any(isinstance(v, tuple) for v in opt._graphs.values()), 'no graph was captured'
+    assert c[0] > 0 and m[0] > 0.0           # the eager steps were timed
