@@ -453,6 +453,9 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
       const bf16x8 a1 = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
       const bf16x8 a2 = __builtin_shufflevector(md[0], md[1], 0, 1, 2, 3, 4, 5, 6, 7);
       const bf16x8 a3 = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      // patch values of transform part s: in flight behind this step's MFMAs (the patch is
+      // visible from the barrier of step 0 on; reading it in the last chunk is harmless)
+      if (s > 0) t_load(s);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi][j][0]);
@@ -469,8 +472,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
       }
       // the patch of chunk c+1 was rewritten right after the previous barrier: every wave is
       // long past that by now, and this step's MFMAs keep the pipe busy while the barrier fills
-      if (s == 0) __syncthreads();
-      if (more) { t_load(s); t_emit(s, Vn); }
+      if (s == 0) { __syncthreads(); t_load(0); }
+      if (more) t_emit(s, Vn);
     }
   };
 
