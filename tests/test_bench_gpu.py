@@ -1,0 +1,55 @@
+"""bench.py as the driver runs it: the single-GPU line, and the sharded launch with several
+ranks SHARING this box's one GPU over gloo (the RCCL launch needs one GPU per rank:
+tests/test_parallel_nccl_gpu.py).  Ranks of a 4- or 8-GPU job hold <= 6 candidates, which
+switches the optimizers to HIP-graph replay by default -- the regime in which the per-launch
+profiler of the bench once failed for every rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QUICK = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-fp32-leg', '--no-extra']
+
+
+def _bench_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_bench_single_gpu_line():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + QUICK, cwd=ROOT,
+                       capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stderr[-4000:]
+    rec = _bench_line(r.stdout)
+    assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['value'] > 0
+    assert rec['unit'] == 'evals/s' and rec['higher_is_better'] is True
+    roof = rec['roofline']
+    assert roof['bound'] == 'mfma' and 0 < roof['frac'] < 1 and roof['launches'] > 0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert len(rec['config']['last_losses']) == 18
+
+
+@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.timeout(900)
+def test_bench_sharded_ranks_share_one_gpu(world):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(29630 + world),
+           os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--backend', 'gloo'] + QUICK
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-4000:]
+    rec = _bench_line(r.stdout)
+    assert rec['n_gpus'] == world and rec['value'] > 0 and rec['scaling'] == 'strong'
+    assert rec['config']['population'] == 18 and len(rec['config']['last_losses']) == 18
+    assert rec['roofline']['launches'] > 0          # the eager timed loop was profiled
