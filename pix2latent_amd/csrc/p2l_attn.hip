@@ -311,23 +311,37 @@ struct AttnX {
 };
 
 // x [B][N][C] -> [b][tile][chunk][piece][lane]: lane (row l31, half lhi) = x[row][16 chunk + 8 lhi + e]
-__global__ __launch_bounds__(256) void attn_rows_prep_kernel(const float* __restrict__ x,
-                                                             f32x4* __restrict__ img, int N, int C,
-                                                             int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;        // (b, tile, chunk, lane)
-  if (idx >= total) return;
+// (up to four matrices per launch: the backward pass needs phi, theta, g and d(o))
+struct RowsPrep {
+  const float* x[4];
+  f32x4* img[4];
+  int C[4];                // channels
+  int end[4];              // exclusive prefix of the item counts (b, tile, chunk, lane)
+};
+
+__global__ __launch_bounds__(256) void attn_rows_prep_kernel(const RowsPrep p) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (idx >= p.end[m]) ++m;
+  if (idx >= p.end[m]) return;
+  if (m > 0) idx -= p.end[m - 1];
+  const float* x = m == 0 ? p.x[0] : (m == 1 ? p.x[1] : (m == 2 ? p.x[2] : p.x[3]));
+  f32x4* img = m == 0 ? p.img[0] : (m == 1 ? p.img[1] : (m == 2 ? p.img[2] : p.img[3]));
+  const int C = m == 0 ? p.C[0] : (m == 1 ? p.C[1] : (m == 2 ? p.C[2] : p.C[3]));
   const int lane = idx & 63;
   int q = idx >> 6;
   const int nch = C >> 4;
   const int chunk = q % nch; q /= nch;                   // q = b * NT + tile
   const int l31 = lane & 31, lhi = lane >> 5;
   const float* src = x + ((size_t)q * 32 + l31) * C + chunk * 16 + lhi * 8;
-  bf16x4 h[2], m[2], l[2];
-  split3(*reinterpret_cast<const f32x4*>(src), h[0], m[0], l[0]);
-  split3(*reinterpret_cast<const f32x4*>(src + 4), h[1], m[1], l[1]);
+  bf16x4 h[2], mm[2], l[2];
+  split3(*reinterpret_cast<const f32x4*>(src), h[0], mm[0], l[0]);
+  split3(*reinterpret_cast<const f32x4*>(src + 4), h[1], mm[1], l[1]);
   f32x4* dst = img + ((size_t)q * nch + chunk) * 192 + lane;
   dst[0] = __builtin_bit_cast(f32x4, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
-  dst[64] = __builtin_bit_cast(f32x4, __builtin_shufflevector(m[0], m[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  dst[64] = __builtin_bit_cast(f32x4, __builtin_shufflevector(mm[0], mm[1], 0, 1, 2, 3, 4, 5, 6, 7));
   dst[128] = __builtin_bit_cast(f32x4, __builtin_shufflevector(l[0], l[1], 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(256) void attn_wprep_kernel(const float* __restrict
 }
 
 template <bool TMAJ>
-__global__ __launch_bounds__(256, 3) void attn_apply_kernel(const AttnP a) {
+__global__ __launch_bounds__(256, 4) void attn_apply_kernel(const AttnP a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -737,16 +751,21 @@ extern "C" int p2l_attn_bwd_qk(const P2LAttn* d, const float* q, const float* k,
   float* dsum = (float*)p; p += align256((size_t)d->B * d->Nq * sizeof(float));
   f32x4* wimg = (f32x4*)p; p += align256((size_t)d->B * ((d->Nq > d->Nk ? d->Nq : d->Nk) >> 5) * AP_TILE_U * 16);
   float* part = (float*)p;
-  auto rows_prep = [&](const float* x, f32x4* img, int N, int C) {
-    const int total = d->B * (N >> 5) * (C >> 4) * 64;
-    hipLaunchKernelGGL(attn_rows_prep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, img, N, C, total);
-    return p2l_check_launch();
-  };
   int rc;
-  if ((rc = rows_prep(k, kimg, d->Nk, AT_D))) return rc;
-  if ((rc = rows_prep(q, qimg, d->Nq, AT_D))) return rc;
-  if ((rc = rows_prep(v, vimg, d->Nk, AT_DV))) return rc;
-  if ((rc = rows_prep(dout, doimg, d->Nq, AT_DV))) return rc;
+  {
+    RowsPrep rp{};
+    const float* xs[4] = {k, q, v, dout};
+    f32x4* imgs[4] = {kimg, qimg, vimg, doimg};
+    const int Ns[4] = {d->Nk, d->Nq, d->Nk, d->Nq}, Cs[4] = {AT_D, AT_D, AT_DV, AT_DV};
+    int end = 0;
+    for (int i = 0; i < 4; ++i) {
+      rp.x[i] = xs[i]; rp.img[i] = imgs[i]; rp.C[i] = Cs[i];
+      end += d->B * (Ns[i] >> 5) * (Cs[i] >> 4) * 64;
+      rp.end[i] = end;
+    }
+    hipLaunchKernelGGL(attn_rows_prep_kernel, dim3(cdiv(end, 256)), dim3(256), 0, st, rp);
+    if ((rc = p2l_check_launch())) return rc;
+  }
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3(cdiv((size_t)d->B * d->Nq, 4)), dim3(256), 0, st, dout,
                      out, dsum, d->B * d->Nq);
   if ((rc = p2l_check_launch())) return rc;
