@@ -253,7 +253,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--prof-period', type=int, default=4,
+    ap.add_argument('--prof-period', type=int, default=10,
                     help='time every N-th conv launch with hipEvents inside the timed steps '
                          '(1 = every launch; costs ~5 %% of the step)')
     ap.add_argument('--no-fp32-leg', action='store_true',
