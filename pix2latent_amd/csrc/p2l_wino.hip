@@ -35,6 +35,7 @@
 #include "p2l_conv_k.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace p2lconv;
 
@@ -211,13 +212,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][0]);
         const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][1]);
         const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[fi & 1][j][2]);
-        f32x16 t = acc[fi][j];                         // smallest terms first
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        f32x16 t = acc[fi][j];                         // (the order of wino16s_conv_kernel: bit-identical results)
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
         acc[fi][j] = t;
       }
     }
@@ -293,6 +294,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
 //     Two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
 // Same additions and products in the same order as the 8x16 kernel: bit-identical results,
 // so which of the two runs is a pure performance choice (p2l_wino_launch).
+// a wave-uniform pointer pinned to scalar registers: hipcc then addresses `p + lane offset` as
+// global_load v_off, s[base] instead of carrying a 64-bit address per lane and load
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
 constexpr int W16_THREADS = 512;
 constexpr int W16_RAW_ROWS = 18 * 18;
 constexpr int W16_RAW_FLOATS = W16_RAW_ROWS * WN_RAW_PITCH;            // 31,104 B
@@ -461,13 +471,13 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi][j][0]);
         const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[fi][j][1]);
         const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[fi][j][2]);
-        f32x16 t = acc[fi][m][j];                       // smallest terms first
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        f32x16 t = acc[fi][m][j];
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
         acc[fi][m][j] = t;
       }
       // the patch of chunk c+1 was rewritten right after the previous barrier: every wave is
@@ -578,6 +588,375 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
   }
 }
 
+// ---- 16x16-pixel blocks, hand-scheduled multiply phase ------------------------------------
+// wino16_conv_kernel above leaves the instruction order of a multiply step to hipcc, which emits
+// [read fragment | 36 VALU of the 3-way split | 12 MFMAs back to back].  The two waves of a SIMD
+// leave every barrier in phase, so they split at the same time (sharing the VALU issue) and then
+// queue their MFMAs at the same time: matrix pipe and VALU never overlap (PMC: MFMA pipe 34 %
+// busy, 43 % of wave cycles waiting to issue).  This form fixes the order by hand
+// (sched_barrier between every MFMA and the <= 5 other instructions that follow it):
+//   * the products of a fragment are taken LARGEST PIECE FIRST: h b1, h b2, h b3, m b1, m b2,
+//     l b1 -- the h pieces are four v_cvt_pk away from the fp32 values, so the first MFMA of a
+//     step issues almost at once and the m / l pieces are computed in the gaps behind the MFMAs
+//     that do not need them yet (one pair of values = 4 VALU per gap);
+//   * the h pieces of the NEXT fragment, the input transform of the next chunk, the patch
+//     write and every load sit in the remaining gaps of the step; nothing but the fragment
+//     read + 4 conversions at the top of a chunk is outside an MFMA shadow.
+// Barriers, LDS layout, weight stream and epilogue are those of wino16_conv_kernel.
+template <int PRO>
+__global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* raw = smem;
+  float* Vs = smem + W16_RAW_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
+  const int tiles_per_image = k.tiles_x * k.tiles_y;                  // 16x16-pixel tiles
+  const int b = __builtin_amdgcn_readfirstlane(mt / tiles_per_image);   // (scalar address bases)
+  const int tile_in_image = mt - b * tiles_per_image;
+  const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
+  const int y0 = by * 16, x0 = bx * 16, n0 = __builtin_amdgcn_readfirstlane(nt * 64);
+
+  // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
+  constexpr int A_ITERS = 3;
+  const int sv = tid & 3;
+  // item `it` of a thread is pixel (tid >> 2) + 128 * it: LDS offsets differ by a constant
+  unsigned a_goff[A_ITERS];                              // (scalar base + 32-bit lane offset)
+  const int a_loff0 = (tid >> 2) * WN_RAW_PITCH + sv * 4;
+  const bool a_third = tid < 4 * (W16_RAW_ROWS - 256);          // items 0, 1 always exist
+  unsigned a_valid = 0;
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int p = (tid + W16_THREADS * it) >> 2;
+    a_goff[it] = 0x80000000u;
+    if (p < W16_RAW_ROWS) {
+      const int hy = p / 18, hx = p - hy * 18;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
+        a_goff[it] = ((iy * k.W + ix) * k.x_ld + sv * 4) * 4;     // bytes inside image b (< 2^32)
+        a_valid |= 1u << it;
+      }
+    }
+  }
+  const char* ps_img = reinterpret_cast<const char*>(k.pro_s + (size_t)b * k.pro_bstride);
+  const char* pt_img = reinterpret_cast<const char*>(k.pro_t + (size_t)b * k.pro_bstride);
+  const unsigned s_off = sv * 16;
+  f32x4 xr[A_ITERS], sr, tr;
+  // image b as a buffer resource: 32-bit lane offsets + the chunk as the scalar offset; lanes
+  // of the zero padding carry an offset past the end and read 0.f
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(k.x + (size_t)b * k.H * k.W * k.x_ld))), 0,
+      __builtin_amdgcn_readfirstlane(k.H * k.W * k.x_ld * 4), 0x00020000);
+  auto load_raw = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_goff[it], c * 64, 0));
+    if (PRO != P2L_PRO_NONE) {
+      sr = *reinterpret_cast<const f32x4*>(ps_img + c * 64 + s_off);
+      tr = *reinterpret_cast<const f32x4*>(pt_img + c * 64 + s_off);
+    }
+  };
+  auto write_raw1 = [&](int it) {
+    if (it == 2 && !a_third) return;
+    f32x4 v = xr[it];
+    if (PRO != P2L_PRO_NONE) {
+      v = v * sr + tr;
+      if (PRO == P2L_PRO_AFFINE_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    if (PRO != P2L_PRO_NONE && !((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // padding is 0 AFTER the prologue
+    *reinterpret_cast<f32x4*>(raw + a_loff0 + it * 128 * WN_RAW_PITCH) = v;
+  };
+
+  // ---- input transform item: (half h, tile tt of 64, channel quad tv) --------------------
+  const int th = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int tt = (tid >> 2) & 63, tv = tid & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
+  const int t_dst = tt * 16 + ((tv ^ ((tt >> 2) & 3)) << 2);
+  // A part = one frequency row x two patch columns (c0, c0 + 2): t_load(part, h) requests the two
+  // patch rows of column c0 + 2h, t_rows(part, h) combines them into Ra (h = 0) / Rb (h = 1)
+  f32x4 tq[2], tRa, tRb;
+  f32x4 tR2;                                            // R[2] of the current frequency row
+  auto t_load = [&](int part, int h) {
+    const int fr = 2 * th + (part >> 1);
+    const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
+    const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
+    const int c0 = (part & 1) + 2 * h;
+    tq[0] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0) * WN_RAW_PITCH);
+    tq[1] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0) * WN_RAW_PITCH);
+  };
+  auto t_rows = [&](int part, int h) {
+    const int fr = 2 * th + (part >> 1);
+    const f32x4 r = (fr == 1) ? tq[0] + tq[1] : sub4(tq[0], tq[1]);
+    if (h == 0) tRa = r; else tRb = r;
+  };
+  // second half: column combinations and the stores
+  auto t_cols = [&](int part, float* Vn) {
+    const int fr = 2 * th + (part >> 1);
+    float* d = Vn + fr * 4 * 1024 + t_dst;
+    const f32x4 Ra = tRa, Rb = tRb;
+    if ((part & 1) == 0) {                              // R[0], R[2]
+      *reinterpret_cast<f32x4*>(d) = sub4(Ra, Rb);
+      tR2 = Rb;
+    } else {                                            // R[1], R[3]
+      *reinterpret_cast<f32x4*>(d + 1024) = Ra + tR2;
+      *reinterpret_cast<f32x4*>(d + 2048) = sub4(tR2, Ra);
+      *reinterpret_cast<f32x4*>(d + 3072) = sub4(Ra, Rb);
+    }
+  };
+
+  // ---- weight fragments: global -> registers, one frequency ahead -------------------------
+  const int n_t32 = k.Cout >> 5;
+  // (buffer resource over the whole image: lane offset in a register, everything else scalar)
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(k.w))), 0,
+      __builtin_amdgcn_readfirstlane(k.Cout * k.nchunks * (16 * 96)), 0x00020000);
+  const int w_lane = lane * 16;
+  f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
+  auto load_b = [&](int c, int fi, int set) {
+    const int base = ((c * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (3 * 64 * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        bw[set][j][p] = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane + p * 1024, base + j * 3072, 0));
+  };
+
+  f32x16 acc[2][2][2];                                 // [freq][M-tile][N-tile]
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[fi][m][j][r] = 0.f;
+
+  // ---- fragment pipeline registers ---------------------------------------------------------
+  const int a_sw = (l31 >> 2) & 3;
+  const int a_off0 = l31 * 16 + (((lhi * 2) ^ a_sw) << 2), a_off1 = l31 * 16 + (((lhi * 2 + 1) ^ a_sw) << 2);
+  // (one set: the values of fragment s+1 are requested once the residuals of fragment s are
+  //  dead, its h pieces are formed once the last h product of fragment s has issued)
+  f32x2 rr[4];                                         // fp32 values -> running residuals, [pair]
+  bf16x2 hh[4];                                        // h pieces
+  bf16x2 mm[4], ll[4];                                 // m, l pieces of the current fragment
+  auto lda = [&](const float* Vc, int s) {
+    const float* rowp = Vc + ((2 * wave + (s >> 1)) * 64 + (s & 1) * 32) * 16;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(rowp + a_off0);
+    const f32x4 q1 = *reinterpret_cast<const f32x4*>(rowp + a_off1);
+    rr[0] = f32x2{q0.x, q0.y}; rr[1] = f32x2{q0.z, q0.w};
+    rr[2] = f32x2{q1.x, q1.y}; rr[3] = f32x2{q1.z, q1.w};
+  };
+  auto hstage = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hh[p] = __builtin_convertvector(rr[p], bf16x2);
+  };
+  auto cat8 = [](const bf16x2 (&q)[4]) {
+    const bf16x4 lo = __builtin_shufflevector(q[0], q[1], 0, 1, 2, 3);
+    const bf16x4 hi = __builtin_shufflevector(q[2], q[3], 0, 1, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+#define P2L_SB() __builtin_amdgcn_sched_barrier(0)
+// (hipcc sinks a conversion to its first use, four gaps later, in a clump: pin it to its gap)
+#define P2L_PIN(X) asm volatile("" : "+v"(X))
+#define P2L_MF(A, FI, J, P, M)                                                                \
+  acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
+      A, __builtin_bit_cast(bf16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                   \
+  P2L_SB()
+
+  const int nchunks = k.nchunks;
+  // The input transform of the NEXT chunk rides along as 20 micro-operations -- per part:
+  // request column pair 0 | combine its rows | request column pair 1 | combine | columns + stores --
+  // one in every second MFMA gap from the barrier of step 0 (gap 8) to gap 10 of step 3.
+  auto tx = [&](int j, float* Vn) {
+    const int part = j / 5, op = j - 5 * part;
+    if (op == 0) t_load(part, 0);
+    else if (op == 1) t_rows(part, 0);
+    else if (op == 2) t_load(part, 1);
+    else if (op == 3) t_rows(part, 1);
+    else t_cols(part, Vn);
+  };
+#define P2L_TX(G)                                                                             \
+  if (more && (G) >= 8 && (((G) - 8) & 1) == 0 && ((G) - 8) / 2 < 20) tx(((G) - 8) / 2, Vn)
+  // one multiply step: fragment (fi, m) = (s >> 1, s & 1) of chunk c
+  // (MORE_: not the last chunk -- a compile-time flag: the last chunk is its own copy of the
+  //  four steps, so the steady-state loop carries no conditional branches)
+  auto step = [&](auto S_, auto MORE_, const float* Vc, float* Vn, int c) {
+    constexpr int s = decltype(S_)::value;
+    constexpr bool more = decltype(MORE_)::value;
+    constexpr int fi = s >> 1, m = s & 1;
+    const bf16x8 a1 = cat8(hh);
+    P2L_MF(a1, fi, 0, 0, m);
+    // gaps 0-3: m pieces pair by pair; (step 0) patch write
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rr[p] = pk_sub(rr[p], widen2(hh[p]));
+      mm[p] = __builtin_convertvector(rr[p], bf16x2);
+      P2L_PIN(mm[p]);
+      if (s == 0 && p >= 1 && more) write_raw1(p - 1);
+      P2L_TX(12 * s + p);
+      P2L_SB();
+      if (p == 0) { P2L_MF(a1, fi, 1, 0, m); }
+      if (p == 1) { P2L_MF(a1, fi, 0, 1, m); }
+      if (p == 2) { P2L_MF(a1, fi, 1, 1, m); }
+      if (p == 3) { P2L_MF(a1, fi, 0, 2, m); }
+    }
+    const bf16x8 a2 = cat8(mm);
+    // gaps 4-7: l pieces
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rr[p] = pk_sub(rr[p], widen2(mm[p]));
+      ll[p] = __builtin_convertvector(rr[p], bf16x2);
+      P2L_PIN(ll[p]);
+      P2L_TX(12 * s + 4 + p);
+      P2L_SB();
+      if (p == 0) { P2L_MF(a1, fi, 1, 2, m); }
+      if (p == 1) { P2L_MF(a2, fi, 0, 0, m); }
+      if (p == 2) { P2L_MF(a2, fi, 1, 0, m); }
+      if (p == 3) { P2L_MF(a2, fi, 0, 1, m); }
+    }
+    const bf16x8 a3 = cat8(ll);
+    // gap 8: the residuals are dead: next fragment's values requested
+    if (s == 0) {
+      // the patch of chunk c+1 (written in gaps 1-3 by every wave) becomes visible; the MFMAs
+      // issued so far keep the pipe busy while the barrier fills
+      __syncthreads();
+    }
+    if (s + 1 < 4) lda(Vc, s + 1);
+    P2L_TX(12 * s + 8);
+    P2L_SB();
+    P2L_MF(a2, fi, 1, 1, m);
+    // gap 9: weight fragments / next patch (address arithmetic + loads)
+    if (s == 0) load_b(c, 1, 1);
+    else if (s == 2 && more) load_b(c + 1, 0, 0);
+    else if (s == 1 && more) load_raw(c + 2 < nchunks ? c + 2 : c + 1);   // (last one: a harmless re-read)
+    P2L_SB();
+    P2L_MF(a3, fi, 0, 0, m);
+    // gap 10
+    P2L_TX(12 * s + 10);
+    P2L_SB();
+    P2L_MF(a3, fi, 1, 0, m);
+    // gap 11: h pieces of the next fragment
+    if (s + 1 < 4) hstage();
+    P2L_SB();
+  };
+
+  load_raw(0);
+  load_b(0, 0, 0);
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) write_raw1(it);
+  __syncthreads();
+  if (nchunks > 1) load_raw(1);
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    t_load(part, 0); t_rows(part, 0); t_load(part, 1); t_rows(part, 1); t_cols(part, Vs);
+  }
+  __syncthreads();
+  using T_ = std::true_type; using F_ = std::false_type;
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
+    float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
+    lda(Vc, 0);
+    hstage();
+    P2L_SB();
+    step(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
+    step(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
+    step(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
+    step(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
+    __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
+  }
+  {
+    const int c = nchunks - 1;
+    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
+    lda(Vc, 0);
+    hstage();
+    P2L_SB();
+    step(std::integral_constant<int, 0>{}, F_{}, Vc, Vc, c);
+    step(std::integral_constant<int, 1>{}, F_{}, Vc, Vc, c);
+    step(std::integral_constant<int, 2>{}, F_{}, Vc, Vc, c);
+    step(std::integral_constant<int, 3>{}, F_{}, Vc, Vc, c);
+    __syncthreads();
+  }
+#undef P2L_TX
+#undef P2L_PIN
+#undef P2L_MF
+#undef P2L_SB
+
+  // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..63][32 channels] ----------
+  float* dump = Vs;
+  const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
+  const int ety = e_t >> 3, etx = e_t & 7;
+  float* red = raw;                                      // [2 kinds][8 waves][32]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          dump[((2 * wave + fi) * 64 + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
+        }
+    __syncthreads();
+    const int nb = n0 + j * 32;
+    EpiSums S;
+    if (nb + e_c4 * 4 < k.n_store) {
+      f32x4 T[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {                  // A^T M, column jj
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        T[0][jj] = (m0 + m1) + m2;
+        T[1][jj] = (m1 - m2) - m3;
+      }
+      f32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                     // (A^T M) A
+        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
+        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
+      }
+      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
+    }
+    if (k.arb_x != nullptr) {
+      f32x4 sgx = S.sgx, sg = S.sg;
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
+        sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
+        sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
+        sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+      }
+      if (lane < 8) {
+        *reinterpret_cast<f32x4*>(red + wave * 32 + lane * 4) = sgx;
+        *reinterpret_cast<f32x4*>(red + 256 + wave * 32 + lane * 4) = sg;
+      }
+      __syncthreads();
+      if (tid < 64 && nb + (tid & 31) < k.n_store) {
+        const int g = tid >> 5, col = tid & 31;
+        const float* r0 = red + g * 128 + col;
+        const float s0 = (r0[0] + r0[32]) + (r0[64] + r0[96]);
+        const float s1 = (r0[256] + r0[288]) + (r0[320] + r0[352]);
+        const size_t slot = (size_t)b * k.arb_nblk + (size_t)(2 * by + g) * k.tiles_x + bx;
+        const size_t o = slot * k.Cout + nb + col;
+        k.arb_partial[o] = s0;
+        k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
 __global__ void wino_pack_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
                                  int transpose_flip) {
@@ -647,6 +1026,7 @@ static int wino16_mode() {
   return g_wino16_mode;
 }
 static void* g_wino_trace = nullptr;
+int g_wino16_sched = 1;          // lab switch: hand-scheduled multiply phase
 // diagnostics: device buffer of 8 waves x 64 chunks x 8 uint64 that ONE block of every following
 // 16x16-pixel launch fills with s_memtime stamps of its phase boundaries (nullptr = off)
 extern "C" int p2l_wino_set_trace(void* buf) {
@@ -654,6 +1034,9 @@ extern "C" int p2l_wino_set_trace(void* buf) {
   return P2L_OK;
 }
 extern "C" int p2l_set_wino_block(int mode) {
+  // (+4: the compiler-scheduled 16x16 kernel -- measurement only, tools/micro/conv_lab.cpp)
+  g_wino16_sched = (mode & 4) ? 0 : 1;
+  mode &= 3;
   if (mode < 0 || mode > 2) return P2L_EINVAL;
   g_wino16_mode = mode;
   return P2L_OK;
@@ -684,6 +1067,23 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL(wino16_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);          \
   } while (0)
+#define P2L_W16S(PRO)                                                                        \
+  do {                                                                                       \
+    static bool attr_set = false;                                                            \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
+  } while (0)
+    if (g_wino16_sched) {
+      if (pro == P2L_PRO_NONE) P2L_W16S(P2L_PRO_NONE);
+      else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16S(P2L_PRO_AFFINE_RELU);
+      else P2L_W16S(P2L_PRO_AFFINE);
+      return p2l_check_launch();
+    }
+#undef P2L_W16S
     if (pro == P2L_PRO_NONE) P2L_W16(P2L_PRO_NONE);
     else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16(P2L_PRO_AFFINE_RELU);
     else P2L_W16(P2L_PRO_AFFINE);

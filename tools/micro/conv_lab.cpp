@@ -1,0 +1,89 @@
+// Standalone timing / agreement harness for the 3x3 conv kernels of libp2l_hip.so through the
+// C ABI (include/p2l.h) -- no Python, no torch: a gpurun call spends its time on kernels.
+//   conv_lab [B]        runs every (layer, kernel form) pair below, prints ms, TFLOP/s and the
+//                       largest difference from the direct bf16x3 kernel of the same layer
+// build: hipcc --offload-arch=gfx950 -O2 -I include tools/micro/conv_lab.cpp -L pix2latent_amd
+//        -lp2l_hip -Wl,-rpath,'$ORIGIN/../../pix2latent_amd' -o tools/micro/conv_lab
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "p2l.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+#define PK(x) do { int r_ = (x); if (r_ != P2L_OK) { printf("p2l error %d at %s:%d\n", r_, __FILE__, __LINE__); exit(1); } } while (0)
+
+static unsigned long long rng = 88172645463325252ull;
+static float urand() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 11) * (1.0 / 9007199254740992.0)); }
+static float nrand() { float u = urand() + 1e-12f, v = urand(); return sqrtf(-2.f * logf(u)) * cosf(6.2831853f * v); }
+
+struct Form { const char* name; int wfmt; int wino_mode; int block; };
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 18;
+  const int pro = argc > 2 ? atoi(argv[2]) : P2L_PRO_NONE;
+  struct { int H, Cin, Cout; } layers[] = {{64, 256, 256}, {32, 512, 512}, {128, 128, 128}, {256, 64, 64},
+                                          {32, 256, 256}, {16, 512, 512}};
+  const Form forms[] = {{"direct", P2L_WFMT_BF16X3, 0, 0}, {"wino8", P2L_WFMT_BF16X3W, 2, 0},
+                        {"wino16-cc", P2L_WFMT_BF16X3W, 2, 2 | 4}, {"wino16-hand", P2L_WFMT_BF16X3W, 2, 2}};
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto L : layers) {
+    const int H = L.H, W = L.H, Cin = L.Cin, Cout = L.Cout;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * Cout, nw = (size_t)Cout * Cin * 9;
+    std::vector<float> hx(nx), hw(nw), hs((size_t)B * Cin), ht((size_t)B * Cin);
+    // ReLU-like input statistics (half the values zero) when there is no prologue
+    for (auto& v : hx) { v = nrand(); if (pro == P2L_PRO_NONE && v < 0.f) v = 0.f; }
+    const float ws = 1.f / sqrtf(9.f * Cin);
+    for (auto& v : hw) v = nrand() * ws;
+    for (auto& v : hs) v = 0.5f + urand();
+    for (auto& v : ht) v = 0.3f * nrand();
+    float *dx, *dwo, *dy, *dref, *dsv, *dtv;
+    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dwo, nw * 4)); CK(hipMalloc(&dy, ny * 4)); CK(hipMalloc(&dref, ny * 4));
+    CK(hipMalloc(&dsv, hs.size() * 4)); CK(hipMalloc(&dtv, ht.size() * 4));
+    CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dwo, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsv, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtv, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> ref(ny), out(ny);
+    for (const Form& f : forms) {
+      const size_t wf = p2l_packed_weight_floats(9, Cout, Cin, f.wfmt);
+      float* dwp; CK(hipMalloc(&dwp, wf * 4));
+      if (f.wfmt == P2L_WFMT_BF16X3W) PK(p2l_pack_conv_weight_bf3w(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
+      else PK(p2l_pack_conv_weight_bf3(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
+      PK(p2l_set_wino_mode(f.wino_mode));
+      PK(p2l_set_wino_block(f.block));
+      P2LConv d; memset(&d, 0, sizeof d);
+      d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = pro;
+      d.pro_bstride = Cin; d.alpha = 1.f; d.act = P2L_ACT_NONE; d.pool = P2L_POOL_NONE; d.y_ld = Cout;
+      d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt;
+      CK(hipMemsetAsync(dy, 0xff, ny * 4, st));
+      for (int i = 0; i < 3; ++i)
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      CK(hipStreamSynchronize(st));
+      const int reps = 20;
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i)
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      CK(hipMemcpy(out.data(), dy, ny * 4, hipMemcpyDeviceToHost));
+      double md = 0, mx = 0; size_t nbad = 0;
+      if (&f == &forms[0]) ref = out;
+      for (size_t i = 0; i < ny; ++i) {
+        if (!(out[i] == out[i])) { ++nbad; continue; }
+        md = fmax(md, fabs((double)out[i] - ref[i])); mx = fmax(mx, fabs((double)ref[i]));
+      }
+      const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
+      printf("%2dx%3d^2 %3d->%3d pro%d %-12s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", B, H, Cin, Cout, pro,
+             f.name, ms, fl / ms / 1e9, md / (mx + 1e-30), nbad);
+      fflush(stdout);
+      CK(hipFree(dwp));
+    }
+    CK(hipFree(dx)); CK(hipFree(dwo)); CK(hipFree(dy)); CK(hipFree(dref)); CK(hipFree(dsv)); CK(hipFree(dtv));
+  }
+  return 0;
+}
