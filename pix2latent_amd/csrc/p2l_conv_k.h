@@ -79,21 +79,31 @@ __device__ __forceinline__ void st4(float* p, unsigned off, f32x4 v) {
 // apart in LDS (ConvK::hp; a rotation over all 6 chunks was tried: 46 % conflicts).
 __device__ __forceinline__ int bf3_chunk(int c, int row) { return c ^ ((row >> 3) & 1); }
 
-// x = h + m + l with three round-to-nearest bf16 pieces.  Written on PAIRS so that every step is
-// one packed instruction per two values (4.5 VALU per value instead of the 7.5 hipcc emits for
-// the element-wise form): v_cvt_pk_bf16_f32, shift / mask back to fp32, packed subtraction.
+// x = h + m + l with three round-to-nearest bf16 pieces.  Written on PAIRS: v_cvt_pk_bf16_f32
+// (half rate), shift / mask back to fp32, two subtractions: 5.5 VALU per value.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 widen2(const bf16x2 p) {
   const unsigned u = __builtin_bit_cast(unsigned, p);
   return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
-// a - b on two values in one instruction (hipcc turns every vector subtraction, and fma(b, -1, a),
-// into scalar v_sub_f32; only additions get packed)
+// a - b on two values.  Two forms:
+//  * P2L_SCALAR_SPLIT (kernels that interleave the split with their own MFMAs, p2l_wino.hip): two
+//    v_sub_f32.  Measured on gfx950 (tools/micro/issue_rate.hip): a packed fp32 add next to
+//    v_mfma_f32_32x32x16_bf16 holds the matrix pipe for ~10 cycles (2 per MFMA: +50 % time) while
+//    up to 4 plain VALU instructions per MFMA and wave are free; such a TU is also built with
+//    -packed-fp32-ops so that hipcc does not pack additions itself.
+//  * otherwise one v_pk_add_f32 with neg modifiers (hipcc turns every vector subtraction, and
+//    fma(b, -1, a), into scalar v_sub_f32; only additions get packed): kernels whose split runs
+//    in its own phase are issue-bound there and measured 3-7 % slower with the scalar form.
 __device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
+#ifdef P2L_SCALAR_SPLIT
+  return f32x2{a.x - b.x, a.y - b.y};
+#else
   f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
   return r;
+#endif
 }
 __device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
   const f32x2 lo = pk_sub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = pk_sub(f32x2{a.z, a.w}, f32x2{b.z, b.w});

@@ -603,7 +603,34 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
 //     write and every load sit in the remaining gaps of the step; nothing but the fragment
 //     read + 4 conversions at the top of a chunk is outside an MFMA shadow.
 // Barriers, LDS layout, weight stream and epilogue are those of wino16_conv_kernel.
-template <int PRO>
+// Transform micro-operation of MFMA gap G = 12 * step + gap of a chunk: part * 8 + op, or -1.
+// Usable gaps: 0-8 and 10 of every step, from gap 8 of step 0 (the patch barrier) on.  Per part:
+// request | (wait) | rows + request | (wait) | rows | columns (1 output for even parts, 3 for odd).
+struct TxTable {
+  int slot[48];
+  constexpr TxTable() : slot{} {
+    constexpr int seq[28] = {0 * 8 + 0, -1, 0 * 8 + 1, -1, 0 * 8 + 2, 0 * 8 + 3,
+                             1 * 8 + 0, -1, 1 * 8 + 1, -1, 1 * 8 + 2, 1 * 8 + 3, 1 * 8 + 4, 1 * 8 + 5,
+                             2 * 8 + 0, -1, 2 * 8 + 1, -1, 2 * 8 + 2, 2 * 8 + 3,
+                             3 * 8 + 0, -1, 3 * 8 + 1, -1, 3 * 8 + 2, 3 * 8 + 3, 3 * 8 + 4, 3 * 8 + 5};
+    int n = 0;
+    for (int g = 0; g < 48; ++g) {
+      const int q = g % 12;
+      slot[g] = -1;
+      if (g < 8 || q == 9 || q == 11) continue;
+      if (n < 28) slot[g] = seq[n];
+      ++n;
+    }
+  }
+};
+constexpr TxTable kTx{};
+
+// ABL (lab builds only, -DP2L_LAB): timing ablations -- results are wrong when set.
+//   1 weights loaded once | 2 no input transform | 4 no barriers in the loop | 8 no m / l pieces
+//   16 no MFMAs | 32 fragment values read once | 64 no patch loads / writes
+// VAR (lab): 1 waves 4-7 at priority 1 | 2 priority handed from the older to the younger half in
+// the middle of a chunk | 4 scalar subtractions instead of v_pk_add_f32 neg
+template <int PRO, int ABL = 0, int VAR = 0>
 __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;
@@ -692,23 +719,29 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     tq[0] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0) * WN_RAW_PITCH);
     tq[1] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0) * WN_RAW_PITCH);
   };
+  // (a + sign * b as one fma per value: the sign is a wave-uniform float, no select)
+  const float t_sgn[2] = {(2 * th + 0 == 1) ? 1.f : -1.f, (2 * th + 1 == 1) ? 1.f : -1.f};
   auto t_rows = [&](int part, int h) {
-    const int fr = 2 * th + (part >> 1);
-    const f32x4 r = (fr == 1) ? tq[0] + tq[1] : sub4(tq[0], tq[1]);
+    const float sg = t_sgn[part >> 1];
+    const f32x4 r = {__builtin_fmaf(tq[1].x, sg, tq[0].x), __builtin_fmaf(tq[1].y, sg, tq[0].y),
+                     __builtin_fmaf(tq[1].z, sg, tq[0].z), __builtin_fmaf(tq[1].w, sg, tq[0].w)};
     if (h == 0) tRa = r; else tRb = r;
   };
-  // second half: column combinations and the stores
-  auto t_cols = [&](int part, float* Vn) {
+  // column combinations + stores: which = 0 the only output of an even part / R[1] of an odd one,
+  // 1, 2 = R[2], R[3] of an odd part
+  auto t_cols = [&](int part, int which, float* Vn) {
     const int fr = 2 * th + (part >> 1);
     float* d = Vn + fr * 4 * 1024 + t_dst;
     const f32x4 Ra = tRa, Rb = tRb;
-    if ((part & 1) == 0) {                              // R[0], R[2]
-      *reinterpret_cast<f32x4*>(d) = sub4(Ra, Rb);
+    if ((part & 1) == 0) {                              // R[0]; Rb is R[2]'s second operand
+      *reinterpret_cast<f32x4*>(d) = Ra - Rb;
       tR2 = Rb;
-    } else {                                            // R[1], R[3]
+    } else if (which == 0) {
       *reinterpret_cast<f32x4*>(d + 1024) = Ra + tR2;
-      *reinterpret_cast<f32x4*>(d + 2048) = sub4(tR2, Ra);
-      *reinterpret_cast<f32x4*>(d + 3072) = sub4(Ra, Rb);
+    } else if (which == 1) {
+      *reinterpret_cast<f32x4*>(d + 2048) = tR2 - Ra;
+    } else {
+      *reinterpret_cast<f32x4*>(d + 3072) = Ra - Rb;
     }
   };
 
@@ -755,9 +788,17 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     rr[0] = f32x2{q0.x, q0.y}; rr[1] = f32x2{q0.z, q0.w};
     rr[2] = f32x2{q1.x, q1.y}; rr[3] = f32x2{q1.z, q1.w};
   };
+  auto resid = [&](const f32x2 v, const bf16x2 piece) {
+    const f32x2 w = widen2(piece);
+    if (VAR & 4) return f32x2{v.x - w.x, v.y - w.y};
+    return pk_sub(v, w);
+  };
   auto hstage = [&]() {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) hh[p] = __builtin_convertvector(rr[p], bf16x2);
+    for (int p = 0; p < 4; ++p) {
+      hh[p] = __builtin_convertvector(rr[p], bf16x2);
+      asm volatile("" : "+v"(hh[p]));                  // (stays in its gap: see P2L_PIN)
+    }
   };
   auto cat8 = [](const bf16x2 (&q)[4]) {
     const bf16x4 lo = __builtin_shufflevector(q[0], q[1], 0, 1, 2, 3);
@@ -768,24 +809,34 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
 // (hipcc sinks a conversion to its first use, four gaps later, in a clump: pin it to its gap)
 #define P2L_PIN(X) asm volatile("" : "+v"(X))
 #define P2L_MF(A, FI, J, P, M)                                                                \
-  acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
-      A, __builtin_bit_cast(bf16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                   \
+  if (!(ABL & 16))                                                                            \
+    acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
+        A, __builtin_bit_cast(bf16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                 \
   P2L_SB()
 
   const int nchunks = k.nchunks;
-  // The input transform of the NEXT chunk rides along as 20 micro-operations -- per part:
-  // request column pair 0 | combine its rows | request column pair 1 | combine | columns + stores --
-  // one in every second MFMA gap from the barrier of step 0 (gap 8) to gap 10 of step 3.
-  auto tx = [&](int j, float* Vn) {
-    const int part = j / 5, op = j - 5 * part;
+#ifdef P2L_LAB
+  // phase timestamps of one block: [wave][chunk][8] s_memtime ticks (slot 0 chunk top, 1-4 after
+  // steps 0-3, 5 after the closing barrier)
+  unsigned long long* trace =
+      (k.ws != nullptr && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
+#define P2L_TR(SLOT, C)                                                                      \
+  if (trace != nullptr && lane == 0 && (C) < 64) trace[(wave * 64 + (C)) * 8 + (SLOT)] = __builtin_amdgcn_s_memtime()
+#else
+#define P2L_TR(SLOT, C)
+#endif
+  // The input transform of the NEXT chunk rides along as micro-operations of <= 4 VALU each, one
+  // per MFMA gap (gaps 9 and 11 of a step carry the loads and the next h pieces), from the
+  // barrier of step 0 on; a request and its first use are two gaps apart.
+  //   op 0: request column pair 0 | 1: combine its rows, request pair 1 | 2: combine | 3..5: columns
+  auto tx = [&](int part, int op, float* Vn) {
     if (op == 0) t_load(part, 0);
-    else if (op == 1) t_rows(part, 0);
-    else if (op == 2) t_load(part, 1);
-    else if (op == 3) t_rows(part, 1);
-    else t_cols(part, Vn);
+    else if (op == 1) { t_rows(part, 0); t_load(part, 1); }
+    else if (op == 2) t_rows(part, 1);
+    else t_cols(part, op - 3, Vn);
   };
 #define P2L_TX(G)                                                                             \
-  if (more && (G) >= 8 && (((G) - 8) & 1) == 0 && ((G) - 8) / 2 < 20) tx(((G) - 8) / 2, Vn)
+  if (more && !(ABL & 2) && kTx.slot[G] >= 0) tx(kTx.slot[G] >> 3, kTx.slot[G] & 7, Vn)
   // one multiply step: fragment (fi, m) = (s >> 1, s & 1) of chunk c
   // (MORE_: not the last chunk -- a compile-time flag: the last chunk is its own copy of the
   //  four steps, so the steady-state loop carries no conditional branches)
@@ -798,10 +849,12 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     // gaps 0-3: m pieces pair by pair; (step 0) patch write
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      rr[p] = pk_sub(rr[p], widen2(hh[p]));
-      mm[p] = __builtin_convertvector(rr[p], bf16x2);
-      P2L_PIN(mm[p]);
-      if (s == 0 && p >= 1 && more) write_raw1(p - 1);
+      if (!(ABL & 8)) {
+        rr[p] = resid(rr[p], hh[p]);
+        mm[p] = __builtin_convertvector(rr[p], bf16x2);
+        P2L_PIN(mm[p]);
+      } else mm[p] = hh[p];
+      if (s == 0 && p >= 1 && more && !(ABL & 64)) write_raw1(p - 1);
       P2L_TX(12 * s + p);
       P2L_SB();
       if (p == 0) { P2L_MF(a1, fi, 1, 0, m); }
@@ -813,9 +866,11 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     // gaps 4-7: l pieces
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      rr[p] = pk_sub(rr[p], widen2(mm[p]));
-      ll[p] = __builtin_convertvector(rr[p], bf16x2);
-      P2L_PIN(ll[p]);
+      if (!(ABL & 8)) {
+        rr[p] = resid(rr[p], mm[p]);
+        ll[p] = __builtin_convertvector(rr[p], bf16x2);
+        P2L_PIN(ll[p]);
+      } else ll[p] = hh[p];
       P2L_TX(12 * s + 4 + p);
       P2L_SB();
       if (p == 0) { P2L_MF(a1, fi, 1, 2, m); }
@@ -828,16 +883,16 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     if (s == 0) {
       // the patch of chunk c+1 (written in gaps 1-3 by every wave) becomes visible; the MFMAs
       // issued so far keep the pipe busy while the barrier fills
-      __syncthreads();
+      if (!(ABL & 4)) __syncthreads();
     }
-    if (s + 1 < 4) lda(Vc, s + 1);
+    if (s + 1 < 4 && !(ABL & 32)) lda(Vc, s + 1);
     P2L_TX(12 * s + 8);
     P2L_SB();
     P2L_MF(a2, fi, 1, 1, m);
     // gap 9: weight fragments / next patch (address arithmetic + loads)
-    if (s == 0) load_b(c, 1, 1);
-    else if (s == 2 && more) load_b(c + 1, 0, 0);
-    else if (s == 1 && more) load_raw(c + 2 < nchunks ? c + 2 : c + 1);   // (last one: a harmless re-read)
+    if (s == 0 && !(ABL & 1)) load_b(c, 1, 1);
+    else if (s == 2 && more && !(ABL & 1)) load_b(c + 1, 0, 0);
+    else if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);   // (last one: a harmless re-read)
     P2L_SB();
     P2L_MF(a3, fi, 0, 0, m);
     // gap 10
@@ -845,8 +900,9 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     P2L_SB();
     P2L_MF(a3, fi, 1, 0, m);
     // gap 11: h pieces of the next fragment
-    if (s + 1 < 4) hstage();
+    if (s + 1 < 4 && !(ABL & 32)) hstage();
     P2L_SB();
+    P2L_TR(1 + s, c);
   };
 
   load_raw(0);
@@ -857,21 +913,28 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   if (nchunks > 1) load_raw(1);
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
-    t_load(part, 0); t_rows(part, 0); t_load(part, 1); t_rows(part, 1); t_cols(part, Vs);
+    t_load(part, 0); t_rows(part, 0); t_load(part, 1); t_rows(part, 1);
+    t_cols(part, 0, Vs);
+    if (part & 1) { t_cols(part, 1, Vs); t_cols(part, 2, Vs); }
   }
   __syncthreads();
   using T_ = std::true_type; using F_ = std::false_type;
+  if (ABL & 1) load_b(0, 1, 1);
+  if ((VAR & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c + 1 < nchunks; ++c) {
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
-    lda(Vc, 0);
-    hstage();
+    P2L_TR(0, c);
+    if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstage(); }
     P2L_SB();
     step(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
     step(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
+    if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(2);
     step(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
     step(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
-    __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
+    if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(0);
+    if (!(ABL & 4)) __syncthreads();    // V(c+1) complete; every read of V(c) and of the patch done
+    P2L_TR(5, c);
   }
   {
     const int c = nchunks - 1;
@@ -886,6 +949,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     __syncthreads();
   }
 #undef P2L_TX
+#undef P2L_TR
 #undef P2L_PIN
 #undef P2L_MF
 #undef P2L_SB
@@ -1026,7 +1090,12 @@ static int wino16_mode() {
   return g_wino16_mode;
 }
 static void* g_wino_trace = nullptr;
+int g_wino16_min_blocks = 0;
 int g_wino16_sched = 1;          // lab switch: hand-scheduled multiply phase
+#ifdef P2L_LAB
+static int g_lab_abl = 0;
+extern "C" int p2l_lab_set(int abl, void* trace) { g_lab_abl = abl; g_wino_trace = trace; return P2L_OK; }
+#endif
 // diagnostics: device buffer of 8 waves x 64 chunks x 8 uint64 that ONE block of every following
 // 16x16-pixel launch fills with s_memtime stamps of its phase boundaries (nullptr = off)
 extern "C" int p2l_wino_set_trace(void* buf) {
@@ -1052,7 +1121,7 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   const long blocks16 = (long)k.B * (k.H / 16) * (k.W / 16) * k.n_ntiles;
   // (in the bench step the 8-wave kernel is 1.03-1.10x on the layers with >= 128 input channels
   //  and 0.93-0.98x on the 64-channel ones: its longer prologue against only 4 chunks)
-  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || (blocks16 >= 512 && k.nchunks >= 8))) {
+  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || blocks16 >= g_wino16_min_blocks)) {
     k.tiles_y = k.H / 16;
     k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
     k.ws = (float*)g_wino_trace;
@@ -1077,6 +1146,35 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
   } while (0)
+#ifdef P2L_LAB
+#define P2L_W16L(ABL)                                                                        \
+  case ABL: {                                                                                \
+    (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, ABL>,           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL>), grid, block, W16_LDS_BYTES, st, k); \
+    return p2l_check_launch();                                                               \
+  }
+    if (g_wino16_sched && pro == P2L_PRO_NONE) {
+      switch (g_lab_abl) {
+        P2L_W16L(0) P2L_W16L(1) P2L_W16L(2) P2L_W16L(4) P2L_W16L(8) P2L_W16L(16) P2L_W16L(64)
+        P2L_W16L(3) P2L_W16L(10) P2L_W16L(67) P2L_W16L(75) P2L_W16L(79) P2L_W16L(111)
+        default: break;
+      }
+#define P2L_W16V(VAR)                                                                        \
+  case 1000 + VAR: {                                                                         \
+    (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, 0, VAR>,        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, 0, VAR>), grid, block, W16_LDS_BYTES, st, k); \
+    return p2l_check_launch();                                                               \
+  }
+      switch (g_lab_abl) {
+        P2L_W16V(1) P2L_W16V(2) P2L_W16V(4) P2L_W16V(5) P2L_W16V(6)
+        default: return P2L_EINVAL;
+      }
+#undef P2L_W16V
+    }
+#undef P2L_W16L
+#endif
     if (g_wino16_sched) {
       if (pro == P2L_PRO_NONE) P2L_W16S(P2L_PRO_NONE);
       else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16S(P2L_PRO_AFFINE_RELU);

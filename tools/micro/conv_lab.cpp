@@ -21,7 +21,80 @@ static float nrand() { float u = urand() + 1e-12f, v = urand(); return sqrtf(-2.
 
 struct Form { const char* name; int wfmt; int wino_mode; int block; };
 
+#ifdef P2L_LAB
+extern "C" int p2l_lab_set(int abl, void* trace);
+// ablations of the hand-scheduled 16x16 Winograd kernel + a phase trace of one block
+static int lab_main(int B) {
+  const int H = 64, W = 64, Cin = 256, Cout = 256;
+  const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * Cout, nw = (size_t)Cout * Cin * 9;
+  std::vector<float> hx(nx), hw(nw);
+  for (auto& v : hx) { v = nrand(); if (v < 0.f) v = 0.f; }
+  for (auto& v : hw) v = nrand() / sqrtf(9.f * Cin);
+  float *dx, *dwo, *dy, *dwp; unsigned long long* dtr;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dwo, nw * 4)); CK(hipMalloc(&dy, ny * 4));
+  CK(hipMalloc(&dtr, 8 * 64 * 8 * 8));
+  CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dwo, hw.data(), nw * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dwp, p2l_packed_weight_floats(9, Cout, Cin, P2L_WFMT_BF16X3W) * 4));
+  PK(p2l_pack_conv_weight_bf3w(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
+  PK(p2l_set_wino_mode(2)); PK(p2l_set_wino_block(2));
+  P2LConv d; memset(&d, 0, sizeof d);
+  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = P2L_PRO_NONE;
+  d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = P2L_WFMT_BF16X3W;
+  const struct { int abl; const char* what; } A[] = {
+      {0, "full"}, {1, "weights once"}, {2, "no transform"}, {4, "no barriers"}, {8, "no m/l pieces"},
+      {16, "no MFMAs"}, {64, "no patch traffic"}, {3, "weights once, no transform"},
+      {10, "no transform, no m/l"}, {67, "no weights/transform/patch"},
+      {75, "no weights/transform/patch/ml"}, {79, "... and no barriers"}, {111, "MFMAs + epilogue only"},
+      {0, "full (again)"}, {1001, "VAR 1: waves 4-7 prio 1"}, {1002, "VAR 2: prio handed over mid-chunk"},
+      {1004, "VAR 4: scalar subtractions"}, {1005, "VAR 1+4"}, {1006, "VAR 2+4"}};
+  // the clocks of an idle GPU take tens of milliseconds to settle: warm up, then two passes
+  PK(p2l_lab_set(0, nullptr));
+  for (int i = 0; i < 400; ++i)
+    PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+  CK(hipStreamSynchronize(st));
+  for (int pass = 0; pass < 2; ++pass)
+  for (auto a : A) {
+    PK(p2l_lab_set(a.abl, nullptr));
+    for (int i = 0; i < 3; ++i)
+      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 20; ++i)
+      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("pass %d abl %4d  %.4f ms   %s\n", pass, a.abl, ms / 20, a.what);
+  }
+  // phase trace of the full kernel
+  CK(hipMemset(dtr, 0, 8 * 64 * 8 * 8));
+  PK(p2l_lab_set(0, dtr));
+  PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+  CK(hipStreamSynchronize(st));
+  PK(p2l_lab_set(0, nullptr));
+  std::vector<unsigned long long> t(8 * 64 * 8);
+  CK(hipMemcpy(t.data(), dtr, t.size() * 8, hipMemcpyDeviceToHost));
+  const int nch = Cin / 16;
+  printf("trace (s_memtime ticks = 100 MHz? see ratio): per chunk, waves 0,1,4,5:  step0 step1 step2 step3 barrier | period\n");
+  for (int c : {1, 2, 7, 12}) for (int w : {0, 1, 4, 5}) {
+    const unsigned long long* a = &t[(w * 64 + c) * 8];
+    const unsigned long long nx0 = t[(w * 64 + c + 1) * 8];
+    printf("c%2d w%d  %6lld %6lld %6lld %6lld %6lld | %6lld\n", c, w, (long long)(a[1] - a[0]), (long long)(a[2] - a[1]),
+           (long long)(a[3] - a[2]), (long long)(a[4] - a[3]), (long long)(a[5] - a[4]), (long long)(nx0 - a[0]));
+  }
+  double per = 0; int n = 0;
+  for (int w = 0; w < 8; ++w) for (int c = 1; c + 2 < nch; ++c) { per += (double)(t[(w * 64 + c + 1) * 8] - t[(w * 64 + c) * 8]); ++n; }
+  printf("mean chunk period %.0f ticks\n", per / n);
+  return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
+#ifdef P2L_LAB
+  return lab_main(argc > 1 ? atoi(argv[1]) : 18);
+#endif
   const int B = argc > 1 ? atoi(argv[1]) : 18;
   const int pro = argc > 2 ? atoi(argv[2]) : P2L_PRO_NONE;
   struct { int H, Cin, Cout; } layers[] = {{64, 256, 256}, {32, 512, 512}, {128, 128, 128}, {256, 64, 64},
@@ -48,6 +121,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dsv, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dtv, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> ref(ny), out(ny);
+    for (int pass = 0; pass < 2; ++pass)
     for (const Form& f : forms) {
       const size_t wf = p2l_packed_weight_floats(9, Cout, Cin, f.wfmt);
       float* dwp; CK(hipMalloc(&dwp, wf * 4));
@@ -60,10 +134,10 @@ int main(int argc, char** argv) {
       d.pro_bstride = Cin; d.alpha = 1.f; d.act = P2L_ACT_NONE; d.pool = P2L_POOL_NONE; d.y_ld = Cout;
       d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt;
       CK(hipMemsetAsync(dy, 0xff, ny * 4, st));
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < (pass == 0 && &f == &forms[0] ? 300 : 5); ++i)   // (idle clocks settle first)
         PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
       CK(hipStreamSynchronize(st));
-      const int reps = 20;
+      const int reps = 30;
       CK(hipEventRecord(e0, st));
       for (int i = 0; i < reps; ++i)
         PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
@@ -72,13 +146,13 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
       CK(hipMemcpy(out.data(), dy, ny * 4, hipMemcpyDeviceToHost));
       double md = 0, mx = 0; size_t nbad = 0;
-      if (&f == &forms[0]) ref = out;
+      if (&f == &forms[0] && pass == 0) ref = out;
       for (size_t i = 0; i < ny; ++i) {
         if (!(out[i] == out[i])) { ++nbad; continue; }
         md = fmax(md, fabs((double)out[i] - ref[i])); mx = fmax(mx, fabs((double)ref[i]));
       }
       const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
-      printf("%2dx%3d^2 %3d->%3d pro%d %-12s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", B, H, Cin, Cout, pro,
+      printf("p%d %2dx%3d^2 %3d->%3d pro%d %-12s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", pass, B, H, Cin, Cout, pro,
              f.name, ms, fl / ms / 1e9, md / (mx + 1e-30), nbad);
       fflush(stdout);
       CK(hipFree(dwp));
