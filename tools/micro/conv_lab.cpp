@@ -91,7 +91,75 @@ static int lab_main(int B) {
 }
 #endif
 
+
+// 1x1 layers of the bench step: exact-fp32 kernel | bf16x3 kernel
+static int pw_main(int B, int pro) {
+  struct { int H, Cin, Cout; } layers[] = {{64, 256, 512}, {64, 512, 256}, {128, 128, 256}, {128, 64, 256},
+                                          {256, 64, 128}, {256, 128, 64}, {64, 128, 512}, {64, 64, 512},
+                                          {32, 256, 1024}, {32, 1024, 256}, {64, 512, 128}, {128, 256, 64}};
+  struct { const char* name; int wfmt; int form; } forms[] = {
+      {"fp32", P2L_WFMT_F32, 0}, {"pw-lds", P2L_WFMT_PW, 0}};
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto L : layers) {
+    const int H = L.H, W = L.H, Cin = L.Cin, Cout = L.Cout;
+    const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * Cout, nw = (size_t)Cout * Cin;
+    std::vector<float> hx(nx), hw(nw), hs((size_t)B * Cin), ht((size_t)B * Cin);
+    for (auto& v : hx) { v = nrand(); if (pro == P2L_PRO_NONE && v < 0.f) v = 0.f; }
+    for (auto& v : hw) v = nrand() / sqrtf((float)Cin);
+    for (auto& v : hs) v = 0.5f + urand();
+    for (auto& v : ht) v = 0.3f * nrand();
+    float *dx, *dwo, *dy, *dsv, *dtv;
+    CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dwo, nw * 4)); CK(hipMalloc(&dy, ny * 4));
+    CK(hipMalloc(&dsv, hs.size() * 4)); CK(hipMalloc(&dtv, ht.size() * 4));
+    CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dwo, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsv, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtv, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> ref(ny), out(ny);
+    for (int pass = 0; pass < 2; ++pass)
+    for (auto& f : forms) {
+      float* dwp;
+      if (f.wfmt == P2L_WFMT_PW) {
+        CK(hipMalloc(&dwp, ((size_t)Cout * Cin * 5 / 2 + 64) * 4));
+        PK(p2l_pack_conv_weight_pw(dwo, Cout, Cin, Cout, Cin, 0, dwp, st));
+      } else {
+        CK(hipMalloc(&dwp, (size_t)Cout * Cin * 4));
+        PK(p2l_pack_conv_weight(dwo, Cout, Cin, 1, Cout, Cin, 0, dwp, st));
+      }
+      P2LConv d; memset(&d, 0, sizeof d);
+      d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 1; d.x_ld = Cin; d.pro = pro;
+      d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt;
+      for (int i = 0; i < (pass == 0 && &f == &forms[0] ? 300 : 5); ++i)
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      CK(hipStreamSynchronize(st));
+      const int reps = 30;
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i)
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      CK(hipMemcpy(out.data(), dy, ny * 4, hipMemcpyDeviceToHost));
+      if (&f == &forms[0] && pass == 0) ref = out;
+      double md = 0, mx = 0; size_t nbad = 0;
+      for (size_t i = 0; i < ny; ++i) {
+        if (!(out[i] == out[i])) { ++nbad; continue; }
+        md = fmax(md, fabs((double)out[i] - ref[i])); mx = fmax(mx, fabs((double)ref[i]));
+      }
+      const double fl = 2.0 * B * H * W * (double)Cin * Cout, by = 4.0 * (nx + ny);
+      if (pass == 1)
+        printf("%2dx%3d^2 %4d->%4d pro%d %-9s %.4f ms %6.1f TFLOP/s %5.2f TB/s  max|d|/max|ref| %.2e nan %zu\n", B, H, Cin,
+               Cout, pro, f.name, ms, fl / ms / 1e9, by / ms / 1e9, md / (mx + 1e-30), nbad);
+      fflush(stdout);
+      CK(hipFree(dwp));
+    }
+    CK(hipFree(dx)); CK(hipFree(dwo)); CK(hipFree(dy)); CK(hipFree(dsv)); CK(hipFree(dtv));
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 3 && atoi(argv[3]) == 1) return pw_main(atoi(argv[1]), atoi(argv[2]));
 #ifdef P2L_LAB
   return lab_main(argc > 1 ? atoi(argv[1]) : 18);
 #endif
