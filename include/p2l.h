@@ -86,6 +86,9 @@ typedef struct P2LConv {
                     /* high-res buffer is [B,H+2,W+2,*] (rows/cols 0..H real,     */
                     /* H+1 zero) and the low-res grid of ups=2 has H/2+1 points   */
   int32_t wfmt;     /* P2L_WFMT_*: format of w_packed (3x3 / sub-pixel only)       */
+  int32_t form;     /* P2L_FORM_* bits: which kernel form may run THIS launch (0 =  */
+                    /* automatic).  Per call, not a library-wide switch: the library  */
+                    /* holds no mutable state that a launch reads                     */
   double algo_flops; /* algorithmic FLOPs of this launch for the profiler;    */
                      /* 0 = 2*B*H*W*Cin*Cout*taps (set it when Cin/Cout are   */
                      /* zero-padded, e.g. the 3-channel image convs)          */
@@ -160,6 +163,11 @@ int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[
  * steps every launch of the step has been timed once.  Without the call every launch is
  * timed. */
 int p2l_prof_step(int step, int period);
+/* p2l_prof_end* also write one line per timed launch to `path` (taps B H W Cin Cout ups pro arb
+ * splitk flops bytes ms) when a path was given; NULL switches it off.  The profiler is the one
+ * process-wide object of the library (the backward pass of a torch program runs on the autograd
+ * engine's thread and must be timed too): opt-in, every access under a mutex. */
+int p2l_prof_dump(const char* path);
 
 /* Extra epilogue terms of the StyleGAN2 styled conv (p2l_conv_fwd_ex):
  *   v = acc * oscale[b][n] + noise_w * noise[b][pixel] + bias[n] ; act            */
@@ -217,7 +225,10 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *   Model structs (P2LBigGAN.wfmt ...) hold the 3x3 format in bits 0-3 and P2L_WFMT_FLAG_PW when
  *   their 1x1 weight buffers are P2L_WFMT_PW buffers. */
 enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2, P2L_WFMT_PW = 3,
-       P2L_WFMT_BF16X3T = 4, P2L_WFMT_FLAG_PW = 0x10, P2L_WFMT_FLAG_THIN = 0x20 };
+       P2L_WFMT_BF16X3T = 4, P2L_WFMT_FLAG_PW = 0x10, P2L_WFMT_FLAG_THIN = 0x20,
+       P2L_WFMT_FLAG_ATTN_GEMM = 0x40 /* model descriptors: self-attention as GEMM + softmax   */
+                                      /* (the attention matrix is stored) instead of the fused  */
+                                      /* kernels of csrc/p2l_attn.hip                          */ };
 /* P2L_WFMT_BF16X3T (3x3 convs with THREE real channels on one side, padded to N_pad == 32 or
  * K_pad == 16: conv_to_rgb, the first VGG conv and their input gradients): the BF16X3 image
  * followed by the image of p2l_thin.hip's kernels (27 tap-channel products as one K dimension
@@ -228,18 +239,19 @@ int p2l_pack_conv_weight_bf3t(const float* w_oihw, int O, int I, int N_pad, int 
 int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_pad, int K_pad,
                             int transpose_flip, float* w_packed, void* stream);
 size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt);
-/* which P2L_WFMT_BF16X3W launches take the Winograd form: 0 = none, 1 = those whose grid gives
- * every CU a block (default; $P2L_WINO overrides the default), 2 = every eligible shape
- * (tests: small grids too) */
-int p2l_set_wino_mode(int mode);
-/* block shape of the Winograd form: 0 = 8x16 pixels (4 waves, two blocks per CU), 1 = 16x16
- * pixels (8 waves, split in the consumer) when that grid still fills the chip (default;
- * $P2L_WINO16 overrides the default), 2 = 16x16 whenever H and W allow it (tests).  Both give
- * bit-identical results. */
-int p2l_set_wino_block(int mode);
-/* diagnostics: device buffer (8 waves x 64 chunks x 8 uint64) that one block of every following
- * 16x16-pixel Winograd launch fills with s_memtime stamps of its phase boundaries; NULL = off */
-int p2l_wino_set_trace(void* buf);
+/* P2LConv.form.  Which P2L_WFMT_BF16X3W launches take the Winograd form by default: those whose
+ * layer shape gives at least 64 blocks of 8x16 pixels x 64 channels per image (never a function
+ * of the batch: a candidate's result must not depend on who shares its launch).  The Winograd
+ * form runs 16x16-pixel blocks (8 waves, hand-scheduled, csrc/p2l_wino.hip) when H and W are
+ * multiples of 16 and 8x16-pixel blocks (4 waves) otherwise; both give bit-identical results. */
+enum {
+  P2L_FORM_AUTO = 0,
+  P2L_FORM_NO_WINO = 1,      /* direct kernel even where the Winograd form is eligible         */
+  P2L_FORM_WINO_ANY = 2,     /* Winograd form for every eligible shape, small grids too (tests) */
+  P2L_FORM_WINO_8X16 = 4,    /* the 8x16-pixel Winograd kernel even where 16x16 fits (tests)   */
+  P2L_FORM_NO_PW = 8,        /* P2L_WFMT_PW weights, but the exact-fp32 1x1 kernel             */
+  P2L_FORM_NO_THIN = 16      /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
+};
 int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
                               int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,

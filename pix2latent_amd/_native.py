@@ -23,7 +23,7 @@ class P2LConv(C.Structure):
                 ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
                 ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
                 ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('ext', C.c_int32),
-                ('wfmt', C.c_int32), ('algo_flops', C.c_double)]
+                ('wfmt', C.c_int32), ('form', C.c_int32), ('algo_flops', C.c_double)]
 
 
 class P2LArb(C.Structure):
@@ -123,7 +123,9 @@ class P2LLossCache(C.Structure):
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
 WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW, WFMT_BF16X3T = 0, 1, 2, 3, 4
-WFMT_FLAG_PW, WFMT_FLAG_THIN = 0x10, 0x20
+WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM = 0x10, 0x20, 0x40
+# P2LConv.form (per launch; the library has no switches of its own)
+FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN = 0, 1, 2, 4, 8, 16
 
 
 def default_wfmt():
@@ -145,6 +147,12 @@ def default_thin():
     """3-channel image convs (conv_to_rgb, first VGG conv and their input gradients) on the
     kernels of csrc/p2l_thin.hip unless P2L_THIN=0 or the exact-fp32 MFMA was asked for"""
     return os.environ.get('P2L_THIN', '1') != '0' and default_wfmt() != WFMT_F32
+
+
+def default_attn_gemm():
+    """P2L_ATTN=0: self-attention of the generator as GEMM + softmax (the attention matrix is
+    stored) instead of the fused kernels -- a MODEL descriptor flag, read here once"""
+    return os.environ.get('P2L_ATTN', '1') == '0'
 
 
 def default_pw():
@@ -193,7 +201,7 @@ EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
     'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
-    'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 'p2l_set_wino_mode', 'p2l_set_wino_block', 'p2l_wino_set_trace',
+    'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 
     'p2l_pack_conv_weight_bf3t',
     'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_attn_supported', 'p2l_attn_fwd_ws_bytes', 'p2l_attn_fwd', 'p2l_attn_bwd_dv_ws_bytes',
@@ -208,7 +216,7 @@ EXPORTS = [
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_step', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
     'p2l_sg2_pixelnorm_fwd', 'p2l_sg2_pixelnorm_bwd', 'p2l_sg2_bias_lrelu_fwd', 'p2l_sg2_lrelu_bwd',
     'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
     'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',

@@ -26,6 +26,7 @@
 //   * every product is the 6-term bf16x3 form (include/p2l.h P2L_WFMT_BF16X3), fp32 accumulate;
 //     exp() is v_exp_f32 on (s - max) * log2(e).
 #include "p2l_conv_k.h"
+#include <atomic>
 
 using namespace p2lconv;
 
@@ -617,7 +618,7 @@ int run_prep(const float* x, const float* w, const float* stat, f32x4* img, int 
 
 template <int MODE>
 int run_core(const AttnK& a, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_core_kernel<MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -770,7 +771,7 @@ extern "C" int p2l_attn_bwd_qk(const P2LAttn* d, const float* q, const float* k,
                      out, dsum, d->B * d->Nq);
   if ((rc = p2l_check_launch())) return rc;
   {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)attn_ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);

@@ -43,7 +43,10 @@
 
 #include <cstdlib>
 #include <array>
+#include <atomic>
 #include <cstdio>
+#include <mutex>
+#include <string>
 #include <vector>
 
 using namespace p2lconv;
@@ -54,7 +57,7 @@ namespace {
 // hipEvents from a pre-created pool are recorded on the launch stream around
 // every conv (incl. its split-K finish); nothing is allocated while enabled.
 struct ConvProf {
-  bool on = false;
+  std::atomic<bool> on{false};
   int n = 0;
   std::vector<hipEvent_t> ev;
   std::vector<double> flops;    // algorithmic (direct convolution on the real channels)
@@ -62,8 +65,19 @@ struct ConvProf {
   std::vector<double> bytes;
   std::vector<int> kind;
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
+  std::string dump_path;                    // p2l_prof_dump
   int seq = 0, period = 1, phase = 0;       // sampling (p2l_prof_step)
-} g_prof;
+  std::mutex mu;                            // launches of any host thread may claim a slot
+};
+// The one piece of process-wide state of the library: the OPT-IN launch profiler (off unless
+// p2l_prof_begin was called).  Process-wide on purpose -- the backward pass of a torch program
+// runs on the autograd engine's thread, and bench.py times those launches too -- and guarded:
+// slot claims and begin / end take the mutex, a disabled profiler costs one relaxed load.
+ConvProf& prof() {
+  static ConvProf p;
+  return p;
+}
+#define g_prof prof()
 
 // BF3 = fp32-equivalent arithmetic on the bf16 matrix pipe (16x the fp32 MFMA rate):
 // every fp32 operand is split into three bf16 pieces x = x1 + x2 + x3 (round-to-nearest
@@ -894,47 +908,33 @@ int halo_pitch(int TW, bool bf3) {
 // inside the bench step (profiles/round2_layers_*.txt) the Winograd kernel is 1.05-1.29x the
 // direct one on those, and 0.92-1.10x on the 16^2 / 32^2 layers with fewer blocks (its longer
 // prologue / epilogue against rounds of the chip that are mostly empty).
-// $P2L_WINO=0 switches it off; mode 2 (p2l_set_wino_mode, tests) takes every eligible shape.
-static int g_wino_mode = -1;
-static int wino_mode() {
-  if (g_wino_mode < 0) { const char* e = getenv("P2L_WINO"); g_wino_mode = e ? atoi(e) : 1; }
-  return g_wino_mode;
-}
-extern "C" int p2l_set_wino_mode(int mode) {
-  if (mode < 0 || mode > 2) return P2L_EINVAL;
-  g_wino_mode = mode;
-  return P2L_OK;
-}
+// P2LConv.form: P2L_FORM_NO_WINO keeps the direct kernel, P2L_FORM_WINO_ANY takes every eligible
+// shape (tests: small grids too).
 static bool wino_shape(const P2LConv* d) {
-  if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || wino_mode() == 0) return false;
+  if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || (d->form & P2L_FORM_NO_WINO)) return false;
   if (d->H % 8 || d->W % 16 || d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin)) return false;
   const int per_image = (d->H / 8) * (d->W / 16) * (d->Cout / 64);
-  return wino_mode() == 2 || per_image >= 64;
+  // (measured, tools/policy_probe.py: a threshold of 32 -- the 32^2 256->256 layers too -- is
+  //  +1 % at 18 candidates per GPU and -2...-4 % at 2-3, where those launches are 48 blocks)
+  return (d->form & P2L_FORM_WINO_ANY) || per_image >= 64;
 }
 
 // bf16x3 form of the 1x1 conv (p2l_pw.hip): weights carry the pre-split image
 // (P2L_WFMT_PW), whole 128-pixel tiles of one image, 64-channel stages and tiles.  Like the
 // Winograd form a function of the layer shape only; the 4^2 .. 16^2 layers stay on the
-// exact-fp32 kernel (split-K regime).  $P2L_PW=0 switches it off.
+// exact-fp32 kernel (split-K regime).  P2L_FORM_NO_PW keeps the exact-fp32 kernel.
 static bool pw_shape(const P2LConv* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("P2L_PW"); on = e ? atoi(e) : 1; }
-  if (!on || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
+  if ((d->form & P2L_FORM_NO_PW) || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
   if (d->Cin % 64 || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16) return false;
   // measured per layer inside the bench step: 1.2-1.9x the exact-fp32 kernel from 256 input
-  // channels up, 1.07-1.39x with 64 / 128 (32-channel stages, four blocks per CU; the first
-  // 64-channel-stage form was 0.8-0.9x there, hence the switch)
-  static int min_cin = -1;
-  if (min_cin < 0) { const char* e = getenv("P2L_PW_MIN_CIN"); min_cin = e ? atoi(e) : 64; }
-  return d->H * d->W >= 1024 && d->Cin >= min_cin;
+  // channels up, 1.07-1.39x with 64 / 128 (32-channel stages, four blocks per CU)
+  return d->H * d->W >= 1024;
 }
 
 // 3-channel image convs (p2l_thin.hip): 0 thin output, 1 thin input, -1 the generic kernel.
 // Shape + format only (the epilogue conditions are checked at the launch).
 static int thin_shape(const P2LConv* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("P2L_THIN"); on = e ? atoi(e) : 1; }
-  if (!on || d->wfmt != P2L_WFMT_BF16X3T || d->taps != 9 || d->ups != 0) return -1;
+  if ((d->form & P2L_FORM_NO_THIN) || d->wfmt != P2L_WFMT_BF16X3T || d->taps != 9 || d->ups != 0) return -1;
   if (d->H % 8 || d->W % 16 || d->x_ld % 4 || d->Cin % 16) return -1;
   return p2l_thin_mode(d->Cout, d->Cin);
 }
@@ -969,7 +969,7 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 #define P2L_LAUNCH(PRO, UPS)                                                     \
   do {                                                                           \
     auto kfn = pick_kernel<TAPS, BN, KC, A_ITERS, PRO, UPS, BF3>();             \
-    static bool attr_set = false;                                                \
+    static std::atomic<bool> attr_set{false};                                                \
     if (!attr_set) {                                                             \
       (void)hipFuncSetAttribute((const void*)kfn,                                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,      \
@@ -1068,6 +1068,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   k.mask_ld = d->mask_ld; k.n_store = d->n_store; k.pro_bstride = d->pro_bstride;
   k.alpha = d->alpha; k.act = d->act; k.pool = d->pool; k.res_ups = d->res_ups;
   k.ups = d->ups;
+  k.form = d->form;
   int rc = choose_tile(d, k);
   if (rc) return rc;
   k.iH = d->H; k.iW = d->W; k.ibH = d->H; k.ibW = d->W; k.obH = d->H; k.obW = d->W;
@@ -1111,9 +1112,12 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) prof_ok = false;
   }
-  if (prof_ok && g_prof.n < (int)g_prof.flops.size() &&
-      (g_prof.seq++ % g_prof.period) == g_prof.phase) {
-    prof_slot = g_prof.n++;
+  if (prof_ok) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.on && g_prof.n < (int)g_prof.flops.size() && (g_prof.seq++ % g_prof.period) == g_prof.phase)
+      prof_slot = g_prof.n++;
+  }
+  if (prof_slot >= 0) {
     g_prof.flops[prof_slot] = d->algo_flops > 0.0
         ? d->algo_flops
         : 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * d->taps;
@@ -1235,7 +1239,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
 #define P2L_LAUNCH_SP2(BNV, AIT, PROV, BF3V)                                              \
     do {                                                                                  \
       auto kfn = pick_kernel<4, BNV, 16, AIT, PROV, false, BF3V>();                       \
-      static bool attr_set = false;                                                       \
+      static std::atomic<bool> attr_set{false};                                                       \
       if (!attr_set) {                                                                    \
         (void)hipFuncSetAttribute((const void*)kfn,                                       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1403,6 +1407,7 @@ extern "C" int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I
 
 extern "C" int p2l_prof_begin(int max_launches) {
   if (max_launches < 1) return P2L_EINVAL;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   while ((int)g_prof.ev.size() < 2 * max_launches) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return P2L_ELAUNCH;
@@ -1419,8 +1424,15 @@ extern "C" int p2l_prof_begin(int max_launches) {
   return P2L_OK;
 }
 
+extern "C" int p2l_prof_dump(const char* path) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.dump_path = path ? path : "";
+  return P2L_OK;
+}
+
 extern "C" int p2l_prof_step(int step, int period) {
   if (step < 0 || period < 1) return P2L_EINVAL;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.seq = 0;
   g_prof.period = period;
   g_prof.phase = step % period;
@@ -1438,13 +1450,13 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
 extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
                              double exec_flops[2]) {
   if (exec_flops) exec_flops[0] = exec_flops[1] = 0.0;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = false;
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
   count[0] = count[1] = 0;
   if (bytes) bytes[0] = bytes[1] = 0.0;
-  // P2L_PROF_DUMP=<file>: one line per launch (tools/prof_layers.py reads it)
-  const char* dump_path = getenv("P2L_PROF_DUMP");
-  FILE* dump = dump_path ? fopen(dump_path, "w") : nullptr;
+  // p2l_prof_dump(<file>): one line per launch (tools/prof_layers.py reads it)
+  FILE* dump = g_prof.dump_path.empty() ? nullptr : fopen(g_prof.dump_path.c_str(), "w");
   for (int i = 0; i < g_prof.n; ++i) {
     if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) return P2L_ELAUNCH;
     float t = 0.f;

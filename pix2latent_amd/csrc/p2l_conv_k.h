@@ -46,7 +46,7 @@ struct ConvK {
   // touches on disjoint banks (with tile width + 2 = 18 every activation-fragment read was a
   // 2-way bank conflict: rows 16 apart share a bank window for the 96-byte row).
   int hp;
-  int abl;   // ablation bits, timing experiments only ($P2L_ABL; results are wrong when set)
+  int form;  // P2LConv.form of this launch (kernel-form choice of the launchers)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

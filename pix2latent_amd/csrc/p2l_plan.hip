@@ -183,10 +183,9 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
         // fused form (p2l_attn.hip): the P x P/4 matrix is never stored; shapes it does not
         // take keep the GEMM + softmax sequence and its matrix
         P2LAttn ad{B, (int)P, (int)(P / 4), C / 8, C / 2};
-        static int on = -1;
-        if (on < 0) { const char* e = getenv("P2L_ATTN"); on = e ? atoi(e) : 1; }
         // (a model built for the exact-fp32 MFMA keeps the exact-fp32 GEMMs here too)
-        L.att_fused = on && (m->wfmt & 0xF) != P2L_WFMT_F32 && p2l_attn_supported(&ad) && (P % 256 == 0);
+        L.att_fused = !(m->wfmt & P2L_WFMT_FLAG_ATTN_GEMM) && (m->wfmt & 0xF) != P2L_WFMT_F32 &&
+                      p2l_attn_supported(&ad) && (P % 256 == 0);
         if (L.att_fused) {
           size_t wsb = p2l_attn_fwd_ws_bytes(&ad);
           if (p2l_attn_bwd_dv_ws_bytes(&ad) > wsb) wsb = p2l_attn_bwd_dv_ws_bytes(&ad);

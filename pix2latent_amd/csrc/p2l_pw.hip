@@ -30,7 +30,7 @@
 //     copied global -> registers -> LDS as an image.
 #include "p2l_conv_k.h"
 
-#include <cstdlib>
+#include <atomic>
 
 using namespace p2lconv;
 
@@ -186,23 +186,19 @@ __global__ __launch_bounds__(256, KS == 64 ? 2 : 4) void pw_bf3_kernel(const Con
 
 int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles), block(256);
-  static int ks_env = -1;                                // $P2L_PW_KS = 64 | 32 (default 32)
-  if (ks_env < 0) { const char* e = getenv("P2L_PW_KS"); ks_env = e ? atoi(e) : 32; }
-#define P2L_PW(PRO, KSV)                                                                     \
+#define P2L_PW(PRO)                                                                          \
   do {                                                                                       \
-    static bool attr_set = false;                                                            \
+    static std::atomic<bool> attr_set{false};                                                \
     if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)pw_bf3_kernel<PRO, KSV>,                        \
+      (void)hipFuncSetAttribute((const void*)pw_bf3_kernel<PRO, 32>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
-    hipLaunchKernelGGL((pw_bf3_kernel<PRO, KSV>), grid, block, PwCfg<KSV>::LDS_BYTES, st, k); \
+    hipLaunchKernelGGL((pw_bf3_kernel<PRO, 32>), grid, block, PwCfg<32>::LDS_BYTES, st, k);  \
   } while (0)
-#define P2L_PW_K(PRO) do { if (ks_env == 64) P2L_PW(PRO, 64); else P2L_PW(PRO, 32); } while (0)
-  if (pro == P2L_PRO_NONE) P2L_PW_K(P2L_PRO_NONE);
-  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW_K(P2L_PRO_AFFINE_RELU);
-  else P2L_PW_K(P2L_PRO_AFFINE);
-#undef P2L_PW_K
+  if (pro == P2L_PRO_NONE) P2L_PW(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW(P2L_PRO_AFFINE_RELU);
+  else P2L_PW(P2L_PRO_AFFINE);
 #undef P2L_PW
   return p2l_check_launch();
 }

@@ -34,7 +34,7 @@
 // (tests/test_kernels_gpu.py runs both against the same tolerance).
 #include "p2l_conv_k.h"
 
-#include <cstdlib>
+#include <atomic>
 #include <type_traits>
 
 using namespace p2lconv;
@@ -162,7 +162,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
   const f32x4* wq = reinterpret_cast<const f32x4*>(k.w);
   f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
   auto load_b = [&](int c, int fi, int set) {
-    if (k.abl & 1) return;
     const size_t base = (((size_t)c * 16 + (4 * wave + fi)) * n_t32 + (n0 >> 5)) * 3 * 64 + lane;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -187,11 +186,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
     const bool more = c + 1 < nchunks;
     write_raw();
     __syncthreads();
-    if (more && !(k.abl & 4)) load_raw(c + 1);
-    if (!(k.abl & 2)) transform();
+    if (more) load_raw(c + 1);
+    transform();
     load_b(c, 1, 1);                 // frequency 1's fragments: in flight across the barrier
     __syncthreads();
-    if (k.abl & 8) continue;
     bf16x8 af[2][3];
     auto lda = [&](int fi, bf16x8 (&a)[3]) {
       const int row = (4 * wave + fi) * 32 + l31;
@@ -277,23 +275,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void wino_conv_kernel(const ConvK k)
 // ---- 16x16-pixel blocks, 8 waves -----------------------------------------------------------
 // The 8x16-pixel kernel above fetches the chunk's whole transform-domain weight slice (96 KB
 // for 64 output channels) once per 32 tiles: with two blocks per CU that alone is ~64 B/clk,
-// the L2 -> L1 rate of a CU, and PMC showed its phases (weight wait | transform + split | MFMA)
-// running one after the other: MFMA pipe 26-34 % busy.  This form doubles the tiles per block
-// and reorganises the phases so that they overlap:
+// the L2 -> L1 rate of a CU, and its phases (weight wait | transform + split | MFMA) run one
+// after the other: MFMA pipe 26-34 % busy.  The 16x16-pixel form:
 //   * block = 16x16 output pixels = 64 tiles (2 M-tiles) x 64 output channels, 8 waves; wave w
 //     owns frequencies 2w, 2w+1: 2 freq x 2 M x 2 N accumulators (128 VGPR).  A weight
-//     fragment now serves two M-tiles: half the L2 traffic per product;
+//     fragment serves two M-tiles: half the L2 traffic per product;
 //   * the transformed input V stays FP32 in LDS ([frequency][tile][16 channels], 64 KB, double
-//     buffered) and is split into bf16 pieces by its CONSUMER: each (frequency, M-tile)
-//     fragment is read by exactly one wave, so the split costs the same VALU work as before
-//     but now sits between that wave's MFMAs instead of in a separate phase;
-//   * the transform of chunk c+1 is cut into four parts that follow the four MFMA groups of
-//     chunk c in every wave's instruction stream (a first version ran the two waves of a SIMD
-//     in opposite phase order instead: the phase trace -- p2l_wino_set_trace -- showed the
-//     multiply phases colliding on the pipe and 28 % of the chunk period without any MFMA).
-//     Two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
-// Same additions and products in the same order as the 8x16 kernel: bit-identical results,
-// so which of the two runs is a pure performance choice (p2l_wino_launch).
+//     buffered, 16-byte slots XOR-swizzled by the tile index) and is split into bf16 pieces by
+//     its CONSUMER: each (frequency, M-tile) fragment is read by exactly one wave;
+//   * two barriers per chunk (V buffers swap | the fp32 patch is rewritten).
+// Same additions and products in the same order as the 8x16 kernel: bit-identical results.
 // a wave-uniform pointer pinned to scalar registers: hipcc then addresses `p + lane offset` as
 // global_load v_off, s[base] instead of carrying a 64-bit address per lane and load
 __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
@@ -311,290 +302,15 @@ constexpr size_t W16_LDS_BYTES = (size_t)(W16_RAW_FLOATS + 2 * W16_V_FLOATS) * s
 static_assert(W16_LDS_BYTES <= 160 * 1024, "one block per CU");
 static_assert(16 * 64 * WN_DUMP_PITCH <= 2 * W16_V_FLOATS, "epilogue dump fits");
 
-template <int PRO>
-__global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw = smem;
-  float* Vs = smem + W16_RAW_FLOATS;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int swz = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
-  const int tiles_per_image = k.tiles_x * k.tiles_y;                  // 16x16-pixel tiles
-  const int b = mt / tiles_per_image;
-  const int tile_in_image = mt - b * tiles_per_image;
-  const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
-  const int y0 = by * 16, x0 = bx * 16, n0 = nt * 64;
-
-  // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
-  constexpr int A_ITERS = 3;
-  const int sv = tid & 3;
-  int a_goff[A_ITERS], a_loff[A_ITERS];
-  unsigned a_valid = 0;
-#pragma unroll
-  for (int it = 0; it < A_ITERS; ++it) {
-    const int p = (tid + W16_THREADS * it) >> 2;
-    a_goff[it] = 0;
-    a_loff[it] = (p < W16_RAW_ROWS) ? p * WN_RAW_PITCH + sv * 4 : -1;
-    if (p < W16_RAW_ROWS) {
-      const int hy = p / 18, hx = p - hy * 18;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
-        a_goff[it] = ((b * k.H + iy) * k.W + ix) * k.x_ld + sv * 4;
-        a_valid |= 1u << it;
-      }
-    }
-  }
-  const int s_off = b * k.pro_bstride + sv * 4;
-  f32x4 xr[A_ITERS], sr, tr;
-  auto load_raw = [&](int c) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
-      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + c * 16);
-    if (PRO != P2L_PRO_NONE) {
-      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + c * 16);
-      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + c * 16);
-    }
-  };
-  auto write_raw = [&]() {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      if (a_loff[it] < 0) continue;
-      f32x4 v = xr[it];
-      if (PRO != P2L_PRO_NONE) {
-        v = v * sr + tr;
-        if (PRO == P2L_PRO_AFFINE_RELU) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-      }
-      if (!((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(raw + a_loff[it]) = v;
-    }
-  };
-
-  // ---- input transform item: (half h, tile tt of 64, channel quad tv) --------------------
-  // V row (frequency f, tile t) holds 16 channels = four 16-byte slots; slot s of a row lives
-  // at s ^ ((t >> 2) & 3): the consumer's ds_read_b128 lane groups then hit 16 distinct slots
-  const int th = __builtin_amdgcn_readfirstlane(tid >> 8);   // (wave-uniform: no exec-masked branches)
-  const int tt = (tid >> 2) & 63, tv = tid & 3;
-  const int tty = tt >> 3, ttx = tt & 7;
-  const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
-  const int t_dst = tt * 16 + ((tv ^ ((tt >> 2) & 3)) << 2);
-  // the transform of one chunk in four parts (two frequency rows x two halves) so that it can
-  // sit between the MFMA groups of the previous chunk: part (i, 0) loads patch columns 0 and 2
-  // and emits frequency 4*fr+0, part (i, 1) loads columns 1 and 3 and emits the other three
-  f32x4 tq[4];                                          // loads in flight
-  f32x4 tR2;                                            // R[2] of the current frequency row
-  auto t_load = [&](int part) {
-    const int fr = 2 * th + (part >> 1);
-    const int ra = (fr == 0) ? 0 : (fr == 2 ? 2 : 1);
-    const int rb = (fr == 2) ? 1 : (fr == 3 ? 3 : 2);
-    const int c0 = part & 1;                            // columns c0, c0 + 2
-    tq[0] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0) * WN_RAW_PITCH);
-    tq[1] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0) * WN_RAW_PITCH);
-    tq[2] = *reinterpret_cast<const f32x4*>(t_src + (ra * 18 + c0 + 2) * WN_RAW_PITCH);
-    tq[3] = *reinterpret_cast<const f32x4*>(t_src + (rb * 18 + c0 + 2) * WN_RAW_PITCH);
-  };
-  auto t_emit = [&](int part, float* Vn) {
-    const int fr = 2 * th + (part >> 1);
-    float* d = Vn + fr * 4 * 1024 + t_dst;
-    const f32x4 Ra = (fr == 1) ? tq[0] + tq[1] : sub4(tq[0], tq[1]);     // column c0
-    const f32x4 Rb = (fr == 1) ? tq[2] + tq[3] : sub4(tq[2], tq[3]);     // column c0 + 2
-    if ((part & 1) == 0) {                              // R[0], R[2]
-      *reinterpret_cast<f32x4*>(d) = sub4(Ra, Rb);
-      tR2 = Rb;
-    } else {                                            // R[1], R[3]
-      *reinterpret_cast<f32x4*>(d + 1024) = Ra + tR2;
-      *reinterpret_cast<f32x4*>(d + 2048) = sub4(tR2, Ra);
-      *reinterpret_cast<f32x4*>(d + 3072) = sub4(Ra, Rb);
-    }
-  };
-  auto transform = [&](float* Vn) {
-#pragma unroll
-    for (int part = 0; part < 4; ++part) { t_load(part); t_emit(part, Vn); }
-  };
-
-  // ---- weight fragments: global -> registers, one frequency ahead -------------------------
-  const int n_t32 = k.Cout >> 5;
-  const f32x4* wq = reinterpret_cast<const f32x4*>(k.w);
-  f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
-  auto load_b = [&](int c, int fi, int set) {
-    const size_t base = (((size_t)c * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * 3 * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bw[set][j][p] = wq[base + (size_t)(j * 3 + p) * 64];
-  };
-
-  f32x16 acc[2][2][2];                                 // [freq][M-tile][N-tile]
-#pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[fi][m][j][r] = 0.f;
-
-  // ---- multiply phase of one chunk: fragments (fi, m), read fp32, split, 12 MFMAs ----------
-  const int a_sw = (l31 >> 2) & 3;
-  const int a_off0 = l31 * 16 + (((lhi * 2) ^ a_sw) << 2), a_off1 = l31 * 16 + (((lhi * 2 + 1) ^ a_sw) << 2);
-  auto multiply = [&](const float* Vc, float* Vn, int c, bool more) {
-    f32x4 ar[2][2];
-    auto lda = [&](int s, f32x4 (&q)[2]) {
-      const float* rowp = Vc + ((2 * wave + (s >> 1)) * 64 + (s & 1) * 32) * 16;
-      q[0] = *reinterpret_cast<const f32x4*>(rowp + a_off0);
-      q[1] = *reinterpret_cast<const f32x4*>(rowp + a_off1);
-    };
-    lda(0, ar[0]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int fi = s >> 1, m = s & 1;
-      if (s == 0) load_b(c, 1, 1);
-      else if (s == 2 && more) load_b(c + 1, 0, 0);
-      if (s + 1 < 4) lda(s + 1, ar[(s + 1) & 1]);
-      bf16x4 h[2], md[2], lo[2];
-      split3(ar[s & 1][0], h[0], md[0], lo[0]);
-      split3(ar[s & 1][1], h[1], md[1], lo[1]);
-      const bf16x8 a1 = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
-      const bf16x8 a2 = __builtin_shufflevector(md[0], md[1], 0, 1, 2, 3, 4, 5, 6, 7);
-      const bf16x8 a3 = __builtin_shufflevector(lo[0], lo[1], 0, 1, 2, 3, 4, 5, 6, 7);
-      // patch values of transform part s: in flight behind this step's MFMAs (the patch is
-      // visible from the barrier of step 0 on; reading it in the last chunk is harmless)
-      if (s > 0) t_load(s);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bw[fi][j][0]);
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bw[fi][j][1]);
-        const bf16x8 b3 = __builtin_bit_cast(bf16x8, bw[fi][j][2]);
-        f32x16 t = acc[fi][m][j];
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, t, 0, 0, 0);
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, t, 0, 0, 0);
-        acc[fi][m][j] = t;
-      }
-      // the patch of chunk c+1 was rewritten right after the previous barrier: every wave is
-      // long past that by now, and this step's MFMAs keep the pipe busy while the barrier fills
-      if (s == 0) { __syncthreads(); t_load(0); }
-      if (more) t_emit(s, Vn);
-    }
-  };
-
-  const int nchunks = k.nchunks;
-  // phase timestamps of one block (diagnostics: p2l_wino_set_trace)
-  unsigned long long* trace =
-      (k.ws != nullptr && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
-#define P2L_TR(SLOT, C)                                                                      \
-  if (trace != nullptr && lane == 0 && (C) < 64) trace[(wave * 64 + (C)) * 8 + (SLOT)] = __builtin_amdgcn_s_memtime()
-  load_raw(0);
-  load_b(0, 0, 0);
-  write_raw();
-  __syncthreads();
-  if (nchunks > 1) load_raw(1);
-  transform(Vs);
-  __syncthreads();
-  if (nchunks > 1) { write_raw(); if (nchunks > 2) load_raw(2); }
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
-    float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
-    P2L_TR(0, c);
-    multiply(Vc, Vn, c, more);
-    P2L_TR(2, c);
-    __syncthreads();                    // V(c+1) complete; every read of V(c) and of the patch done
-    P2L_TR(3, c);
-    if (c + 2 < nchunks) {
-      write_raw();                      // (made visible by the barrier inside the next chunk)
-      if (c + 3 < nchunks) load_raw(c + 3);
-    }
-    P2L_TR(4, c);
-  }
-  P2L_TR(5, 0);
-#undef P2L_TR
-
-  // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..63][32 channels] ----------
-  float* dump = Vs;
-  const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
-  const int ety = e_t >> 3, etx = e_t & 7;
-  float* red = raw;                                      // [2 kinds][8 waves][32]
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          dump[((2 * wave + fi) * 64 + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
-        }
-    __syncthreads();
-    const int nb = n0 + j * 32;
-    EpiSums S;
-    if (nb + e_c4 * 4 < k.n_store) {
-      f32x4 T[2][4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {                  // A^T M, column jj
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        T[0][jj] = (m0 + m1) + m2;
-        T[1][jj] = (m1 - m2) - m3;
-      }
-      f32x4 v[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {                     // (A^T M) A
-        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
-        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
-      }
-      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
-    }
-    if (k.arb_x != nullptr) {
-      // waves 0-3 hold the upper 8x16-pixel tile of the caller's 128-pixel tiling, waves 4-7 the
-      // lower one: same shuffle / wave order as epi_arb_reduce (bit-identical partial sums)
-      f32x4 sgx = S.sgx, sg = S.sg;
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-        sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
-        sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
-        sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
-        sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
-      }
-      if (lane < 8) {
-        *reinterpret_cast<f32x4*>(red + wave * 32 + lane * 4) = sgx;
-        *reinterpret_cast<f32x4*>(red + 256 + wave * 32 + lane * 4) = sg;
-      }
-      __syncthreads();
-      if (tid < 64 && nb + (tid & 31) < k.n_store) {
-        const int g = tid >> 5, col = tid & 31;
-        const float* r0 = red + g * 128 + col;
-        const float s0 = (r0[0] + r0[32]) + (r0[64] + r0[96]);
-        const float s1 = (r0[256] + r0[288]) + (r0[320] + r0[352]);
-        const size_t slot = (size_t)b * k.arb_nblk + (size_t)(2 * by + g) * k.tiles_x + bx;
-        const size_t o = slot * k.Cout + nb + col;
-        k.arb_partial[o] = s0;
-        k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
-      }
-    }
-    __syncthreads();                                   // dump / red are rewritten by the next pass
-  }
-}
-
 // ---- 16x16-pixel blocks, hand-scheduled multiply phase ------------------------------------
-// wino16_conv_kernel above leaves the instruction order of a multiply step to hipcc, which emits
-// [read fragment | 36 VALU of the 3-way split | 12 MFMAs back to back].  The two waves of a SIMD
-// leave every barrier in phase, so they split at the same time (sharing the VALU issue) and then
-// queue their MFMAs at the same time: matrix pipe and VALU never overlap (PMC: MFMA pipe 34 %
-// busy, 43 % of wave cycles waiting to issue).  This form fixes the order by hand
-// (sched_barrier between every MFMA and the <= 5 other instructions that follow it):
+// Left to hipcc, a multiply step comes out as [read fragment | 36 VALU of the 3-way split | 12
+// MFMAs back to back] (round 2: MFMA pipe 34 % busy, 43 % of wave cycles waiting to issue): the
+// two waves of a SIMD leave every barrier in phase, split at the same time and then queue their
+// MFMAs at the same time.  What the SIMD can overlap was measured (tools/micro/issue_rate.hip):
+// up to 4 plain VALU instructions per MFMA and wave are free, v_cvt_pk_bf16_f32 is half rate,
+// and a packed fp32 add holds the matrix pipe for ~10 cycles.  So the order is fixed by hand
+// (sched_barrier between every MFMA and the few other instructions that follow it), the TU is
+// built without packed fp32 instructions, and:
 //   * the products of a fragment are taken LARGEST PIECE FIRST: h b1, h b2, h b3, m b1, m b2,
 //     l b1 -- the h pieces are four v_cvt_pk away from the fp32 values, so the first MFMA of a
 //     step issues almost at once and the m / l pieces are computed in the gaps behind the MFMAs
@@ -602,7 +318,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16_conv_kernel(const ConvK
 //   * the h pieces of the NEXT fragment, the input transform of the next chunk, the patch
 //     write and every load sit in the remaining gaps of the step; nothing but the fragment
 //     read + 4 conversions at the top of a chunk is outside an MFMA shadow.
-// Barriers, LDS layout, weight stream and epilogue are those of wino16_conv_kernel.
+// Chunk period 6 500 -> 4 950 cycles (3 072 of MFMA work per SIMD); tools/micro/conv_lab.cpp.
 // Transform micro-operation of MFMA gap G = 12 * step + gap of a chunk: part * 8 + op, or -1.
 // Usable gaps: 0-8 and 10 of every step, from gap 8 of step 0 (the patch barrier) on.  Per part:
 // request | (wait) | rows + request | (wait) | rows | columns (1 output for even parts, 3 for odd).
@@ -628,9 +344,7 @@ constexpr TxTable kTx{};
 // ABL (lab builds only, -DP2L_LAB): timing ablations -- results are wrong when set.
 //   1 weights loaded once | 2 no input transform | 4 no barriers in the loop | 8 no m / l pieces
 //   16 no MFMAs | 32 fragment values read once | 64 no patch loads / writes
-// VAR (lab): 1 waves 4-7 at priority 1 | 2 priority handed from the older to the younger half in
-// the middle of a chunk | 4 scalar subtractions instead of v_pk_add_f32 neg
-template <int PRO, int ABL = 0, int VAR = 0>
+template <int PRO, int ABL = 0>
 __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;
@@ -788,11 +502,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     rr[0] = f32x2{q0.x, q0.y}; rr[1] = f32x2{q0.z, q0.w};
     rr[2] = f32x2{q1.x, q1.y}; rr[3] = f32x2{q1.z, q1.w};
   };
-  auto resid = [&](const f32x2 v, const bf16x2 piece) {
-    const f32x2 w = widen2(piece);
-    if (VAR & 4) return f32x2{v.x - w.x, v.y - w.y};
-    return pk_sub(v, w);
-  };
+  auto resid = [&](const f32x2 v, const bf16x2 piece) { return pk_sub(v, widen2(piece)); };
   auto hstage = [&]() {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -920,7 +630,6 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   __syncthreads();
   using T_ = std::true_type; using F_ = std::false_type;
   if (ABL & 1) load_b(0, 1, 1);
-  if ((VAR & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int c = 0; c + 1 < nchunks; ++c) {
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
@@ -929,10 +638,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     P2L_SB();
     step(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
     step(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
-    if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(2);
     step(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
     step(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
-    if ((VAR & 2) && wave >= 4) __builtin_amdgcn_s_setprio(0);
     if (!(ABL & 4)) __syncthreads();    // V(c+1) complete; every read of V(c) and of the patch done
     P2L_TR(5, c);
   }
@@ -1084,69 +791,26 @@ int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int t
   return p2l_check_launch();
 }
 
-static int g_wino16_mode = -1;       // $P2L_WINO16: 0 = never, 1 = by grid size, 2 = whenever the shape allows
-static int wino16_mode() {
-  if (g_wino16_mode < 0) { const char* e = getenv("P2L_WINO16"); g_wino16_mode = e ? atoi(e) : 1; }
-  return g_wino16_mode;
-}
-static void* g_wino_trace = nullptr;
-int g_wino16_min_blocks = 0;
-int g_wino16_sched = 1;          // lab switch: hand-scheduled multiply phase
-#ifdef P2L_LAB
-static int g_lab_abl = 0;
-extern "C" int p2l_lab_set(int abl, void* trace) { g_lab_abl = abl; g_wino_trace = trace; return P2L_OK; }
-#endif
-// diagnostics: device buffer of 8 waves x 64 chunks x 8 uint64 that ONE block of every following
-// 16x16-pixel launch fills with s_memtime stamps of its phase boundaries (nullptr = off)
-extern "C" int p2l_wino_set_trace(void* buf) {
-  g_wino_trace = buf;
-  return P2L_OK;
-}
-extern "C" int p2l_set_wino_block(int mode) {
-  // (+4: the compiler-scheduled 16x16 kernel -- measurement only, tools/micro/conv_lab.cpp)
-  g_wino16_sched = (mode & 4) ? 0 : 1;
-  mode &= 3;
-  if (mode < 0 || mode > 2) return P2L_EINVAL;
-  g_wino16_mode = mode;
-  return P2L_OK;
-}
-
 // k arrives with the 8x16-pixel tiling (tiles_x = W/16, tiles_y = H/8, n_mtiles, n_ntiles =
-// Cout/64).  Layers whose 16x16-pixel grid still fills the chip run the 8-wave kernel; both
-// give bit-identical results.
+// Cout/64).  16x16-pixel blocks whenever H and W allow it (measured in the bench step at 18, 9,
+// 5, 3, 2 candidates per GPU: tools/policy_probe.py), the 8x16-pixel kernel otherwise or on
+// P2L_FORM_WINO_8X16; both give bit-identical results.
+#ifdef P2L_LAB
+// lab build (tools/micro/build_lab.sh): timing ablations and the phase trace of one block
+static int g_lab_abl = 0;
+static void* g_lab_trace = nullptr;
+extern "C" int p2l_lab_set(int abl, void* trace) { g_lab_abl = abl; g_lab_trace = trace; return P2L_OK; }
+#endif
+
 int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   ConvK k = k_in;
-  { const char* e = getenv("P2L_ABL"); k.abl = e ? atoi(e) : 0; }
-  const int mode = wino16_mode();
-  const long blocks16 = (long)k.B * (k.H / 16) * (k.W / 16) * k.n_ntiles;
-  // (in the bench step the 8-wave kernel is 1.03-1.10x on the layers with >= 128 input channels
-  //  and 0.93-0.98x on the 64-channel ones: its longer prologue against only 4 chunks)
-  if (mode && k.H % 16 == 0 && k.W % 16 == 0 && (mode == 2 || blocks16 >= g_wino16_min_blocks)) {
+  if (k.H % 16 == 0 && k.W % 16 == 0 && !(k.form & P2L_FORM_WINO_8X16)) {
     k.tiles_y = k.H / 16;
     k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
-    k.ws = (float*)g_wino_trace;
+    k.ws = nullptr;
     dim3 grid(k.n_mtiles * k.n_ntiles), block(W16_THREADS);
-#define P2L_W16(PRO)                                                                         \
-  do {                                                                                       \
-    static bool attr_set = false;                                                            \
-    if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)wino16_conv_kernel<PRO>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      attr_set = true;                                                                       \
-    }                                                                                        \
-    hipLaunchKernelGGL(wino16_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);          \
-  } while (0)
-#define P2L_W16S(PRO)                                                                        \
-  do {                                                                                       \
-    static bool attr_set = false;                                                            \
-    if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO>,                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-      attr_set = true;                                                                       \
-    }                                                                                        \
-    hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
-  } while (0)
 #ifdef P2L_LAB
+    k.ws = (float*)g_lab_trace;
 #define P2L_W16L(ABL)                                                                        \
   case ABL: {                                                                                \
     (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, ABL>,           \
@@ -1154,44 +818,35 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL>), grid, block, W16_LDS_BYTES, st, k); \
     return p2l_check_launch();                                                               \
   }
-    if (g_wino16_sched && pro == P2L_PRO_NONE) {
+    if (pro == P2L_PRO_NONE) {
       switch (g_lab_abl) {
         P2L_W16L(0) P2L_W16L(1) P2L_W16L(2) P2L_W16L(4) P2L_W16L(8) P2L_W16L(16) P2L_W16L(64)
         P2L_W16L(3) P2L_W16L(10) P2L_W16L(67) P2L_W16L(75) P2L_W16L(79) P2L_W16L(111)
-        default: break;
-      }
-#define P2L_W16V(VAR)                                                                        \
-  case 1000 + VAR: {                                                                         \
-    (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, 0, VAR>,        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
-    hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, 0, VAR>), grid, block, W16_LDS_BYTES, st, k); \
-    return p2l_check_launch();                                                               \
-  }
-      switch (g_lab_abl) {
-        P2L_W16V(1) P2L_W16V(2) P2L_W16V(4) P2L_W16V(5) P2L_W16V(6)
         default: return P2L_EINVAL;
       }
-#undef P2L_W16V
     }
 #undef P2L_W16L
 #endif
-    if (g_wino16_sched) {
-      if (pro == P2L_PRO_NONE) P2L_W16S(P2L_PRO_NONE);
-      else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16S(P2L_PRO_AFFINE_RELU);
-      else P2L_W16S(P2L_PRO_AFFINE);
-      return p2l_check_launch();
-    }
+#define P2L_W16S(PRO)                                                                        \
+  do {                                                                                       \
+    static std::atomic<bool> attr_set{false};                                                \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
+  } while (0)
+    if (pro == P2L_PRO_NONE) P2L_W16S(P2L_PRO_NONE);
+    else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16S(P2L_PRO_AFFINE_RELU);
+    else P2L_W16S(P2L_PRO_AFFINE);
 #undef P2L_W16S
-    if (pro == P2L_PRO_NONE) P2L_W16(P2L_PRO_NONE);
-    else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16(P2L_PRO_AFFINE_RELU);
-    else P2L_W16(P2L_PRO_AFFINE);
-#undef P2L_W16
     return p2l_check_launch();
   }
   dim3 grid(k.n_mtiles * k.n_ntiles), block(WN_THREADS);
 #define P2L_WN(PRO)                                                                          \
   do {                                                                                       \
-    static bool attr_set = false;                                                            \
+    static std::atomic<bool> attr_set{false};                                                \
     if (!attr_set) {                                                                         \
       (void)hipFuncSetAttribute((const void*)wino_conv_kernel<PRO>,                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \

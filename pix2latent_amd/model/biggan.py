@@ -124,7 +124,8 @@ class BigGAN(nn.Module):
         # conv_to_rgb and its input gradient: three real channels on one side (csrc/p2l_thin.hip)
         self._thin = N.default_thin() and self._wfmt != N.WFMT_F32
         self._desc.wfmt = (self._wfmt | (N.WFMT_FLAG_PW if self._pw else 0) |
-                           (N.WFMT_FLAG_THIN if self._thin else 0))
+                           (N.WFMT_FLAG_THIN if self._thin else 0) |
+                           (N.WFMT_FLAG_ATTN_GEMM if N.default_attn_gemm() else 0))
         self._ws = None
         self._ws_B = -1
         self._ticket = 0

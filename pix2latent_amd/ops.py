@@ -32,12 +32,19 @@ def pack_conv_weight_subpix(w_oihw, n_pad, k_pad, flip=False, mode=0, wfmt=N.WFM
     return N.pack_conv_weight(w_oihw, 9, n_pad, k_pad, flip, wfmt, subpix_mode=mode)
 
 
+# P2LConv.form of launches that do not say otherwise (N.FORM_*): a PYTHON-side default for tests
+# and tools; the native library takes the form per call and has no switch of its own
+DEFAULT_FORM = N.FORM_AUTO
+
+
 def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s=None,
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
-         splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0, wfmt=N.WFMT_F32):
+         splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0, wfmt=N.WFMT_F32,
+         form=None):
     d = N.P2LConv()
     d.wfmt = wfmt
+    d.form = DEFAULT_FORM if form is None else form
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.ups = int(ups)
     d.x_ld = x_ld if x_ld is not None else Cin
@@ -244,7 +251,7 @@ def lpips_tap_bwd(f, nft, lin, wt, gscale):
 
 def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride, pool_sum=False,
                    skip=None, skip_C=0, skip_ups=False, subpix=False, wfmt=N.WFMT_F32, splitk=1,
-                   keep=None):
+                   keep=None, form=None):
     """fused input-gradient conv + backward of relu(x*s+t) (p2l_conv_dgrad_arb);
     H, W = resolution of dy; Cin = channels of dy, Cout = channels of x.
     splitk > 1: the split-K form, activation backward in the finish kernel
@@ -252,6 +259,7 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
     alive until p2l_arb_defer_flush when the finish is deferred)."""
     d = N.P2LConv()
     d.wfmt = wfmt
+    d.form = DEFAULT_FORM if form is None else form
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = B, H, W, Cin, Cout, taps
     d.x_ld = Cin
     d.alpha = 1.0

@@ -47,7 +47,7 @@ def test_version_and_errors(lib):
 def test_struct_layouts_match_c(lib):
     """sizes implied by include/p2l.h on LP64"""
     from pix2latent_amd import _native as N
-    assert C.sizeof(N.P2LConv) == 22 * 4 + 8
+    assert C.sizeof(N.P2LConv) == 23 * 4 + 4 + 8          # (+ form; padded to the double)
     assert C.sizeof(N.P2LGemm) == 7 * 4 + 4 + 3 * 8 + 4 * 4
     assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 14 * 8
     assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8 + 8
@@ -92,6 +92,26 @@ def test_product_path_fails_loudly_without_gpu():
     from pix2latent_amd.model.stylegan2 import StyleGAN2
     with pytest.raises(N.NativeError, match='no CPU fallback'):
         StyleGAN2(weights={}, size=64, device='cpu')
+
+
+def test_library_has_no_switches_of_its_own():
+    """re-entrant, no global mutable state.  Kernel-form choices travel per call
+    (P2LConv.form, model descriptor flags), environment variables are read in Python only, the
+    deferred-reduction / last-error state is per host thread, and the one process-wide object --
+    the opt-in launch profiler, which must also see the launches of torch's autograd thread --
+    sits behind a mutex (p2l_conv.hip prof())."""
+    csrc = os.path.join(ROOT, 'pix2latent_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(('.hip', '.cpp', '.h')):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        src = re.sub(r'#ifdef P2L_LAB.*?#endif', '', src, flags=re.S)      # measurement build only
+        assert 'getenv' not in src, f
+        # namespace-scope definitions of g_* variables (declarations start in column 0)
+        for m in re.finditer(r'^[A-Za-z_][A-Za-z0-9_:<>\s]*?\bg_[a-z0-9_]+\s*(=|;|\{)', src, flags=re.M):
+            assert 'thread_local' in m.group(0), '%s: %s' % (f, m.group(0))
+    hdr = open(os.path.join(ROOT, 'include', 'p2l.h')).read()
+    assert 'p2l_set_' not in hdr
 
 
 def test_oracle_not_imported_by_product():

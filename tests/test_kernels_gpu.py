@@ -1,6 +1,7 @@
 """Per-kernel parity: every HIP kernel of libp2l_hip against plain PyTorch-CPU
 fp32 ops (the oracle's building blocks) on seeded inputs.  Tolerances are
 fp32-summation-order level and written per test."""
+import ctypes as C
 import math
 
 import pytest
@@ -93,22 +94,21 @@ def _skip_unless_format_applies(wfmt, taps, H=None, ups=False):
 def _fmt(wfmt):
     """test id 4 -> the real weight format (2) with the 16x16-pixel block shape forced"""
     if wfmt == 4:
-        from pix2latent_amd import _native as N
-        N.check(N.lib().p2l_set_wino_block(2))
+        from pix2latent_amd import _native as N, ops as O
+        O.DEFAULT_FORM = N.FORM_WINO_ANY
         return 2
     return wfmt
 
 
 @pytest.fixture(autouse=True)
 def _force_winograd_for_small_grids(dev):
-    """the default only sends launches with >= 224 blocks to the Winograd kernel; the test
-    shapes are small, so force it for every eligible shape and restore the default after"""
-    from pix2latent_amd import _native as N
-    N.check(N.lib().p2l_set_wino_mode(2))
-    N.check(N.lib().p2l_set_wino_block(0))
+    """the default only sends layers with >= 64 blocks per image to the Winograd kernel; the test
+    shapes are small, so ask for it on every eligible shape (P2LConv.form, per launch: the
+    8x16-pixel kernel here, the 16x16-pixel one under format id 4) and restore the default"""
+    from pix2latent_amd import _native as N, ops as O
+    O.DEFAULT_FORM = N.FORM_WINO_ANY | N.FORM_WINO_8X16
     yield
-    N.check(N.lib().p2l_set_wino_mode(1))
-    N.check(N.lib().p2l_set_wino_block(1))
+    O.DEFAULT_FORM = N.FORM_AUTO
 
 
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
@@ -334,6 +334,57 @@ def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip, C, Co):
     assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
+def test_two_host_threads_two_streams_bit_identical(dev, O):
+    """the library is re-entrant.  Two host threads drive the same conv layers (direct,
+    Winograd 8x16 / 16x16, pointwise: the form travels in P2LConv) on two streams at the same time,
+    with the (process-wide, mutex-guarded, opt-in) launch profiler running; every result equals
+    the single-threaded one bit for bit and every launch of both threads got its own slot."""
+    import threading
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(77)
+    B, H = 4, 32
+    cases = []
+    for Cin, Cout, taps, wf, form in ((64, 128, 9, 1, 0), (64, 128, 9, 2, N.FORM_WINO_ANY | N.FORM_WINO_8X16),
+                                      (64, 128, 9, 2, N.FORM_WINO_ANY), (128, 64, 1, 3, 0)):
+        k = 3 if taps == 9 else 1
+        x = torch.randn(B, H, H, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(k * k * Cin)).to(dev)
+        cases.append((x, O.pack_conv_weight(w, taps, Cout, Cin, wfmt=wf), Cin, Cout, taps, wf, form))
+
+    def run_all(reps):
+        outs = []
+        for _ in range(reps):
+            outs = [O.conv(x, wp, B, H, H, Cin, Cout, taps, wfmt=wf, form=form)[0]
+                    for x, wp, Cin, Cout, taps, wf, form in cases]
+        return outs
+    ref = [y.clone() for y in run_all(1)]
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(name):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                outs = run_all(20)
+                st.synchronize()
+            results[name] = [y.clone() for y in outs]
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+    N.check(N.lib().p2l_prof_begin(512), 'prof_begin')
+    th = [threading.Thread(target=worker, args=('a',)), threading.Thread(target=worker, args=('b',))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    f, m, c = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
+    N.check(N.lib().p2l_prof_end(f, m, c), 'prof_end')
+    assert not errors, errors
+    assert c[0] + c[1] == 2 * 20 * len(cases)
+    for name in ('a', 'b'):
+        for y, r in zip(results[name], ref):
+            assert torch.equal(y, r)
+
+
 @pytest.mark.parametrize('arb', [False, True], ids=['forward', 'dgrad-fused-arb'])
 def test_winograd_block_shapes_bit_identical(dev, O, arb):
     """the 8x16-pixel / 4-wave and the 16x16-pixel / 8-wave Winograd kernels do the same
@@ -350,8 +401,8 @@ def test_winograd_block_shapes_bit_identical(dev, O, arb):
     bias = (0.1 * torch.randn(Cout, generator=g)).to(dev)
     res = torch.randn(B, H, H, Cout, generator=g).to(dev)
     xa = torch.randn(B, H, H, Cout, generator=g).to(dev)
-    for block in (0, 2):
-        N.check(N.lib().p2l_set_wino_block(block))
+    for form in (N.FORM_WINO_ANY | N.FORM_WINO_8X16, N.FORM_WINO_ANY):
+        O.DEFAULT_FORM = form
         if not arb:
             wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=2)
             y, _ = O.conv(x, wp, B, H, H, Cin, Cout, 9, wfmt=2, bias=bias, pro=N.PRO_AFFINE_RELU,

@@ -16,8 +16,9 @@ for B, H, Cin, Cout in CASES:
     s = (0.5 + torch.rand(B, Cin, generator=g)).to(dev)
     t = (0.3 * torch.randn(B, Cin, generator=g)).to(dev)
     res = {}
-    for name, wf, blk in (('f32', 0, 1), ('bf16x3', 1, 1), ('wino', 2, 0), ('wino16', 2, 2)):
-        N.check(N.lib().p2l_set_wino_block(blk))
+    for name, wf, form in (('f32', 0, 0), ('bf16x3', 1, 0), ('wino', 2, N.FORM_WINO_ANY | N.FORM_WINO_8X16),
+                           ('wino16', 2, N.FORM_WINO_ANY)):
+        O.DEFAULT_FORM = form
         wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=wf)
         for _ in range(3):
             y, _ = O.conv(x, wp, B, H, H, Cin, Cout, 9, pro=N.PRO_AFFINE_RELU, pro_s=s, pro_t=t,

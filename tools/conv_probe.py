@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pix2latent_amd import ops, _native as N
 dev = torch.device('cuda'); B = 18
 SH = [(256, 64, 64, 9), (64, 256, 256, 9), (32, 512, 512, 9)]
-for WF, BLK in ((1, 1), (2, 0), (2, 2)):
-  N.check(N.lib().p2l_set_wino_block(BLK))
+for WF, FORM in ((1, 0), (2, N.FORM_WINO_ANY | N.FORM_WINO_8X16), (2, N.FORM_WINO_ANY)):
+  ops.DEFAULT_FORM = FORM
   for H, Cin, Cout, taps in SH:
       k = 3 if taps == 9 else 1
       x = torch.randn(B, H, H, Cin, device=dev)

@@ -56,7 +56,7 @@ if not os.path.exists(cache):
         res['dz' + tag], res['dc' + tag] = zr.grad, cr.grad
     torch.save(res, cache)
 for name, env in (('default', {}), ('P2L_CONV_WFMT=f32', {'P2L_CONV_WFMT': 'f32'}), ('P2L_ATTN=0', {'P2L_ATTN': '0'}),
-                  ('P2L_PW=0', {'P2L_PW': '0'}), ('P2L_THIN=0', {'P2L_THIN': '0'}), ('P2L_WINO=0', {'P2L_WINO': '0'}),
-                  ('all bf16x3 forms off', {'P2L_ATTN': '0', 'P2L_PW': '0', 'P2L_THIN': '0', 'P2L_WINO': '0'})):
+                  ('P2L_PW=0', {'P2L_PW': '0'}), ('P2L_THIN=0', {'P2L_THIN': '0'}), ('direct 3x3 kernels', {'P2L_CONV_WFMT': 'bf16x3-direct'}),
+                  ('all bf16x3 forms off', {'P2L_ATTN': '0', 'P2L_PW': '0', 'P2L_THIN': '0', 'P2L_CONV_WFMT': 'bf16x3-direct'})):
     e = dict(os.environ); e.update(env)
     subprocess.call([sys.executable, os.path.abspath(__file__), 'native', name], env=e)

@@ -19,7 +19,7 @@ static unsigned long long rng = 88172645463325252ull;
 static float urand() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)((rng >> 11) * (1.0 / 9007199254740992.0)); }
 static float nrand() { float u = urand() + 1e-12f, v = urand(); return sqrtf(-2.f * logf(u)) * cosf(6.2831853f * v); }
 
-struct Form { const char* name; int wfmt; int wino_mode; int block; };
+struct Form { const char* name; int wfmt; int form; };
 
 #ifdef P2L_LAB
 extern "C" int p2l_lab_set(int abl, void* trace);
@@ -39,17 +39,15 @@ static int lab_main(int B) {
   CK(hipMemcpy(dwo, hw.data(), nw * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dwp, p2l_packed_weight_floats(9, Cout, Cin, P2L_WFMT_BF16X3W) * 4));
   PK(p2l_pack_conv_weight_bf3w(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
-  PK(p2l_set_wino_mode(2)); PK(p2l_set_wino_block(2));
   P2LConv d; memset(&d, 0, sizeof d);
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = P2L_PRO_NONE;
-  d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = P2L_WFMT_BF16X3W;
+  d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = P2L_WFMT_BF16X3W; d.form = P2L_FORM_WINO_ANY;
   const struct { int abl; const char* what; } A[] = {
       {0, "full"}, {1, "weights once"}, {2, "no transform"}, {4, "no barriers"}, {8, "no m/l pieces"},
       {16, "no MFMAs"}, {64, "no patch traffic"}, {3, "weights once, no transform"},
       {10, "no transform, no m/l"}, {67, "no weights/transform/patch"},
       {75, "no weights/transform/patch/ml"}, {79, "... and no barriers"}, {111, "MFMAs + epilogue only"},
-      {0, "full (again)"}, {1001, "VAR 1: waves 4-7 prio 1"}, {1002, "VAR 2: prio handed over mid-chunk"},
-      {1004, "VAR 4: scalar subtractions"}, {1005, "VAR 1+4"}, {1006, "VAR 2+4"}};
+      {0, "full (again)"}};
   // the clocks of an idle GPU take tens of milliseconds to settle: warm up, then two passes
   PK(p2l_lab_set(0, nullptr));
   for (int i = 0; i < 400; ++i)
@@ -167,8 +165,8 @@ int main(int argc, char** argv) {
   const int pro = argc > 2 ? atoi(argv[2]) : P2L_PRO_NONE;
   struct { int H, Cin, Cout; } layers[] = {{64, 256, 256}, {32, 512, 512}, {128, 128, 128}, {256, 64, 64},
                                           {32, 256, 256}, {16, 512, 512}};
-  const Form forms[] = {{"direct", P2L_WFMT_BF16X3, 0, 0}, {"wino8", P2L_WFMT_BF16X3W, 2, 0},
-                        {"wino16-cc", P2L_WFMT_BF16X3W, 2, 2 | 4}, {"wino16-hand", P2L_WFMT_BF16X3W, 2, 2}};
+  const Form forms[] = {{"direct", P2L_WFMT_BF16X3, 0}, {"wino8", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY | P2L_FORM_WINO_8X16},
+                        {"wino16", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY}};
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto L : layers) {
@@ -195,12 +193,10 @@ int main(int argc, char** argv) {
       float* dwp; CK(hipMalloc(&dwp, wf * 4));
       if (f.wfmt == P2L_WFMT_BF16X3W) PK(p2l_pack_conv_weight_bf3w(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
       else PK(p2l_pack_conv_weight_bf3(dwo, Cout, Cin, 9, Cout, Cin, 0, dwp, st));
-      PK(p2l_set_wino_mode(f.wino_mode));
-      PK(p2l_set_wino_block(f.block));
       P2LConv d; memset(&d, 0, sizeof d);
       d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = pro;
       d.pro_bstride = Cin; d.alpha = 1.f; d.act = P2L_ACT_NONE; d.pool = P2L_POOL_NONE; d.y_ld = Cout;
-      d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt;
+      d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt; d.form = f.form;
       CK(hipMemsetAsync(dy, 0xff, ny * 4, st));
       for (int i = 0; i < (pass == 0 && &f == &forms[0] ? 300 : 5); ++i)   // (idle clocks settle first)
         PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));

@@ -1,6 +1,6 @@
 """Per-launch table of the conv kernel inside one BasinCMA inner step (BigGAN-256, pop 18):
 shape, time, algorithmic TFLOP/s and GB/s per launch, grouped by layer shape.
-Uses the library's own hipEvent profiler (P2L_PROF_DUMP)."""
+Uses the library's own hipEvent profiler (p2l_prof_dump)."""
 import collections
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch  # noqa: E402
 
-DUMP = os.environ.setdefault('P2L_PROF_DUMP', '/tmp/p2l_layers.txt')
+DUMP = os.environ.get('P2L_PROF_DUMP', '/tmp/p2l_layers.txt')
 
 
 def main():
@@ -41,6 +41,7 @@ def main():
     torch.cuda.synchronize()
     lib = N.lib()
     N.check(lib.p2l_prof_begin(4096), 'prof_begin')
+    N.check(lib.p2l_prof_dump(DUMP.encode()), 'prof_dump')
     steps = 3
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -49,6 +50,7 @@ def main():
     step_ms = (time.perf_counter() - t0) / steps * 1e3
     f, m, c, b = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)()
     N.check(lib.p2l_prof_end2(f, m, c, b), 'prof_end2')
+    lib.p2l_prof_dump(None)
     rows = collections.OrderedDict()
     for line in open(DUMP):
         v = line.split()
