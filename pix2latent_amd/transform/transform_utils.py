@@ -13,43 +13,47 @@ import torch
 from ..utils.image import binarize
 
 
-def compute_pre_alignment(weight):
-    """ Precompute initialization based on BigGAN bias """
-    dst_center, dst_size = get_biggan_stats()
-    src_center, src_size = compute_stat_from_mask(binarize(weight))
-    t = convert_to_t(src_center, src_size, dst_center, dst_size)
-    return t.numpy()
-
-
-def convert_to_t(src_center, src_size, dst_center, dst_size):
-    """ transformation parameter that moves the object (center, size) onto the
-    destination (center, size); scale follows the larger object side """
-    src_center, src_size = np.array(src_center), np.array(src_size)
-    dst_center, dst_size = np.array(dst_center), np.array(dst_size)
-
-    scale_idx = np.argmax(src_size).squeeze()
-    s = (src_size / dst_size)[scale_idx]
-    dxy = (src_center - dst_center) * 2.
-    t = np.array([s, *dxy[::-1]])
-    return torch.from_numpy(t).float()
+# Where BigGAN puts its objects, as fractions of the image side (the constants of the reference's
+# get_biggan_stats, transform_utils.py:87-91): centre of mass (row, column) and extent (rows, columns).
+_BIGGAN_OBJECT = {'center': (137 / 255., 127 / 255.), 'size': (213 / 255., 210 / 255.)}
 
 
 def get_biggan_stats():
-    """ precomputed biggan statistics """
-    center_of_mass = [137 / 255., 127 / 255.]
-    object_size = [213 / 255., 210 / 255.]
-    return center_of_mass, object_size
+    """(centre, size) of the typical BigGAN object, each as (row, column) image fractions"""
+    return list(_BIGGAN_OBJECT['center']), list(_BIGGAN_OBJECT['size'])
 
 
 def compute_stat_from_mask(mask):
-    """ Given a binarized mask 0, 1. Compute the object size and center """
-    st_h, st_w, en_h, en_w = bbox_from_mask(mask)
-    obj_size = obj_h, obj_w = en_h - st_h, en_w - st_w
-    obj_center = (st_h + obj_h // 2, st_w + obj_w // 2)
+    """(centre, size) of the bounding box of a binarised [C,H,W] mask, as (row, column) fractions
+    of the image.  The centre is the box corner plus the INTEGER half extent (what the reference
+    computes, transform_utils.py:94-102: an odd box rounds towards the corner)."""
+    top, left, bottom, right = bbox_from_mask(mask)
+    extent = (bottom - top, right - left)
+    corner = (top, left)
+    side = (mask.size(1), mask.size(2))
+    center = tuple((corner[a] + extent[a] // 2) / side[a] for a in (0, 1))
+    size = tuple(extent[a] / side[a] for a in (0, 1))
+    return center, size
 
-    obj_size = (obj_size[0] / mask.size(1), obj_size[1] / mask.size(2))
-    obj_center = (obj_center[0] / mask.size(1), obj_center[1] / mask.size(2))
-    return obj_center, obj_size
+
+def convert_to_t(src_center, src_size, dst_center, dst_size):
+    """[scale, tx, ty] of the SpatialTransform that carries an object at (src_center, src_size)
+    onto (dst_center, dst_size), all in (row, column) image fractions: the scale is the size
+    ratio along the object's LONGER side, the shift is twice the centre offset (grid coordinates
+    span [-1, 1]) in (x, y) = (column, row) order.  float32 tensor, as the reference returns."""
+    src_center, dst_center = np.asarray(src_center, dtype=np.float64), np.asarray(dst_center, dtype=np.float64)
+    src_size, dst_size = np.asarray(src_size, dtype=np.float64), np.asarray(dst_size, dtype=np.float64)
+    longer = int(np.argmax(src_size))
+    scale = src_size[longer] / dst_size[longer]
+    shift_rc = 2.0 * (src_center - dst_center)
+    return torch.tensor([scale, shift_rc[1], shift_rc[0]], dtype=torch.float64).float()
+
+
+def compute_pre_alignment(weight):
+    """initial [scale, tx, ty] from a weight mask: the mask's object box mapped onto the place
+    where BigGAN draws objects (reference transform_utils.py:53-58); numpy float32"""
+    center, size = compute_stat_from_mask(binarize(weight))
+    return convert_to_t(center, size, *get_biggan_stats()).numpy()
 
 
 def bbox_from_mask(mask):
