@@ -6,14 +6,18 @@ API kept from reference pix2latent/optimizer/base_cma_optimizer.py: the `CMA` fa
 `setup_cma / cma_init / cma_update` with attributes `num_samples`, `cma_optimizers`
 (:28-141).  The implementation is a `PopulationSampler` strategy (search_loop.py): it owns
 ask, the broadcast of rank 0's ask to the other ranks, and the Baldwinian tell.  The
-evolution strategy itself is optimizer/cma_es.py (pycma is not available; PARITY UNPINNED).
+evolution strategy is the installed `cma` package when it imports -- what the reference
+instantiates, base_cma_optimizer.py:2,176 -- and optimizer/cma_es.py otherwise
+(optimizer/backends.py; PARITY UNPINNED for the fallback).
 """
 import numpy as np
 import torch
 
-from .cma_es import CMAEvolutionStrategy
+from . import backends
 from .search_loop import PopulationSampler, find_grad_free
 from ..utils.misc import cprint
+
+CMAEvolutionStrategy, CMA_BACKEND = backends.cma_strategy()
 
 
 class CMA(object):

@@ -12,9 +12,13 @@ that may straddle the strategy's own generations, and one tell per candidate.
 import numpy as np
 import torch
 
-from . import ng_compat as ng
+from . import backends
 from .search_loop import PopulationSampler, find_grad_free
 from ..utils.misc import cprint
+
+# the installed nevergrad when it imports (what the reference calls, base_ng_optimizer.py:1,81-83),
+# optimizer/ng_compat.py otherwise
+ng, NG_BACKEND, NG_EXTERNAL = backends.nevergrad()
 
 #: methods that evaluate one candidate at a time (not an exhaustive list, as in the reference)
 SEQUENTIAL_METHODS = ('SQPCMA', 'chainCMAPowell', 'Powell')
@@ -24,10 +28,9 @@ class AskTellSampler(PopulationSampler):
 
     def __init__(self, var_type, var_name, method, mu, budget, seed=None):
         PopulationSampler.__init__(self, var_type, var_name)
-        factory = ng.optimizers.registry[method]
         # the reference leaves the mutation sigma at its default of 1 (its set_mutation call
         # is commented out, base_ng_optimizer.py:82)
-        self.opt = factory(parametrization=ng.p.Array(init=mu), budget=budget, seed=seed)
+        self.opt = backends.make_ng_optimizer(ng, NG_EXTERNAL, method, mu, budget, seed=seed)
 
     def _ask(self, n):
         candidates = [self.opt.ask() for _ in range(n)]

@@ -69,7 +69,10 @@ class CMAEvolutionStrategy(object):
             return cma_on * min(1 - c1_of(mueff),
                                 2 * (mueff - 2 + 1 / mueff) / ((N + 2) ** 2 + mueff))
         w, mu, mueff = recombination_weights(lam, N, c1_of, cmu_of, active)
-        cs = (mueff + 2) / (N + mueff + 5)
+        # step-size path constant: pycma's CMAAdaptSigmaCSA uses N + mueff + 3 in the denominator
+        # (cma/sigma_adaptation.py, as recalled; the tutorial's (mueff + 2) / (N + mueff + 5) is
+        # what purecma uses).  The reference runs pycma, so the pycma value it is.
+        cs = (mueff + 2) / (N + mueff + 3)
         self.sp = types.SimpleNamespace(
             popsize=lam, mu=mu, weights=w, mueff=mueff, active=active,
             cc=(4 + mueff / N) / (N + 4 + 2 * mueff / N), cs=cs,

@@ -1,0 +1,79 @@
+"""optimizer/backends.py: the installed `cma` / `nevergrad` packages are preferred (they are what
+the reference instantiates: base_cma_optimizer.py:2,176, base_ng_optimizer.py:1,81-83), the
+in-tree restatements are the fallback.  Both branches, with recording fakes standing in for the
+packages (neither is installed in the build environment)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _toy import FakeCMAES, FakeNGOpt, fake_nevergrad  # noqa: E402
+
+
+@pytest.fixture
+def fresh(monkeypatch):
+    """reload the modules that resolve a backend at import, and put them back afterwards"""
+    names = ['pix2latent_amd.optimizer.backends', 'pix2latent_amd.optimizer.base_cma_optimizer',
+             'pix2latent_amd.optimizer.base_ng_optimizer']
+
+    def reload_all():
+        return [importlib.reload(importlib.import_module(n)) for n in names]
+    yield reload_all
+    monkeypatch.undo()
+    for k in ('cma', 'nevergrad'):
+        sys.modules.pop(k, None) if isinstance(sys.modules.get(k), types.ModuleType) and \
+            getattr(sys.modules.get(k), '_p2l_fake', False) else None
+    reload_all()
+
+
+def _fake_module(name, **attrs):
+    m = types.ModuleType(name)
+    m._p2l_fake = True
+    m.__version__ = '0.0-fake'
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+def test_fallback_when_packages_are_absent(fresh, monkeypatch):
+    for k in ('cma', 'nevergrad'):
+        monkeypatch.setitem(sys.modules, k, None)          # import raises ImportError
+    B, C, G = fresh()
+    from pix2latent_amd.optimizer import cma_es, ng_compat
+    assert C.CMAEvolutionStrategy is cma_es.CMAEvolutionStrategy and 'in-tree' in C.CMA_BACKEND
+    assert G.ng is ng_compat and not G.NG_EXTERNAL
+    es = C.CMA(mu=np.zeros(6), sigma=0.5, seed=3)
+    x = es.ask()
+    assert x.shape == (es.batch_size(), 6)
+    es.tell(x, np.arange(len(x), dtype=np.float64))
+
+
+def test_installed_packages_are_preferred(fresh, monkeypatch):
+    ng = fake_nevergrad()
+    monkeypatch.setitem(sys.modules, 'cma', _fake_module('cma', CMAEvolutionStrategy=FakeCMAES))
+    monkeypatch.setitem(sys.modules, 'nevergrad', _fake_module('nevergrad', optimizers=ng.optimizers, p=ng.p))
+    B, C, G = fresh()
+    assert C.CMAEvolutionStrategy is FakeCMAES and C.CMA_BACKEND.startswith('pycma')
+    assert G.NG_EXTERNAL and G.NG_BACKEND.startswith('nevergrad')
+    # the facade drives the package exactly as the reference does: x0, sigma0, options
+    FakeCMAES.log = []
+    es = C.CMA(mu=np.arange(4.0), sigma=0.7)
+    asked = es.ask()
+    es.tell(asked, np.ones(len(asked)))
+    assert FakeCMAES.log and np.array_equal(FakeCMAES.log[-1][0], asked)
+    # nevergrad proper takes no seed argument: the random state hangs off the parametrisation
+    FakeNGOpt.log, FakeNGOpt.instances = [], []
+    s = G.AskTellSampler('input', 'z', 'CMA', np.zeros(5), budget=12, seed=None)
+    assert FakeNGOpt.instances[-1].budget == 12 and s.opt is FakeNGOpt.instances[-1]
+
+
+def test_environment_forces_the_in_tree_samplers(fresh, monkeypatch):
+    monkeypatch.setitem(sys.modules, 'cma', _fake_module('cma', CMAEvolutionStrategy=FakeCMAES))
+    monkeypatch.setenv('P2L_SAMPLERS', 'intree')
+    B, C, G = fresh()
+    from pix2latent_amd.optimizer import cma_es
+    assert C.CMAEvolutionStrategy is cma_es.CMAEvolutionStrategy
