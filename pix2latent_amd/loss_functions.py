@@ -222,6 +222,7 @@ class _LossEngine(object):
         self.cache = None        # P2LLossCache of the slot bound by the last prepare()
         self._memo = {}
         self._fwd_ticket = 0
+        self.generation = 0
 
     def _alloc(self, B, H, W, dev):
         """workspace + image staging sized for the LARGEST chunk seen at this resolution: a
@@ -241,6 +242,7 @@ class _LossEngine(object):
         self._img16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
         self._dimg16 = torch.empty(B, H, W, 16, device=dev, dtype=torch.float32)
         self.shape = (B, H, W)
+        self.generation += 1                         # captured HIP graphs hold the old pointers
 
     @property
     def img16(self):

@@ -128,6 +128,7 @@ class BigGAN(nn.Module):
                            (N.WFMT_FLAG_ATTN_GEMM if N.default_attn_gemm() else 0))
         self._ws = None
         self._ws_B = -1
+        self.ws_generation = 0
         self._ticket = 0
         self._img16 = None
         self._pack(weights)
@@ -251,6 +252,7 @@ class BigGAN(nn.Module):
             self._ws = torch.empty(nbytes // 4, device=self._dev, dtype=torch.float32)
             self._ws_bytes = nbytes
             self._ws_B = B
+            self.ws_generation += 1          # captured HIP graphs hold the old pointers
             self._img16 = torch.empty(B, 256, 256, 16, device=self._dev, dtype=torch.float32)
             self._dimg16 = torch.empty(B, 256, 256, 16, device=self._dev, dtype=torch.float32)
         return self._ws

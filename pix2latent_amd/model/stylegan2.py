@@ -119,6 +119,7 @@ class StyleGAN2(nn.Module):
         self._wfmt = N.default_wfmt() if wfmt is None else wfmt
         self._desc.wfmt = self._wfmt
         self._ws, self._ws_B, self._ticket = None, -1, 0
+        self.ws_generation = 0
         self._pack(weights)
         self.search = search
         with torch.no_grad():
@@ -213,6 +214,7 @@ class StyleGAN2(nn.Module):
             self._img16 = torch.empty(B, S, S, 16, device=self._dev, dtype=torch.float32)
             self._dimg16 = torch.empty(B, S, S, 16, device=self._dev, dtype=torch.float32)
             self._ws_B = B
+            self.ws_generation += 1          # captured HIP graphs hold the old pointers
 
     # -------------------------------------------------------------- pieces
     def mapping(self, z):

@@ -79,8 +79,12 @@ class PycmaSampler(PopulationSampler):
             # every replica tells rank 0's population, so the replicas stay identical
             self._handle = values.reshape(len(values), -1)
             if self.es.is_scalar:
+                # a scalar variable lives in a 2-d proxy problem whose second coordinate the
+                # strategy draws on its own: step-size adaptation sees BOTH coordinates, so every
+                # replica must tell rank 0's full draw, not a copy of column 0 (the trajectory
+                # must not depend on the number of GPUs)
                 self.es._proxy = self._handle
-                self.es._full = np.repeat(self._handle, 2, axis=1)
+                self.es._full = shard.broadcast_numpy(np.asarray(self.es._full, dtype=np.float64), src=0)
         return values
 
     def _tell(self, asked, losses):

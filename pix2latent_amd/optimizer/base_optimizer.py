@@ -215,7 +215,13 @@ class _BaseOptimizer(SearchLoopMixin):
         # identity of everything the captured launches point at: the variable buffers, and for
         # the output variables (targets, weights) also their version - the loss keeps target
         # features cached per version, a transform that rewrites the targets must re-capture
-        key = (variables.num_samples, lo, hi, self.max_batch_size, self.exec_batch_size) + tuple(
+        # ... and WHICH optimizer / workspaces they belong to: the caching allocator hands the
+        # addresses of freed buffers out again (vm.initialize() in a loop gives new variables
+        # and a new Adam state at the old addresses), and a model or loss that re-allocates its
+        # workspace for a larger batch leaves the old pointers baked into the captured launches
+        key = (variables.num_samples, lo, hi, self.max_batch_size, self.exec_batch_size,
+               variables.opt.state_key(), getattr(self.model, 'ws_generation', 0),
+               getattr(getattr(self.loss_fn, '_engine', None), 'generation', 0)) + tuple(
             (name, v.buf.data_ptr()) for name, v in sorted(variables.input.items())
             if v.get('buf', None) is not None) + tuple(
             (name, v.buf.data_ptr(), v.buf._version) for name, v in sorted(variables.output.items())
@@ -241,8 +247,10 @@ class _BaseOptimizer(SearchLoopMixin):
                 self.use_graph = False
                 self._graphs = {}
                 return None
-            entry = self._graphs[key] = (graph, out, loss, other)
-        graph, out, loss, other = entry
+            # the entry PINS what the graph points at (variables -> buffers, Adam moments and step
+            # counters): none of those addresses can be recycled while the graph can be replayed
+            entry = self._graphs[key] = (graph, out, loss, other, variables, variables.opt)
+        graph, out, loss, other = entry[:4]
         graph.replay()
         # the captured tensors are static buffers the replay has just refilled
         self.out = self.out_local = out
@@ -276,13 +284,17 @@ class _BaseOptimizer(SearchLoopMixin):
                 proto = self.out_local
             else:
                 proto = None
-            shape = self.shard_out_shape(proto)
+            shape = self.shard_out_shape(proto, variables)
             local = proto if proto is not None else torch.zeros((0,) + shape, device=v.data[0].device)
             self.out = self.shard.all_gather_rows(local, n)
 
-    def shard_out_shape(self, proto):
+    def shard_out_shape(self, proto, variables=None):
+        """shape of one output image on a rank that owns no candidate (population < world
+        size): the generator renders at the target's size, whatever the model"""
         if proto is not None:
             self._out_shape = tuple(proto.shape[1:])
+        elif not hasattr(self, '_out_shape') and variables is not None and 'target' in variables.output:
+            self._out_shape = tuple(variables.output.target.data[0].shape)
         return getattr(self, '_out_shape', (3, 256, 256))
 
     def optimize(self):

@@ -169,30 +169,41 @@ class SearchLoopMixin(object):
         base_ng_optimizer.py:104)."""
         variables = None
         # graph execution of the inner step wants stable device addresses across generations
+        pooled_before = self.var_manager.reuse_buffers
         if getattr(self, 'use_graph', False) is not False and torch.cuda.is_available():
             lo, hi = self.shard.bounds(num_samples) if self.shard.enabled else (0, num_samples)
             if self.use_graph or os.environ.get('P2L_GRAPH') == '1' or \
                     (os.environ.get('P2L_GRAPH') != '0' and 0 < hi - lo <= 6):
                 self.var_manager.reuse_buffers = True
-        for g_idx, gen in enumerate(plan):
-            with torch.no_grad():
-                variables = self.var_manager.initialize(num_samples=num_samples)
-                if sampler is not None:
-                    sampler.draw(variables, self.shard)
-            if after_draw is not None:
-                after_draw(g_idx, variables)
-            for j in range(gen.steps):
-                self.step(variables, optimize=gen.refine, transform=(gen.refine and j == 0))
-                if self.log and j == 0 and hasattr(self, 'vis_transform'):
-                    self.vis_transform(variables)
-                ticker.tick(variables, gen.shift)
-            told = None
-            if gen.report and sampler is not None:
+        try:
+            for g_idx, gen in enumerate(plan):
                 with torch.no_grad():
-                    told = self.losses_for_tell(variables)
-                sampler.report(told)
-            if after_generation is not None:
-                after_generation(g_idx, variables, told)
+                    variables = self.var_manager.initialize(num_samples=num_samples)
+                    if sampler is not None:
+                        sampler.draw(variables, self.shard)
+                if after_draw is not None:
+                    after_draw(g_idx, variables)
+                for j in range(gen.steps):
+                    self.step(variables, optimize=gen.refine, transform=(gen.refine and j == 0))
+                    if self.log and j == 0 and hasattr(self, 'vis_transform'):
+                        self.vis_transform(variables)
+                    ticker.tick(variables, gen.shift)
+                told = None
+                if gen.report and sampler is not None:
+                    with torch.no_grad():
+                        told = self.losses_for_tell(variables)
+                    sampler.report(told)
+                if after_generation is not None:
+                    after_generation(g_idx, variables, told)
+        finally:
+            if self.var_manager.reuse_buffers and not pooled_before:
+                # the caller gets the last generation's tensors: they leave the pool (a later
+                # initialize() / optimize() on the same VariableManager must not overwrite a
+                # result the reference returns as independent tensors), and the captured graphs
+                # that point into them are retired
+                self.var_manager.reuse_buffers = False
+                self.var_manager.release_pool()
+                self._graphs = {}
         return variables
 
     def finish(self, variables, total_steps):

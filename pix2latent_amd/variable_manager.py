@@ -63,6 +63,14 @@ class FusedAdam(object):
             for leaf in e['leaves']:
                 self.param_groups.append({'params': [leaf], 'lr': e['lr']})
 
+    def state_key(self):
+        """device addresses of everything a captured step writes through this optimizer
+        (moments and step counters): part of the HIP-graph key of the inner step.  With
+        `reuse_buffers` a re-initialised optimizer keeps them; without, a new optimizer that
+        happens to sit on recycled variable addresses is told apart by these."""
+        return tuple((n, e['m'].data_ptr(), e['v'].data_ptr(), e['steps'].data_ptr())
+                     for n, e in sorted(self.entries.items()))
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g['params']:
@@ -225,6 +233,11 @@ class VariableManager():
         return True
 
     @torch.no_grad()
+    def release_pool(self):
+        """forget the pooled device buffers (`reuse_buffers`): the tensors of the last
+        `initialize()` then belong to their holder alone, the next call allocates anew"""
+        self._pool = {}
+
     def initialize(self, num_samples):
         """
         Materialises `num_samples` samples of every registered variable and a

@@ -278,3 +278,54 @@ def test_random_hooks_do_not_depend_on_the_number_of_ranks():
                 assert np.allclose(r[k], single[k], atol=1e-6), (world, rank, k)
             for a, b in zip(r['told'], single['told']):
                 assert np.allclose(a, b, atol=1e-6)
+
+
+def _scalar_sigma_path(shard, seed, gens=4):
+    """a ONE-dimensional grad-free variable through the sampler: step sizes after each tell"""
+    from pix2latent_amd import VariableManager
+    from pix2latent_amd.optimizer.base_cma_optimizer import PycmaSampler
+    from pix2latent_amd.optimizer import cma_es
+    import pix2latent_amd.optimizer.base_cma_optimizer as B
+    B.CMAEvolutionStrategy = cma_es.CMAEvolutionStrategy
+    s = PycmaSampler('input', 'a', np.zeros(1), 0.5, seed=seed)
+    vm = VariableManager(device='cpu')
+    vm.register('a', (1,), 'input', grad_free=True, learning_rate=0.01,
+                distribution=lambda n, shape: torch.zeros(n, *shape))
+    path = []
+    for _ in range(gens):
+        variables = vm.initialize(num_samples=s.population)
+        values = s.draw(variables, shard)
+        s.report((np.asarray(values).reshape(len(values), -1)[:, 0] - 0.3) ** 2)
+        path.append(s.es.cma.sigma)
+    return np.array(path)
+
+
+def _scalar_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pix2latent_amd.parallel import PopulationShard
+        # replicas with DIFFERENT random streams: only rank 0's draw may matter
+        q.put((rank, _scalar_sigma_path(PopulationShard(), seed=11 + 100 * rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_scalar_variable_step_size_path_independent_of_world_size():
+    """a scalar grad-free variable is embedded in two dimensions; step-size adaptation sees both
+    coordinates, so every replica must tell rank 0's FULL draw: the sigma path
+    of a 2-rank run equals the single-process one"""
+    single = _scalar_sigma_path(None, seed=11)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    procs = [ctx.Process(target=_scalar_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0], single) and np.array_equal(res[1], single)

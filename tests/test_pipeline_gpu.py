@@ -268,6 +268,42 @@ def test_hip_graph_across_generations_with_buffer_reuse(dev):
     assert np.array_equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
 
 
+def test_hip_graph_never_replays_onto_recycled_addresses(dev):
+    """the kept reference API -- vm.initialize() + opt.step() in a loop, no buffer pool: the
+    caching allocator hands the freed variable / Adam-state addresses out again.  The graph cache
+    pins what a captured step points at and keys on the optimizer's state buffers, so every
+    round is captured afresh (or runs on live buffers) and equals the eager trajectory; and a
+    second optimize() on one VariableManager does not overwrite the first result."""
+    from pix2latent_amd.utils import function_hooks as hook
+    from pix2latent_amd.optimizer import GradientOptimizer, BasinCMAOptimizer
+    model, loss_fn, vm = _graph_problem(dev, hook.Clamp(2.0), 2)
+    runs = {}
+    for mode in (False, True):
+        torch.manual_seed(21)
+        opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, use_graph=mode)
+        finals = []
+        for rnd in range(3):
+            variables = vm.initialize(num_samples=2)          # previous round's tensors die here
+            for i in range(4):
+                opt.step(variables, optimize=True, transform=(i == 0))
+            finals.append((torch.stack(list(variables.input.z.data)).detach().cpu().clone(),
+                           variables.opt.state_steps('z')))
+            del variables
+        runs[mode] = finals
+    for (z0, s0), (z1, s1) in zip(runs[False], runs[True]):
+        assert torch.equal(z0, z1) and s0 == s1 == [4, 4]
+    # optimize() twice on one VariableManager: the first result stays what it was
+    torch.manual_seed(5)
+    opt = BasinCMAOptimizer(model, vm, loss_fn, max_batch_size=9, use_graph=True)
+    opt.cma_seed = 3
+    v1, _, _ = opt.optimize(meta_steps=1, grad_steps=3, last_grad_steps=3)
+    keep = torch.stack(list(v1.input.z.data)).detach().cpu().clone()
+    assert vm.reuse_buffers is False
+    v2, _, _ = opt.optimize(meta_steps=1, grad_steps=3, last_grad_steps=3)
+    assert torch.equal(torch.stack(list(v1.input.z.data)).detach().cpu(), keep)
+    assert v2.input.z.buf.data_ptr() != v1.input.z.buf.data_ptr()
+
+
 def test_random_hook_under_graph_replay_draws_fresh_noise(dev):
     """NormalPerturb inside a replayed graph: torch's graph-safe generator advances per replay
     (noise differs from step to step), Clamp still bounds the latents"""
