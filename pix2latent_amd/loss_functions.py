@@ -416,7 +416,13 @@ def _vgg_params(net, weights, device):
     if key not in _VGG_PARAMS:
         if weights is None:
             path = os.environ.get('P2L_LPIPS_%s_WEIGHTS' % net.upper())
-            if path:
+            if path and ',' in path:
+                # the two upstream files: torchvision backbone state_dict, lpips v0.1 linear layers
+                # (reference loss_functions.py:131 -> lpips.LPIPS(net=...))
+                from .utils.checkpoint import load_lpips_vgg, load_lpips_alex
+                backbone, lin = (torch.load(f.strip(), map_location='cpu') for f in path.split(',')[:2])
+                w = (load_lpips_alex if net == 'alex' else load_lpips_vgg)(backbone, lin)
+            elif path:
                 w = torch.load(path, map_location='cpu')
             else:
                 warnings.warn('LPIPS-%s: no pretrained weights available (no network); using '
