@@ -14,7 +14,7 @@ from pix2latent_amd import distribution, VariableManager, save_variables  # noqa
 __version__ = _impl.__version__
 
 for _name in ('distribution', 'variable_manager', 'loss_functions', 'optimizer', 'model',
-              'utils', 'utils.image', 'utils.misc', 'utils.function_hooks', 'parallel',
+              'utils', 'utils.image', 'utils.misc', 'utils.function_hooks', 'utils.video', 'parallel',
               'optimizer.closure', 'optimizer.base_optimizer',
               'optimizer.gradient_optimizer', 'optimizer.basincma_optimizer',
               'optimizer.cma_optimizer', 'optimizer.base_cma_optimizer',

@@ -65,3 +65,27 @@ def test_grid_save_roundtrip(tmp_path):
     assert (back - x[0]).abs().max().item() < 2.0 / 255 + 1e-6   # 8-bit quantisation only
     m = torch.tensor([[0.2, 0.9995], [1.0, -1.0]])
     assert torch.equal(image.binarize(m), torch.tensor([[0., 1.], [1., 0.]]))
+
+
+def test_make_gif_and_video_soft_dependencies(tmp_path):
+    """utils/video.py (reference utils/video.py:14-69): the module imports without cv2 / imageio /
+    skvideo; make_gif falls back to PIL; make_video names the missing package"""
+    import importlib.util
+    import numpy as np
+    import pytest
+    from PIL import Image
+    from pix2latent_amd.utils import video
+    frames = [np.full((8, 12, 3), v, dtype=np.float32) for v in (0.0, 0.5, 1.0)]     # [0, 1] stack
+    path = str(tmp_path / 'h.gif')
+    video.make_gif(path, frames, duration=0.6)
+    with Image.open(path) as g:
+        assert g.n_frames == 3 and g.size == (12, 8)
+        g.seek(2)
+        assert np.asarray(g.convert('RGB')).max() >= 250           # rescaled to 0..255
+    assert video.make_video(str(tmp_path / 'h.avi'), frames) is False
+    if importlib.util.find_spec('cv2') is None:
+        with pytest.raises(ImportError, match='cv2'):
+            video.make_video(str(tmp_path / 'h.webm'), frames, duration=1.0)
+    if importlib.util.find_spec('skvideo') is None:
+        with pytest.raises(ImportError, match='skvideo'):
+            video.make_video(str(tmp_path / 'h.mp4'), frames)
