@@ -32,6 +32,7 @@ POP = 18
 MAX_BATCH = 9
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6      # dense v_mfma_f32_32x32x16_bf16 = 16 x the fp32 MFMA rate
+HBM_PEAK_TBS = 8.0                  # MI355X_MICROARCH.md: HBM3E peak (achievable ~6.3 read; measured write 4.4-4.9)
 GFLOP_PER_EVAL = 197.8              # BASELINE.md §2 (conv_to_rgb sliced to 3 channels)
 
 
@@ -115,14 +116,87 @@ def cpu_baseline(problem, chunk=MAX_BATCH):
         return time.perf_counter() - t0
     one(chunk, False)                       # warm-up at the timed shapes (thread pools, oneDNN primitives)
     t_off = one(chunk, False)
-    t_on = one(chunk, True)
-    return {'value': round(chunk / t_on, 4), 'unit': 'evals/s',
+    t_on = sorted(one(chunk, True) for _ in range(3))        # median of 3 (one sample moved 0.58-0.75)
+    cpu_model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), None)
+    except OSError:
+        pass
+    return {'value': round(chunk / t_on[1], 4), 'unit': 'evals/s',
             'cores': torch.get_num_threads(), 'kind': 'port',
-            'wgrad': {'on': round(chunk / t_on, 4), 'off': round(chunk / t_off, 4)},
+            'cpu': cpu_model, 'host_cpus': os.cpu_count(),
+            'samples_evals_per_s': [round(chunk / t, 4) for t in t_on],
+            'wgrad': {'on': round(chunk / t_on[1], 4), 'off': round(chunk / t_off, 4)},
             'sample': '1 reference chunk of %d candidates (fwd+loss+bwd, BigGAN-deep-256 + '
-                      'L1+10*LPIPS-VGG16, torch-CPU fp32), timed once with weight gradients '
-                      'enabled (the reference never freezes the networks: value) and once '
-                      'with input gradients only' % chunk}
+                      'L1+10*LPIPS-VGG16, torch-CPU fp32), weight gradients enabled (the reference '
+                      'never freezes the networks): median of 3 timings = value; once with input '
+                      'gradients only' % chunk}
+
+
+class _GpuTelemetry(object):
+    """socket power and shader clock of the bench GPU while the timed steps run, read from the
+    amdgpu hwmon files at ~20 Hz on a side thread (no rocm-smi process; null when the files are
+    not there).  The kernels of this step are power-limited: the clock a number was
+    measured at belongs next to the number."""
+
+    def __init__(self, index=0):
+        import glob
+        self.paths = None
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
+        # the box shows every GPU of the node in sysfs; the one this process runs on is found by
+        # its PCI address
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            want = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [c for c in cards
+                    if os.path.basename(os.path.realpath(os.path.join(c, '..', '..'))) == want]
+            cards = mine or cards
+        except Exception:           # noqa: BLE001  (older torch: no PCI fields)
+            pass
+        if cards:
+            h = cards[0 if len(cards) == 1 else min(index, len(cards) - 1)]
+            pw = next((os.path.join(h, n) for n in ('power1_average', 'power1_input')
+                       if os.path.exists(os.path.join(h, n))), None)
+            self.paths = (pw, os.path.join(h, 'freq1_input'))
+        self.power, self.sclk, self._stop = [], [], False
+
+    def _read(self, path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            pw, fq = self._read(self.paths[0]), self._read(self.paths[1])
+            if pw is not None:
+                self.power.append(pw * 1e-6)
+            if fq is not None:
+                self.sclk.append(fq * 1e-6)
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.paths is not None:
+            import threading
+            self._t = threading.Thread(target=self._loop, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self.paths is not None:
+            self._t.join(1.0)
+
+    def summary(self):
+        def stat(v):
+            return None if not v else {'min': round(min(v), 1), 'mean': round(sum(v) / len(v), 1),
+                                       'max': round(max(v), 1), 'samples': len(v)}
+        return {'socket_power_w': stat(self.power), 'sclk_mhz': stat(self.sclk),
+                'source': 'amdgpu hwmon (power1_average, freq1_input) sampled during the timed steps'
+                          if self.paths else None}
 
 
 # ---------------------------------------------------------------------------------------
@@ -321,12 +395,13 @@ def main():
     # step); time every PERIOD-th launch, rotating the phase with the step, so that each
     # launch of the step is timed once per PERIOD steps
     period = max(1, min(args.prof_period, args.steps))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        lib.p2l_prof_step(i, period)
-        opt.step(variables, optimize=True)
-    sync()
-    elapsed = time.perf_counter() - t0
+    with _GpuTelemetry(local_rank) as telemetry:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            lib.p2l_prof_step(i, period)
+            opt.step(variables, optimize=True)
+        sync()
+        elapsed = time.perf_counter() - t0
     flops = (C.c_double * 2)()
     ms = (C.c_double * 2)()
     cnt = (C.c_int32 * 2)()
@@ -361,7 +436,7 @@ def main():
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        for name in ('round2_traffic.json', 'round1_traffic.json'):
+        for name in ('round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
             tpath = os.path.join(prof_dir, name)
             if os.path.exists(tpath):
                 with open(tpath) as f:
@@ -412,8 +487,8 @@ def main():
             'roofline': {
                 'kernel': ('every 3x3 conv launch of the step, bf16x3 arithmetic (6 x '
                            'v_mfma_f32_32x32x16_bf16 per 16 channels on 3-way split fp32 operands): '
-                           'wino16_conv_kernel / wino_conv_kernel (Winograd F(2x2,3x3), 16x16 | 8x16 '
-                           'pixel blocks), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel), '
+                           'wino16s_conv_kernel / wino_conv_kernel (Winograd F(2x2,3x3), 16x16 hand-scheduled '
+                           '| 8x16 pixel blocks), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel), '
                            'conv_thinin/thinout_kernel (3-channel image convs)'
                            if bf3 else
                            'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
@@ -434,19 +509,37 @@ def main():
                              'bf16_mfma_tflops_issued': round(6 * exec_tflops, 1) if bf3 else None,
                              'frac_of_peak': round(exec_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
                                                                   else FP32_MFMA_PEAK_TFLOPS), 4)},
+                # the matrix-pipe utilisation proper: bf16 MFMA FLOP/s issued / dense bf16 peak.
+                # `frac` above is ALGORITHMIC FLOPs against peak/6: Winograd and sub-pixel launches
+                # issue 16/36 of the direct products, so its ceiling is up to 2.25, not 1
+                'frac_executed': round((6 * exec_tflops if bf3 else exec_tflops) /
+                                       (BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS), 4),
+                'algorithmic_ceiling_of_frac': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,
                 'algo_bytes_per_launch': round(abytes[0] / max(cnt[0], 1)),
-                'launches': int(cnt[0]),
+                'sampled_launches': int(cnt[0]),
+                'launches_per_step': round(cnt[0] * period / args.steps, 1),
                 'launch_sampling': 'every %d-th conv launch timed (hipEvent pairs), phase rotating '
                                    'with the step' % period,
                 'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
                 'algo_gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),
                 'time_share_of_step': round(period * ms[0] * 1e-3 / elapsed, 4),
-                'conv1x1': {'achieved': round(conv1_tflops, 2), 'launches': int(cnt[1]),
-                            'time_share_of_step': round(period * ms[1] * 1e-3 / elapsed, 4)},
+                # the 1x1 family is output-dominated: its roof is memory, and the WRITE rate of the
+                # part (4.4-4.9 TB/s, tools/micro/mem_rate.hip) rather than the 8 TB/s headline
+                'conv1x1': {'achieved': round(conv1_tflops, 2), 'unit': 'TFLOP/s',
+                            'sampled_launches': int(cnt[1]),
+                            'launches_per_step': round(cnt[1] * period / args.steps, 1),
+                            'time_share_of_step': round(period * ms[1] * 1e-3 / elapsed, 4),
+                            'bound': 'hbm',
+                            'achieved_tb_per_s': round(abytes[1] / (ms[1] * 1e-3) / 1e12, 3) if ms[1] > 0 else None,
+                            'peak_tb_per_s': HBM_PEAK_TBS,
+                            'measured_stream_tb_per_s': {'write': 4.5, 'read': 6.5, 'copy': 5.0},
+                            'frac': round(abytes[1] / (ms[1] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if ms[1] > 0 else None,
+                            'per_layer_table': 'profiles/round3_conv1x1_roofline.txt'},
             },
+            'telemetry': telemetry.summary(),
         }
         if world == 1 and bf3 and not args.no_fp32_leg:
             # the same steps with every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
