@@ -227,7 +227,7 @@ def extra_configs(dev, n_steps=3):
     out = {}
     Wv = S.lpips_vgg_weights(1)
 
-    def run(name, model, vm, n, size, note, **kw):
+    def run(name, model, vm, n, size, note, profile=None, **kw):
         loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
         opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=MAX_BATCH, **kw)
         variables = vm.initialize(num_samples=n)
@@ -238,6 +238,33 @@ def extra_configs(dev, n_steps=3):
         out[name] = {'evals_per_s': round(n / dt, 1), 'ms_per_step': round(1e3 * dt, 2),
                      'candidates': n, 'resolution': size, 'what': note,
                      'hip_graph_replay': bool(opt._graphs) and any(isinstance(v, tuple) for v in opt._graphs.values())}
+        if profile:
+            # which kernel dominates and where it stands: the 3x3 conv launches of two more
+            # (eager) steps timed with the library's hipEvent pairs, every 4th launch
+            from pix2latent_amd import _native as N
+            lib = N.lib()
+            saved, opt.use_graph = opt.use_graph, False
+            N.check(lib.p2l_prof_begin(8192), 'p2l_prof_begin')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(4):
+                lib.p2l_prof_step(i, 4)
+                opt.step(variables, optimize=True)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            f, m, c, b, x = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
+                             (C.c_double * 2)())
+            N.check(lib.p2l_prof_end3(f, m, c, b, x), 'p2l_prof_end3')
+            opt.use_graph = saved
+            if m[0] > 0:
+                tf = f[0] / (m[0] * 1e-3) / 1e12
+                out[name]['dominant_kernel'] = {
+                    'family': '3x3 / sub-pixel convs (wino16s_conv_kernel + conv_mfma_kernel<4>)',
+                    'time_share_of_step': round(4 * m[0] * 1e-3 / el, 3),
+                    'achieved_tflops_algorithmic': round(tf, 1),
+                    'frac_of_bf16x3_ceiling': round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 3),
+                    'frac_executed_of_bf16_peak': round(6 * x[0] / (m[0] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 3),
+                    'rocprof': profile}
         del opt, variables, loss_fn
         torch.cuda.empty_cache()
 
@@ -274,6 +301,7 @@ def extra_configs(dev, n_steps=3):
         run('stylegan2_cars_512_n32', FixedNoise(), vm, 32, 512,
             'BASELINE config 4 inner step: 32 samples (reference chunks 9,9,9,5 define the '
             'gradient scale; executed in one device pass), z-space, rows 64:-64 loss mask',
+            profile='profiles/round3_sg2_512_kernel_stats.csv, round3_sg2_512_layers.txt',
             exec_batch_size='all')
         del gen, fixed
         torch.cuda.empty_cache()
@@ -290,7 +318,8 @@ def extra_configs(dev, n_steps=3):
         vm.register('weight', (3, 1024, 1024), 'output', requires_grad=False, default=S.synthetic_weight_mask(1024))
         run('stylegan2_ffhq_1024_shard3_wplus', gen, vm, 3, 1024,
             'BASELINE config 5, one rank\'s shard: 3 candidates, W+ latents [18,512] and the '
-            '2.8M-element noise vector both optimised')
+            '2.8M-element noise vector both optimised',
+            profile='profiles/round3_sg2_1024_kernel_stats.csv, round3_sg2_1024_layers.txt')
     return out
 
 
