@@ -93,41 +93,52 @@ __global__ void demod_bwd_kernel(const float* s, const float* Wsq, const float* 
 // blur(u)[Y,X] = sum_{j,i} a_j a_i u[Y+j-1, X+i-1],  a = [.25 .75 .75 .25]
 __device__ __forceinline__ float fir_a(int j) { return (j == 0 || j == 3) ? 0.25f : 0.75f; }
 
+// A thread produces FOUR vertically adjacent outputs of one column x 4 channels: the 4-tap row
+// sums of the 7 input rows they share are formed once (28 loads per 4 outputs instead of 64:
+// round 2's one-output-per-thread form ran at 1.8 TB/s, request-bound, profiles/round3_sg2_*).
 __global__ void blur_fwd_kernel(const float* u, const float* d, const float* noise, float nw,
                                 const float* bias, float* y, int Bn, int H, int W, int C) {
-  const int C4 = C >> 2;
+  const int C4 = C >> 2, H4 = H >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Bn * H * W * C4) return;
+  if (idx >= (size_t)Bn * H4 * W * C4) return;
   const int c = (int)(idx % C4) * 4;
   size_t p = idx / C4;
   const int X = (int)(p % W);
   p /= W;
-  const int Y = (int)(p % H);
-  const int b = (int)(p / H);
+  const int Y0 = (int)(p % H4) * 4;
+  const int b = (int)(p / H4);
   const int UW = W + 2, UH = H + 2;
-  f32x4 acc = {0, 0, 0, 0};
+  f32x4 hrow[7];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int yy = Y + j - 1;
-    if (yy < 0) continue;
+  for (int r = 0; r < 7; ++r) {
+    const int yy = Y0 + r - 1;
     f32x4 row = {0, 0, 0, 0};
+    if (yy >= 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int xx = X + i - 1;
-      if (xx < 0) continue;
-      row += *reinterpret_cast<const f32x4*>(u + (((size_t)b * UH + yy) * UW + xx) * C + c) * fir_a(i);
+      for (int i = 0; i < 4; ++i) {
+        const int xx = X + i - 1;
+        if (xx < 0) continue;
+        row += *reinterpret_cast<const f32x4*>(u + (((size_t)b * UH + yy) * UW + xx) * C + c) * fir_a(i);
+      }
     }
-    acc += row * fir_a(j);
+    hrow[r] = row;
   }
   const f32x4 d4 = *reinterpret_cast<const f32x4*>(d + (size_t)b * C + c);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c);
-  const float nz = noise ? nw * noise[((size_t)b * H + Y) * W + X] : 0.f;
-  f32x4 v = acc * d4 + b4 + nz;
-  v.x *= v.x > 0.f ? kSqrt2 : kSlope * kSqrt2;
-  v.y *= v.y > 0.f ? kSqrt2 : kSlope * kSqrt2;
-  v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
-  v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
-  *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X) * C + c) = v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int Y = Y0 + k;
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += hrow[k + j] * fir_a(j);
+    const float nz = noise ? nw * noise[((size_t)b * H + Y) * W + X] : 0.f;
+    f32x4 v = acc * d4 + b4 + nz;
+    v.x *= v.x > 0.f ? kSqrt2 : kSlope * kSqrt2;
+    v.y *= v.y > 0.f ? kSqrt2 : kSlope * kSqrt2;
+    v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
+    v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
+    *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X) * C + c) = v;
+  }
 }
 
 // activation backward of a styled conv (with or without blur): given dy and the saved
@@ -212,33 +223,44 @@ __global__ void noise_grad_finish_kernel(const float* strips, float* dnoise, flo
   dnoise[i] = nw * a;
 }
 
-// transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d)
+// transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d).  As the forward
+// kernel: four vertically adjacent rows of du per thread (rows yy0 .. yy0+3 of the H+2; the frame
+// height is even but not always a multiple of 4: rows past the end are skipped).
 __global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C) {
-  const int C4 = C >> 2, UH = H + 2, UW = W + 2;
+  const int C4 = C >> 2, UH = H + 2, UW = W + 2, UH4 = (UH + 3) >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Bn * UH * UW * C4) return;
+  if (idx >= (size_t)Bn * UH4 * UW * C4) return;
   const int c = (int)(idx % C4) * 4;
   size_t p = idx / C4;
   const int xx = (int)(p % UW);
   p /= UW;
-  const int yy = (int)(p % UH);
-  const int b = (int)(p / UH);
-  // u[yy,xx] feeds y[Y,X] with Y = yy - j + 1, X = xx - i + 1
-  f32x4 acc = {0, 0, 0, 0};
+  const int yy0 = (int)(p % UH4) * 4;
+  const int b = (int)(p / UH4);
+  // u[yy,xx] feeds y[Y,X] with Y = yy - j + 1, X = xx - i + 1: rows Y = yy0 - 2 .. yy0 + 4
+  f32x4 hrow[7];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int Y = yy - j + 1;
-    if (Y < 0 || Y >= H) continue;
+  for (int r = 0; r < 7; ++r) {
+    const int Y = yy0 + r - 2;
     f32x4 row = {0, 0, 0, 0};
+    if (Y >= 0 && Y < H) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int X = xx - i + 1;
-      if (X < 0 || X >= W) continue;
-      row += *reinterpret_cast<const f32x4*>(g + (((size_t)b * H + Y) * W + X) * C + c) * fir_a(i);
+      for (int i = 0; i < 4; ++i) {
+        const int X = xx - i + 1;
+        if (X < 0 || X >= W) continue;
+        row += *reinterpret_cast<const f32x4*>(g + (((size_t)b * H + Y) * W + X) * C + c) * fir_a(i);
+      }
     }
-    acc += row * fir_a(j);
+    hrow[r] = row;
   }
-  *reinterpret_cast<f32x4*>(du + idx * 4) = acc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = yy0 + k;
+    if (yy >= UH) break;
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += hrow[k + 3 - j] * fir_a(j);       // Y = yy - j + 1 = yy0 + (k + 3 - j) - 2
+    *reinterpret_cast<f32x4*>(du + ((((size_t)b * UH + yy) * UW + xx) * C4) * 4 + c) = acc;
+  }
 }
 
 // RGB skip: out[B,2h,2w,16] = upfirdn2d(skip[B,h,w,16], up=2, pad=(2,1)); per dim:
@@ -370,7 +392,8 @@ extern "C" int p2l_sg2_blur_fwd(const float* u, const float* d, const float* noi
                                 const float* bias, float* y, int Bn, int H, int W, int C,
                                 void* stream) {
   if (C % 4) return P2L_EINVAL;
-  hipLaunchKernelGGL(blur_fwd_kernel, dim3(cdiv((size_t)Bn * H * W * (C / 4), 256)), dim3(256), 0,
+  if (H % 4) return P2L_EINVAL;
+  hipLaunchKernelGGL(blur_fwd_kernel, dim3(cdiv((size_t)Bn * (H / 4) * W * (C / 4), 256)), dim3(256), 0,
                      ST(stream), u, d, noise, nw, bias, y, Bn, H, W, C);
   return p2l_check_launch();
 }
@@ -400,7 +423,7 @@ extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const flo
 extern "C" int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C,
                                 void* stream) {
   if (C % 4) return P2L_EINVAL;
-  hipLaunchKernelGGL(blur_bwd_kernel, dim3(cdiv((size_t)Bn * (H + 2) * (W + 2) * (C / 4), 256)),
+  hipLaunchKernelGGL(blur_bwd_kernel, dim3(cdiv((size_t)Bn * ((H + 5) / 4) * (W + 2) * (C / 4), 256)),
                      dim3(256), 0, ST(stream), g, du, Bn, H, W, C);
   return p2l_check_launch();
 }

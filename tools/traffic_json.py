@@ -10,7 +10,7 @@ import sys
 
 # every kernel a 3x3 launch of the bench step can be: direct (TAPS=9), sub-pixel (TAPS=4), Winograd
 # (8x16 and 16x16 blocks), three-channel image convs
-KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'wino_conv_kernel', 'wino16_conv_kernel',
+KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'wino_conv_kernel', 'wino16s_conv_kernel',
            'conv_thinin_kernel', 'conv_thinout_kernel')
 
 
@@ -27,7 +27,7 @@ nf, f = per_launch(sys.argv[1], 'FETCH_SIZE')
 nw, w = per_launch(sys.argv[2], 'WRITE_SIZE')
 out = {
     'kernel': '3x3 conv launches: conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
-              'wino16_conv_kernel + conv_thinin/thinout_kernel',
+              'wino16s_conv_kernel + conv_thinin/thinout_kernel',
     'commit': sys.argv[4] if len(sys.argv) > 4 else None,
     'box': sys.argv[5] if len(sys.argv) > 5 else None,
     'command': sys.argv[6] if len(sys.argv) > 6 else None,
