@@ -252,6 +252,13 @@ enum {
   P2L_FORM_NO_PW = 8,        /* P2L_WFMT_PW weights, but the exact-fp32 1x1 kernel             */
   P2L_FORM_NO_THIN = 16      /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
 };
+/* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
+ * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels
+ * cut into this many slices (2 or 4; >= 8 chunks of 16 channels each) and the deterministic
+ * split-K finish -- IF the caller passes exactly this number as P2LConv.splitk (and the
+ * workspace p2l_conv_workspace_bytes asks for); p2l_conv_suggest_splitk returns it for such a
+ * shape.  A function of the layer shape only, never of the batch.  1 = not such a layer. */
+int p2l_wino_split_factor(int H, int W, int Cin, int Cout);
 int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N_pad,
                               int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,

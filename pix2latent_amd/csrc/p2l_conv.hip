@@ -910,13 +910,23 @@ int halo_pitch(int TW, bool bf3) {
 // prologue / epilogue against rounds of the chip that are mostly empty).
 // P2LConv.form: P2L_FORM_NO_WINO keeps the direct kernel, P2L_FORM_WINO_ANY takes every eligible
 // shape (tests: small grids too).
+// K slices of a small-grid Winograd layer (shape only; 1 = none)
+static int wino_split(const P2LConv* d) {
+  if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || (d->form & P2L_FORM_NO_WINO)) return 1;
+  if (d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin) || (d->form & P2L_FORM_WINO_8X16)) return 1;
+  return p2l_wino_split_factor(d->H, d->W, d->Cin, d->Cout);
+}
 static bool wino_shape(const P2LConv* d) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || (d->form & P2L_FORM_NO_WINO)) return false;
   if (d->H % 8 || d->W % 16 || d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin)) return false;
   const int per_image = (d->H / 8) * (d->W / 16) * (d->Cout / 64);
-  // (measured, tools/policy_probe.py: a threshold of 32 -- the 32^2 256->256 layers too -- is
-  //  +1 % at 18 candidates per GPU and -2...-4 % at 2-3, where those launches are 48 blocks)
-  return (d->form & P2L_FORM_WINO_ANY) || per_image >= 64;
+  if ((d->form & P2L_FORM_WINO_ANY) || per_image >= 64) return true;
+  // small-grid layers: in the K-sliced form only, i.e. when the caller passes the slice count
+  // p2l_conv_suggest_splitk gives for the shape (with it a 48-block launch at 2-3 candidates per
+  // GPU becomes 96-192 short blocks; unsliced, a threshold of 32 measured +1 % at 18 candidates
+  // and -2...-4 % at 2-3)
+  const int s = wino_split(d);
+  return s > 1 && d->splitk == s;
 }
 
 // bf16x3 form of the 1x1 conv (p2l_pw.hip): weights carry the pre-split image
@@ -996,6 +1006,9 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (d->ups >= 2) return 1;             // sub-pixel modes never split K
+  if (choose_tile(d, k) == P2L_OK && wino_split(d) > 1 && !(d->form & P2L_FORM_WINO_ANY) &&
+      (d->H / 8) * (d->W / 16) * (d->Cout / 64) < 64)
+    return wino_split(d);                // small-grid Winograd layer: a function of the shape only
   if (choose_tile(d, k) != P2L_OK || wino_shape(d) || pw_any(d)) return 1;
   const int bn = choose_bn(d, k.n_mtiles);
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
@@ -1018,6 +1031,7 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
 static int effective_splitk(const P2LConv* d) {
+  if (d->splitk > 1 && d->ups == 0 && wino_split(d) == d->splitk && wino_shape(d)) return d->splitk;
   if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d) || pw_any(d)) return 1;
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
   const int nchunks = d->Cin / kc;
@@ -1094,7 +1108,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   const int bn = choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
-  k.splitk = (d->splitk < 1 || wino_shape(d) || pw_any(d)) ? 1 : d->splitk;
+  const bool wino_sliced = wino_shape(d) && d->splitk > 1 && wino_split(d) == d->splitk;
+  k.splitk = (d->splitk < 1 || (wino_shape(d) && !wino_sliced) || pw_any(d)) ? 1 : d->splitk;
   if (k.splitk > k.nchunks) k.splitk = k.nchunks;
   k.chunks_per_split = cdiv(k.nchunks, k.splitk);
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
@@ -1152,8 +1167,20 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     kw.n_mtiles = d->B * kw.tiles_x * kw.tiles_y;
     kw.n_ntiles = d->Cout / 64;
     kw.nchunks = d->Cin / 16;
-    kw.splitk = 1;
+    if (wino_sliced) {
+      kw.splitk = d->splitk;
+      kw.chunks_per_split = kw.nchunks / kw.splitk;     // (the factor divides the chunk count)
+    } else {
+      kw.splitk = 1;
+    }
     rc = p2l_wino_launch(kw, d->pro, st);
+    if (rc == P2L_OK && wino_sliced) {
+      // the slices meet in the deterministic finish kernel of the direct path: fixed-order sum,
+      // then the whole epilogue (bias / residual / activation / fused activation backward)
+      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
+      hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+      rc = p2l_check_launch();
+    }
     if (prof_slot >= 0) {
       g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * 4;   // 16 per quad
       (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);

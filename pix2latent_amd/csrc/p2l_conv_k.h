@@ -383,6 +383,7 @@ int p2l_thinout_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
 // Winograd F(2x2,3x3) form of the bf16x3 3x3 conv (p2l_wino.hip)
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);
 extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad);
+extern "C" int p2l_wino_split_factor(int H, int W, int Cin, int Cout);
 int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
                   float* dst, hipStream_t st);
 int p2l_wino_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

@@ -722,11 +722,17 @@ extern "C" size_t p2l_loss_cache_floats(int B, int H, int W, size_t nft_off[5],
 
 extern "C" size_t p2l_projloss_ws_bytes(int B, int H, int W) {
   // no descriptor here: size for the format with the largest split-K workspace (the last
-  // region of the arena; every other offset is format-independent)
+  // region of the arena; every other offset is format-independent): the exact-fp32 kernels split
+  // K by the grid size, the Winograd format slices its small-grid layers by their shape
+  size_t total = 0;
+  for (int fmt : {(int)P2L_WFMT_F32, (int)P2L_WFMT_BF16X3W, (int)P2L_WFMT_BF16X3}) {
+    g_plan_wfmt = fmt;
+    PLLayout L;
+    if (pl_layout(B, H, W, L)) return 0;
+    if (L.total > total) total = L.total;
+  }
   g_plan_wfmt = P2L_WFMT_F32;
-  PLLayout L;
-  if (pl_layout(B, H, W, L)) return 0;
-  return L.total * sizeof(float);
+  return total * sizeof(float);
 }
 
 extern "C" int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,

@@ -362,6 +362,14 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
   const int y0 = by * 16, x0 = bx * 16, n0 = __builtin_amdgcn_readfirstlane(nt * 64);
 
+  // split-K (blockIdx.y = slice z of the input channels): chunks c_lo .. c_lo + nchunks - 1 of the
+  // layer; the un-scaled partial outputs go to k.ws[z] and conv_splitk_finish adds the slices in
+  // fixed order and runs the epilogue (p2l_conv.hip).  The slice count is a function of the LAYER
+  // SHAPE only (p2l_wino_split_factor), like the choice of the Winograd form itself.
+  const int z = blockIdx.y;
+  const int c_lo = z * k.chunks_per_split;
+  const int nchunks = min(k.chunks_per_split, k.nchunks - c_lo);
+
   // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
   constexpr int A_ITERS = 3;
   const int sv = tid & 3;
@@ -395,10 +403,10 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   auto load_raw = [&](int c) {
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it)
-      xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_goff[it], c * 64, 0));
+      xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_goff[it], (c_lo + c) * 64, 0));
     if (PRO != P2L_PRO_NONE) {
-      sr = *reinterpret_cast<const f32x4*>(ps_img + c * 64 + s_off);
-      tr = *reinterpret_cast<const f32x4*>(pt_img + c * 64 + s_off);
+      sr = *reinterpret_cast<const f32x4*>(ps_img + (c_lo + c) * 64 + s_off);
+      tr = *reinterpret_cast<const f32x4*>(pt_img + (c_lo + c) * 64 + s_off);
     }
   };
   auto write_raw1 = [&](int it) {
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int w_lane = lane * 16;
   f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
   auto load_b = [&](int c, int fi, int set) {
-    const int base = ((c * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (3 * 64 * 16);
+    const int base = (((c_lo + c) * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (3 * 64 * 16);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -524,12 +532,11 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
         A, __builtin_bit_cast(bf16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                 \
   P2L_SB()
 
-  const int nchunks = k.nchunks;
 #ifdef P2L_LAB
   // phase timestamps of one block: [wave][chunk][8] s_memtime ticks (slot 0 chunk top, 1-4 after
   // steps 0-3, 5 after the closing barrier)
   unsigned long long* trace =
-      (k.ws != nullptr && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
+      (k.ws != nullptr && k.splitk <= 1 && swz == (int)(gridDim.x / 2)) ? reinterpret_cast<unsigned long long*>(k.ws) : nullptr;
 #define P2L_TR(SLOT, C)                                                                      \
   if (trace != nullptr && lane == 0 && (C) < 64) trace[(wave * 64 + (C)) * 8 + (SLOT)] = __builtin_amdgcn_s_memtime()
 #else
@@ -666,6 +673,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
   const int ety = e_t >> 3, etx = e_t & 7;
   float* red = raw;                                      // [2 kinds][8 waves][32]
+  const bool split = k.splitk > 1;
+  const float alpha = split ? 1.f : k.alpha;             // (the finish kernel scales the sum)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -694,12 +703,21 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       f32x4 v[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {                     // (A^T M) A
-        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * k.alpha;
-        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * k.alpha;
+        v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * alpha;
+        v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * alpha;
       }
-      epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
+      if (split) {
+        const size_t pix = ((size_t)b * k.H + y0 + 2 * ety) * k.W + x0 + 2 * etx;
+        float* wp = k.ws + (((size_t)z * k.B * k.H * k.W + pix) * k.Cout + nb + e_c4 * 4);
+        *reinterpret_cast<f32x4*>(wp) = v[0];
+        *reinterpret_cast<f32x4*>(wp + k.Cout) = v[1];
+        *reinterpret_cast<f32x4*>(wp + (size_t)k.W * k.Cout) = v[2];
+        *reinterpret_cast<f32x4*>(wp + (size_t)(k.W + 1) * k.Cout) = v[3];
+      } else {
+        epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
+      }
     }
-    if (k.arb_x != nullptr) {
+    if (k.arb_x != nullptr && !split) {
       f32x4 sgx = S.sgx, sg = S.sg;
 #pragma unroll
       for (int o = 8; o < 64; o <<= 1) {
@@ -778,6 +796,25 @@ extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad) {
   return (size_t)N_pad * K_pad * 24;
 }
 
+// Small-grid layers (16 ... 63 blocks of 8x16x64 per image, H and W multiples of 16): the 16x16
+// kernel with the input channels cut into this many slices -- a function of the layer shape only,
+// never of the batch (1 = not such a layer).  At least 8 chunks per slice.  Measured with 18
+// candidates (tools/micro/conv_lab.cpp): 32^2 256->256 and 16^2 512->512 run 1.5-1.7x faster than
+// on the direct kernel; without the slices the same layers would be 24-48 blocks at 2-3 candidates
+// per GPU.
+extern "C" int p2l_wino_split_factor(int H, int W, int Cin, int Cout) {
+#ifdef P2L_NO_WINO_SLICES
+  return 1;                                            // (A/B build: tools/ab_build.sh)
+#endif
+  if (H % 16 || W % 16 || Cout % 64 || Cin % 16) return 1;
+  const int per_image = (H / 8) * (W / 16) * (Cout / 64);
+  if (per_image >= 64 || per_image < 16) return 1;
+  int s = 64 / per_image;                              // 2 or 4
+  const int nchunks = Cin / 16;
+  while (s > 1 && nchunks / s < 8) s >>= 1;
+  return s;
+}
+
 // shapes the Winograd kernel takes (the launcher adds the per-launch conditions)
 extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad) {
   return N_pad % 64 == 0 && K_pad % 16 == 0;
@@ -807,10 +844,10 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   if (k.H % 16 == 0 && k.W % 16 == 0 && !(k.form & P2L_FORM_WINO_8X16)) {
     k.tiles_y = k.H / 16;
     k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
-    k.ws = nullptr;
-    dim3 grid(k.n_mtiles * k.n_ntiles), block(W16_THREADS);
+    if (k.splitk <= 1) { k.ws = nullptr; k.splitk = 1; k.chunks_per_split = k.nchunks; }
+    dim3 grid(k.n_mtiles * k.n_ntiles, k.splitk), block(W16_THREADS);
 #ifdef P2L_LAB
-    k.ws = (float*)g_lab_trace;
+    if (k.splitk <= 1) k.ws = (float*)g_lab_trace;
 #define P2L_W16L(ABL)                                                                        \
   case ABL: {                                                                                \
     (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, ABL>,           \

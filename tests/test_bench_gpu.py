@@ -33,7 +33,9 @@ def test_bench_single_gpu_line():
     assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['value'] > 0
     assert rec['unit'] == 'evals/s' and rec['higher_is_better'] is True
     roof = rec['roofline']
-    assert roof['bound'] == 'mfma' and 0 < roof['frac'] < 1 and roof['launches'] > 0
+    assert roof['bound'] == 'mfma' and 0 < roof['frac'] < 1 and roof['sampled_launches'] > 0
+    assert 0 < roof['frac_executed'] < 1 and roof['launches_per_step'] > 0
+    assert roof['conv1x1']['bound'] == 'hbm' and 'telemetry' in rec
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     assert len(rec['config']['last_losses']) == 18
 
@@ -52,4 +54,4 @@ def test_bench_sharded_ranks_share_one_gpu(world):
     rec = _bench_line(r.stdout)
     assert rec['n_gpus'] == world and rec['value'] > 0 and rec['scaling'] == 'strong'
     assert rec['config']['population'] == 18 and len(rec['config']['last_losses']) == 18
-    assert rec['roofline']['launches'] > 0          # the eager timed loop was profiled
+    assert rec['roofline']['sampled_launches'] > 0          # the eager timed loop was profiled

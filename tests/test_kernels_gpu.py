@@ -334,6 +334,55 @@ def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip, C, Co):
     assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
+@pytest.mark.parametrize('shape', [(32, 256, 256, 2), (16, 512, 512, 4), (32, 512, 256, 2)],
+                         ids=['32x32-256to256', '16x16-512to512', '32x32-512to256'])
+def test_winograd_k_sliced_small_grid_layers(dev, O, shape):
+    """small-grid 3x3 layers (16..63 blocks of 8x16x64 per image) run the 16x16 Winograd kernel
+    with the input channels cut into slices -- a count that depends on the LAYER SHAPE only -- and
+    the deterministic split-K finish kernel: same numbers as torch, forward and the input-gradient
+    form with the fused activation backward; and a candidate's result does not depend on how many
+    others share the launch (bit for bit)."""
+    from pix2latent_amd import _native as N
+    H, Cin, Cout, slices = shape
+    O.DEFAULT_FORM = N.FORM_AUTO                      # the product's own choice for this shape
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.x_ld, d.wfmt, d.splitk = 3, H, H, Cin, Cout, 9, Cin, 2, 1
+    assert N.lib().p2l_conv_suggest_splitk(C.byref(d)) == slices
+    d.B = 18
+    assert N.lib().p2l_conv_suggest_splitk(C.byref(d)) == slices      # ... whatever the batch
+    g = torch.Generator().manual_seed(31)
+    B = 3
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    s = 0.5 + torch.rand(B, Cin, generator=g)
+    t = 0.3 * torch.randn(B, Cin, generator=g)
+    ref = F.conv2d(F.relu(x * s.view(B, Cin, 1, 1) + t.view(B, Cin, 1, 1)), w, bias, padding=1)
+    wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
+    y, _ = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, 9, wfmt=2, bias=bias.to(dev),
+                  pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin)
+    assert relerr(nchw(y), ref) < 2e-5
+    y1, _ = O.conv(nhwc(x[1:2], dev), wp, 1, H, H, Cin, Cout, 9, wfmt=2, bias=bias.to(dev),
+                   pro=N.PRO_AFFINE_RELU, pro_s=s[1:2].to(dev), pro_t=t[1:2].to(dev), pro_bstride=Cin)
+    assert torch.equal(y1[0], y[1]), 'result depends on the batch composition'
+    # input-gradient form Cout -> Cin with the fused backward of relu(xa*s+t), K-sliced finish
+    xa = torch.randn(B, Cin, H, H, generator=g, requires_grad=True)
+    sa = (0.5 + torch.rand(B, Cin, generator=g)).requires_grad_(True)
+    ta = (0.3 * torch.randn(B, Cin, generator=g)).requires_grad_(True)
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    F.conv2d(F.relu(xa * sa.view(B, Cin, 1, 1) + ta.view(B, Cin, 1, 1)), w, None, padding=1).backward(dy)
+    wt = O.pack_conv_weight(w.to(dev), 9, Cin, Cout, flip=True, wfmt=2)
+    dd = N.P2LConv()
+    dd.B, dd.H, dd.W, dd.Cin, dd.Cout, dd.taps, dd.x_ld, dd.wfmt, dd.splitk = B, H, H, Cout, Cin, 9, Cout, 2, 1
+    sk = N.lib().p2l_conv_suggest_splitk(C.byref(dd))
+    assert sk == N.lib().p2l_wino_split_factor(H, H, Cout, Cin)      # (1 for 32^2 256->512: a full-grid layer)
+    dx, ds, dt = O.conv_dgrad_arb(nhwc(dy, dev), wt, B, H, H, Cout, Cin, 9, nhwc(xa.detach(), dev),
+                                  sa.detach().to(dev), ta.detach().to(dev), Cin, wfmt=2, splitk=sk)
+    torch.cuda.synchronize()
+    assert relerr(nchw(dx), xa.grad) < 2e-5
+    assert relerr(ds.cpu(), sa.grad) < 5e-5 and relerr(dt.cpu(), ta.grad) < 5e-5
+
+
 def test_two_host_threads_two_streams_bit_identical(dev, O):
     """the library is re-entrant.  Two host threads drive the same conv layers (direct,
     Winograd 8x16 / 16x16, pointwise: the form travels in P2LConv) on two streams at the same time,
