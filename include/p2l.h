@@ -531,6 +531,10 @@ int p2l_biggan_bwd(const P2LBigGAN* m, int Bn, void* ws, size_t ws_bytes,
 /*       4 = d s, 5 = d t (after bwd),                                       */
 /*       6 = d loss / d (CBN gains | CBN biases) [B][2*cbn_total] (after bwd):*/
 /*           the per-layer gradients the parity tests compare with the oracle */
+/*       7 = input of bn_1 | bn_2 | bn_3 of GenBlock L / 3 (k = L % 3),         */
+/*       8 / 9 = un-pooled phi / g of the self-attention: with 0-3 every       */
+/*           discrete decision of a forward pass (ReLU signs, max-pool winners) */
+/*           can be read back (tests/test_fixed_mask_grad_gpu.py)              */
 int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int L,
                          size_t* float_off, int32_t shape[4]);
 
@@ -555,6 +559,9 @@ typedef struct P2LLossCache {
 size_t p2l_loss_cache_floats(int Bn, int H, int W, size_t nft_off[5],
                              size_t wt_off[5], size_t* wsum_off);
 size_t p2l_projloss_ws_bytes(int Bn, int H, int W);
+/* debug/test hook: float offset + shape [B,h,w,C] of the post-ReLU output of VGG conv idx
+ * (0..12) inside ws after p2l_projloss_fwd */
+int p2l_projloss_ws_lookup(int Bn, int H, int W, int idx, size_t* float_off, int32_t shape[4]);
 /* target/weight/loss_mask: NCHW3 [B,3,H,W] (loss_mask may be NULL)           */
 int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
                          const float* weight, const float* loss_mask, int Bn,

@@ -20,6 +20,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from .masks import relu as _relu, maxpool2 as _maxpool2      # (`tape`: oracle/masks.py; None = plain ops)
+
 # biggan-deep-256 config [3P-recall: config.py BigGANConfig for 'biggan-deep-256']
 CH = 128
 Z_DIM = 128
@@ -73,18 +75,18 @@ def cbn(W, prefix, x, cond, truncation, taps=None):
     return (x - mean) / torch.sqrt(var + BN_EPS) * weight + bias
 
 
-def gen_block(W, p, x, cond, truncation, up, cin, cout, taps=None):
+def gen_block(W, p, x, cond, truncation, up, cin, cout, taps=None, tape=None):
     """GenBlock.forward [3P-recall]: bottleneck 1x1 -> 3x3 -> 3x3 -> 1x1 + shortcut."""
     x0 = x
-    x = F.relu(cbn(W, p + '.bn_0', x, cond, truncation, taps))
+    x = _relu(cbn(W, p + '.bn_0', x, cond, truncation, taps), tape, p + '.bn_0')
     x = F.conv2d(x, W[p + '.conv_0.weight'], W[p + '.conv_0.bias'])
-    x = F.relu(cbn(W, p + '.bn_1', x, cond, truncation, taps))
+    x = _relu(cbn(W, p + '.bn_1', x, cond, truncation, taps), tape, p + '.bn_1')
     if up:
         x = F.interpolate(x, scale_factor=2, mode='nearest')
     x = F.conv2d(x, W[p + '.conv_1.weight'], W[p + '.conv_1.bias'], padding=1)
-    x = F.relu(cbn(W, p + '.bn_2', x, cond, truncation, taps))
+    x = _relu(cbn(W, p + '.bn_2', x, cond, truncation, taps), tape, p + '.bn_2')
     x = F.conv2d(x, W[p + '.conv_2.weight'], W[p + '.conv_2.bias'], padding=1)
-    x = F.relu(cbn(W, p + '.bn_3', x, cond, truncation, taps))
+    x = _relu(cbn(W, p + '.bn_3', x, cond, truncation, taps), tape, p + '.bn_3')
     x = F.conv2d(x, W[p + '.conv_3.weight'], W[p + '.conv_3.bias'])
     if cin != cout:
         x0 = x0[:, :cin // 2]
@@ -93,20 +95,20 @@ def gen_block(W, p, x, cond, truncation, up, cin, cout, taps=None):
     return x + x0
 
 
-def self_attn(W, p, x):
+def self_attn(W, p, x, tape=None):
     """SelfAttn.forward [3P-recall]."""
     b, ch, h, w = x.shape
     theta = F.conv2d(x, W[p + '.snconv1x1_theta.weight']).view(b, ch // 8, h * w)
-    phi = F.max_pool2d(F.conv2d(x, W[p + '.snconv1x1_phi.weight']), 2, 2).view(b, ch // 8, h * w // 4)
+    phi = _maxpool2(F.conv2d(x, W[p + '.snconv1x1_phi.weight']), tape, p + '.phi').view(b, ch // 8, h * w // 4)
     attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
-    g = F.max_pool2d(F.conv2d(x, W[p + '.snconv1x1_g.weight']), 2, 2).view(b, ch // 2, h * w // 4)
+    g = _maxpool2(F.conv2d(x, W[p + '.snconv1x1_g.weight']), tape, p + '.g').view(b, ch // 2, h * w // 4)
     attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(b, ch // 2, h, w)
     attn_g = F.conv2d(attn_g, W[p + '.snconv1x1_o_conv.weight'])
     return x + W[p + '.gamma'] * attn_g
 
 
 def generator_forward(W, cond, truncation=1.0, ch=CH, layers=LAYERS, attn_pos=ATTN_POS,
-                      return_intermediates=False, cbn_taps=None):
+                      return_intermediates=False, cbn_taps=None, tape=None):
     """Generator.forward [3P-recall]; `cond` = cat(z, class_embedding) [B, 2*z_dim]."""
     inter = {}
     z = F.linear(cond, W['generator.gen_z.weight'], W['generator.gen_z.bias'])
@@ -115,15 +117,15 @@ def generator_forward(W, cond, truncation=1.0, ch=CH, layers=LAYERS, attn_pos=AT
     for i, spec in enumerate(layer_table(ch, layers, attn_pos)):
         p = 'generator.layers.%d' % i
         if spec[0] == 'attn':
-            z = self_attn(W, p, z)
+            z = self_attn(W, p, z, tape)
         else:
             _, up, cin, cout = spec
-            z = gen_block(W, p, z, cond, truncation, up, cin, cout, cbn_taps)
+            z = gen_block(W, p, z, cond, truncation, up, cin, cout, cbn_taps, tape)
         inter['layer%d' % i] = z
     mean, var = _bn_stats(W['generator.bn.running_means'], W['generator.bn.running_vars'], truncation)
     z = F.batch_norm(z, mean, var, W['generator.bn.weight'], W['generator.bn.bias'],
                      training=False, momentum=0.0, eps=BN_EPS)
-    z = F.relu(z)
+    z = _relu(z, tape, 'generator.bn')
     z = F.conv2d(z, W['generator.conv_to_rgb.weight'], W['generator.conv_to_rgb.bias'], padding=1)
     z = z[:, :3]
     out = torch.tanh(z)

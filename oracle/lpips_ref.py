@@ -74,21 +74,27 @@ def _weighted(loss, weight, loss_mask):         # loss_functions.py:119-123 / :1
     return loss
 
 
-def reconstruction_loss(output, target, weight=None, loss_mask=None, loss_type='l1'):
-    """ReconstructionLoss.__call__ (loss_functions.py:117-124)."""
+def reconstruction_loss(output, target, weight=None, loss_mask=None, loss_type='l1', tape=None):
+    """ReconstructionLoss.__call__ (loss_functions.py:117-124).  `tape` (oracle/masks.py): the
+    sign of (output - target) per pixel is a discrete decision of the L1 term."""
     fn = l1_loss if loss_type in ['l1', 1] else l2_loss
+    if tape is not None and fn is l1_loss:
+        return _weighted(tape.abs_diff(output, target, 'l1'), weight, loss_mask)
     return _weighted(fn(output, target), weight, loss_mask)
 
 
-def vgg_features(Wv, x):
+def vgg_features(Wv, x, tape=None):
     """torchvision vgg16.features sliced as lpips.pretrained_networks.vgg16 does
-    [3P-recall]: returns relu1_2, relu2_2, relu3_3, relu4_3, relu5_3."""
+    [3P-recall]: returns relu1_2, relu2_2, relu3_3, relu4_3, relu5_3.
+    `tape` (oracle/masks.py): record / replay of the ReLU signs and max-pool winners."""
+    from .masks import relu as _relu, maxpool2 as _maxpool2
     taps, ci = [], 0
     for item in VGG_CFG:
         if item == 'M':
-            x = F.max_pool2d(x, 2, 2)
+            x = _maxpool2(x, tape, 'vgg.pool%d' % ci)
         else:
-            x = F.relu(F.conv2d(x, Wv['vgg.conv%d.weight' % ci], Wv['vgg.conv%d.bias' % ci], padding=1))
+            x = _relu(F.conv2d(x, Wv['vgg.conv%d.weight' % ci], Wv['vgg.conv%d.bias' % ci], padding=1),
+                      tape, 'vgg.conv%d' % ci)
             if ci in VGG_TAPS_AFTER_CONV:
                 taps.append(x)
             ci += 1
@@ -114,12 +120,13 @@ def normalize_tensor(f, eps=1e-10):
     return f / (norm + eps)
 
 
-def lpips_spatial(Wv, in0, in1):
-    """lpips.LPIPS(net='vgg', spatial=True).forward(in0, in1) -> [B,1,H,W]  [3P-recall]."""
+def lpips_spatial(Wv, in0, in1, tape=None):
+    """lpips.LPIPS(net='vgg', spatial=True).forward(in0, in1) -> [B,1,H,W]  [3P-recall].
+    `tape` applies to the features of in0 (the generated image: the differentiated pass)."""
     shift = torch.tensor(LPIPS_SHIFT, dtype=in0.dtype).view(1, 3, 1, 1)
     scale = torch.tensor(LPIPS_SCALE, dtype=in0.dtype).view(1, 3, 1, 1)
     feats = alex_features if 'alex.conv0.weight' in Wv else vgg_features
-    f0 = feats(Wv, (in0 - shift) / scale)
+    f0 = feats(Wv, (in0 - shift) / scale, tape) if tape is not None else feats(Wv, (in0 - shift) / scale)
     f1 = feats(Wv, (in1 - shift) / scale)
     val = None
     for kk in range(len(f0)):
@@ -130,13 +137,13 @@ def lpips_spatial(Wv, in0, in1):
     return val
 
 
-def perceptual_loss(Wv, output, target, weight=None, loss_mask=None):
+def perceptual_loss(Wv, output, target, weight=None, loss_mask=None, tape=None):
     """PerceptualLoss.__call__ (loss_functions.py:140-148)."""
-    return _weighted(lpips_spatial(Wv, output, target), weight, loss_mask)
+    return _weighted(lpips_spatial(Wv, output, target, tape), weight, loss_mask)
 
 
-def projection_loss(Wv, output, target, weight=None, loss_mask=None, beta=10):
+def projection_loss(Wv, output, target, weight=None, loss_mask=None, beta=10, tape=None):
     """ProjectionLoss.__call__ (loss_functions.py:97-100): rec + beta * per."""
-    rec = reconstruction_loss(output, target, weight, loss_mask)
-    per = perceptual_loss(Wv, output, target, weight, loss_mask)
+    rec = reconstruction_loss(output, target, weight, loss_mask, tape=tape)
+    per = perceptual_loss(Wv, output, target, weight, loss_mask, tape)
     return rec + beta * per

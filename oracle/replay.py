@@ -1,0 +1,73 @@
+"""ORACLE (test infrastructure): reads the discrete decisions of a NATIVE forward pass back from
+the product's workspaces, in the order the CPU oracle takes them (oracle/masks.py DecisionTape):
+49 generator ReLUs (input tensor x and the folded CBN affine s, t: sign of x*s + t), the two
+attention max-pools, the sign of (out - target) of the L1 term, 13 VGG ReLUs and 4 VGG max-pools.
+Uses the test hooks p2l_biggan_ws_lookup / p2l_projloss_ws_lookup.
+
+Only tests/ and __graft_entry__.smoke() may import this module."""
+import ctypes as C
+
+import torch
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def native_decisions(model, loss_fn, W, B, dev, out, target, diag=None):
+    """tape items (oracle call order: generator, L1 term, VGG of the generated image) read back
+    from the workspaces of the LAST native forward of `model` / `loss_fn` on B candidates;
+    `out` = the image the native loss saw, `target` = its target (device tensors, NCHW)"""
+    from pix2latent_amd import _native as N
+    from oracle import biggan_ref as R
+    from oracle.masks import winner_mask
+    items = []
+    d = model._desc
+    s_all, t_all = model.saved_activation(2), model.saved_activation(3)      # [B,1,1,cbn_total]
+    s_all, t_all = s_all.view(B, -1), t_all.view(B, -1)
+    prev = model.saved_activation(1)                                          # gen_z output, NHWC
+    bi = 0
+    for i, spec in enumerate(R.layer_table()):
+        p = 'generator.layers.%d' % i
+        if spec[0] == 'attn':
+            for what, nm in ((8, '.phi'), (9, '.g')):
+                items.append((p + nm, 'pool', winner_mask(_nchw(model.saved_activation(what))).cpu()))
+        else:
+            for k in range(4):
+                x = prev if k == 0 else model.saved_activation(7, 3 * bi + (k - 1))
+                c = x.shape[-1]
+                off = d.blocks[bi].cbn_off[k]
+                sv, tv = s_all[:, off:off + c].view(B, 1, 1, c), t_all[:, off:off + c].view(B, 1, 1, c)
+                pre = torch.addcmul(tv, x, sv)
+                if diag is not None:
+                    pre_b = (x * sv) + tv
+                    pre_c = x.double() * sv.double() + tv.double()
+                    amb = (pre_c.abs() < 4e-7 * (x.double() * sv.double()).abs() + 4e-7 * tv.double().abs())
+                    diag.append(('%s.bn_%d' % (p, k), [int(v) for v in ((pre > 0) != (pre_b > 0)).flatten(1).sum(1)],
+                                 [int(v) for v in ((pre > 0) != (pre_c > 0)).flatten(1).sum(1)],
+                                 [int(v) for v in amb.flatten(1).sum(1)]))
+                items.append(('%s.bn_%d' % (p, k), 'relu', _nchw(pre > 0).cpu()))
+            bi += 1
+        prev = model.saved_activation(0, i)
+    # tail: unconditional BN folded as the plan folds it
+    mean, var = R._bn_stats(W['generator.bn.running_means'], W['generator.bn.running_vars'], 1.0)
+    s = (W['generator.bn.weight'] / torch.sqrt(var + R.BN_EPS)).to(dev)
+    t = (W['generator.bn.bias'] - mean * W['generator.bn.weight'] / torch.sqrt(var + R.BN_EPS)).to(dev)
+    items.append(('generator.bn', 'relu', _nchw(torch.addcmul(t, prev, s) > 0).cpu()))
+    # L1 term: sign of (out - target) of the pixels the native loss saw
+    items.append(('l1', 'sign', torch.sign(out.detach() - target).cpu()))
+    # VGG of the generated image
+    eng = loss_fn._engine
+    H = Wd = 256
+    lib = N.lib()
+
+    def vgg_y(idx):
+        off, shape = C.c_size_t(0), (C.c_int32 * 4)()
+        N.check(lib.p2l_projloss_ws_lookup(B, H, Wd, idx, C.byref(off), shape), 'p2l_projloss_ws_lookup')
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        return eng.ws[off.value:off.value + n].view(*list(shape))
+    for ci in range(13):
+        if ci in (2, 4, 7, 10):
+            items.append(('vgg.pool%d' % ci, 'pool', winner_mask(_nchw(vgg_y(ci - 1))).cpu()))
+        items.append(('vgg.conv%d' % ci, 'relu', _nchw(vgg_y(ci) > 0).cpu()))
+    return items

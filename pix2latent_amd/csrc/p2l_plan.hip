@@ -320,6 +320,22 @@ extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Li
     *float_off = L.draw; shape[0] = Bn; shape[1] = 1; shape[2] = 1; shape[3] = 2 * m->cbn_total;
     return P2L_OK;
   }
+  if (what == 7) {  // inner activations of GenBlock Lidx / 3: input of bn_1 | bn_2 | bn_3
+    const int bi = Lidx / 3, kk = Lidx % 3;
+    if (bi < 0 || bi >= m->n_blocks) return P2L_EINVAL;
+    const BGBlockOff& o = L.blk[bi];
+    *float_off = kk == 0 ? o.h1 : kk == 1 ? o.h2 : o.h3;
+    const int r = kk == 0 ? o.H : o.Ho;
+    shape[0] = Bn; shape[1] = r; shape[2] = r; shape[3] = m->blocks[bi].cin / 4;
+    return P2L_OK;
+  }
+  if (what == 8 || what == 9) {  // un-pooled phi / g of the self-attention
+    if (m->attn_before < 0 || m->attn_before >= m->n_blocks) return P2L_EINVAL;
+    *float_off = what == 8 ? L.att_phi : L.att_g;
+    shape[0] = Bn; shape[1] = L.att_H; shape[2] = L.att_H;
+    shape[3] = what == 8 ? m->attn_ch / 8 : m->attn_ch / 2;
+    return P2L_OK;
+  }
   if (what != 0) return P2L_EINVAL;
   // ModuleList index -> block index (SelfAttn occupies index attn_before)
   int idx = 0;
@@ -718,6 +734,17 @@ extern "C" size_t p2l_loss_cache_floats(int B, int H, int W, size_t nft_off[5],
   }
   *wsum_off = a.take(B);
   return a.off;
+}
+
+// debug/test hook: float offset + shape of the post-ReLU output of VGG conv `idx` (0..12) in ws
+extern "C" int p2l_projloss_ws_lookup(int B, int H, int W, int idx, size_t* float_off,
+                                      int32_t shape[4]) {
+  if (idx < 0 || idx >= 13 || !float_off || !shape) return P2L_EINVAL;
+  PLLayout L;
+  RET_IF(pl_layout(B, H, W, L));
+  *float_off = L.y[idx];
+  shape[0] = B; shape[1] = H / kVggDiv[idx]; shape[2] = W / kVggDiv[idx]; shape[3] = kVggCout[idx];
+  return P2L_OK;
 }
 
 extern "C" size_t p2l_projloss_ws_bytes(int B, int H, int W) {
