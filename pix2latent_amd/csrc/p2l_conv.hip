@@ -757,6 +757,44 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
   k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + po] = sg;
 }
 
+// Finish of a K-sliced Winograd launch (2 or 4 slices of [B,H,W,Cout] partial outputs): item =
+// one 2x2 quad x FOUR consecutive channels, every access a float4 (the scalar kernel above is
+// made for the 4^2 ... 16^2 split-K layers: 4-byte accesses, 0.8 TB/s on a 9 MB output).  Slices
+// are added in the same fixed order, ((z0 + z1) + (z2 + z3)), then the shared epilogue item runs:
+// bias / residual / activation / mask / pooling, or the fused activation backward with one
+// partial sum per quad (arb_nblk = quads per image, as the scalar finish writes them).
+__global__ __launch_bounds__(256) void conv_splitk_finish4(const ConvK k) {
+  const int Hh = k.H >> 1, Wh = k.W >> 1, C4 = k.n_store >> 2;
+  const size_t total = (size_t)k.B * Hh * Wh * C4;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx % C4) * 4;
+  size_t q = idx / C4;
+  const int qx = (int)(q % Wh);
+  q /= Wh;
+  const int qy = (int)(q % Hh);
+  const int b = (int)(q / Hh);
+  const size_t mtot = (size_t)k.B * k.H * k.W;
+  f32x4 v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const size_t pix = ((size_t)b * k.H + 2 * qy + (s >> 1)) * k.W + 2 * qx + (s & 1);
+    f32x4 z[4];
+#pragma unroll
+    for (int zz = 0; zz < 4; ++zz)
+      z[zz] = zz < k.splitk ? *reinterpret_cast<const f32x4*>(k.ws + ((size_t)zz * mtot + pix) * k.Cout + n)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    v[s] = ((z[0] + z[1]) + (z[2] + z[3])) * k.alpha;
+  }
+  EpiSums S;
+  epi_item(k, v, b, 2 * qy, 2 * qx, n, 0, 0, 0, S);
+  if (k.arb_x != nullptr) {
+    const size_t po = ((size_t)b * k.arb_nblk + (size_t)qy * Wh + qx) * k.Cout + n;
+    *reinterpret_cast<f32x4*>(k.arb_partial + po) = S.sgx;
+    *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + po) = S.sg;
+  }
+}
+
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
 // its input-gradient conv O->I (K=O, N=I, taps mirrored).
 // bf16x3 packed element: row (idx / 16) holds [x1 k0-15 | x2 k0-15 | x3 k0-15] (96 bytes)
@@ -1177,8 +1215,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     if (rc == P2L_OK && wino_sliced) {
       // the slices meet in the deterministic finish kernel of the direct path: fixed-order sum,
       // then the whole epilogue (bias / residual / activation / fused activation backward)
-      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
-      hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * (k.n_store >> 2);
+      hipLaunchKernelGGL(conv_splitk_finish4, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
       rc = p2l_check_launch();
     }
     if (prof_slot >= 0) {
