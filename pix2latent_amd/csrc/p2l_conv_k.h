@@ -109,11 +109,20 @@ __device__ __forceinline__ f32x4 sub4(const f32x4 a, const f32x4 b) {
   const f32x2 lo = pk_sub(f32x2{a.x, a.y}, f32x2{b.x, b.y}), hi = pk_sub(f32x2{a.z, a.w}, f32x2{b.z, b.w});
   return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
+// v - (the two bf16 values of p): shift / mask back to fp32 + two subtractions.
+// (Tried: gfx950's v_dot2c_f32_bf16 with the selectors (-1, 0) / (0, -1) takes one half of a packed
+// pair off an fp32 value in ONE instruction -- 3 instead of 5 VALU per split stage, bit-identical
+// residuals (tools/micro/split_exact.hip).  But a DOT instruction holds the matrix pipe like
+// v_pk_add_f32 does (tools/micro/issue_rate.hip rows "dot2c": +12 cycles each next to an MFMA): the
+// 16x16 Winograd kernel got 8 % slower, the kernels with a separate split phase did not change, the
+// step went 922 -> 898 evals/s.  Also: hipcc emits the selector (-1, 0) = 0x0000BF80 as the inline
+// constant "-1.0", which the hardware reads as 0xBF800000 = (0, -1) in this instruction.)
+__device__ __forceinline__ f32x2 resid2(const f32x2 v, const bf16x2 p) { return pk_sub(v, widen2(p)); }
 __device__ __forceinline__ void split3_pair(const f32x2 v, bf16x2& h, bf16x2& m, bf16x2& l) {
   h = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = pk_sub(v, widen2(h));
+  const f32x2 r1 = resid2(v, h);
   m = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = pk_sub(r1, widen2(m));
+  const f32x2 r2 = resid2(r1, m);
   l = __builtin_convertvector(r2, bf16x2);
 }
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     rr[0] = f32x2{q0.x, q0.y}; rr[1] = f32x2{q0.z, q0.w};
     rr[2] = f32x2{q1.x, q1.y}; rr[3] = f32x2{q1.z, q1.w};
   };
-  auto resid = [&](const f32x2 v, const bf16x2 piece) { return pk_sub(v, widen2(piece)); };
+  auto resid = [&](const f32x2 v, const bf16x2 piece) { return resid2(v, piece); };
   auto hstage = [&]() {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {

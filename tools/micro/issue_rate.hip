@@ -23,6 +23,15 @@ __device__ __forceinline__ void filler(unsigned& a, unsigned& b, f32x2& p, f32x2
     else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(p.x), "v"(p.y));
   } else if (TYPE == 5) asm volatile("s_nop 0");
   else if (TYPE == 6) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+  else if (TYPE == 7) asm volatile("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(p.x) : "v"(a), "s"(0x0000BF80u));
+  else if (TYPE == 9) asm volatile("v_dot2c_f32_bf16 %0, 0xbf800000, %1" : "+v"(p.x) : "v"(a));
+  else if (TYPE == 10) asm volatile("v_dot2c_f32_bf16 %0, -1.0, %1" : "+v"(p.x) : "v"(a));
+  else if (TYPE == 8) {                                  // the split stage with v_dot2c residuals, one of 3 per call
+    const int m = i % 3;
+    if (m == 0) asm volatile("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(p.x) : "v"(a), "s"(0x0000BF80u));
+    else if (m == 1) asm volatile("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(p.y) : "v"(a), "s"(0xBF800000u));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(a) : "v"(p.x), "v"(p.y));
+  }
 }
 
 template <int TYPE, int NF, bool MFMA>
@@ -82,6 +91,6 @@ int main() {
   // warm the clocks
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<0, 4, true>), dim3(256), dim3(512), 0, 0, d, c, 2000);
   hipDeviceSynchronize();
-  ROW(0, "v_and") ROW(1, "cvt_pk") ROW(2, "pk_add") ROW(3, "v_sub") ROW(4, "splitmix") ROW(5, "s_nop") ROW(6, "s_add")
+  ROW(0, "v_and") ROW(1, "cvt_pk") ROW(2, "pk_add") ROW(3, "v_sub") ROW(4, "splitmix") ROW(5, "s_nop") ROW(6, "s_add") ROW(7, "dot2c") ROW(8, "dotmix") ROW(9, "dot2c_lit") ROW(10, "dot2c_inl")
   return 0;
 }
