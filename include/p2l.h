@@ -217,6 +217,17 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     image: a function of the layer shape only, never of the batch) in the
  *     Winograd form (2.25x fewer matrix products, csrc/p2l_wino.hip) and everything else on the
  *     direct kernel.  Results agree with P2L_WFMT_BF16X3 to fp32 rounding.
+ *     The buffer ends with a SECOND transform-domain image in the fp16 x 2 arithmetic of the
+ *     16x16-pixel Winograd kernel: every operand is scaled by a power of two (weights: per layer,
+ *     at pack time; activations: per image, from a max-|x| pass in front of the launch) so that
+ *     its largest value sits at 2^13..2^15, and split into TWO round-to-nearest fp16 pieces
+ *     (x = h + m to 1 ulp of fp32; elements more than 2^29 below the maximum of their image lose
+ *     relative precision, 2^-40 of the maximum in absolute terms); the product is accumulated in
+ *     fp32 from THREE v_mfma_f32_32x32x16_f16 cross terms (h h, h m, m h) and un-scaled exactly in
+ *     the epilogue: half the matrix work and a third of the split instructions of bf16 x 3.
+ *     [K_pad/16][16][N_pad/32][2 pieces][64 lanes] x 16 B, then 4 floats (the bits of max |w|).
+ *     Needs 256 B of workspace per image (p2l_conv_workspace_bytes counts them); without it, or
+ *     on P2L_FORM_WINO_BF3, the launch keeps the bf16 x 3 arithmetic.
  *     p2l_packed_weight_floats() gives the buffer size of any format.
  *   P2L_WFMT_PW (1x1 convs only): the fp32 layout of p2l_pack_conv_weight FOLLOWED by the
  *     bf16x3 image [K_pad/16][N_pad/32][32 rows][96 B] (p2l_pack_conv_weight_pw).  Layers of at
@@ -250,7 +261,8 @@ enum {
   P2L_FORM_WINO_ANY = 2,     /* Winograd form for every eligible shape, small grids too (tests) */
   P2L_FORM_WINO_8X16 = 4,    /* the 8x16-pixel Winograd kernel even where 16x16 fits (tests)   */
   P2L_FORM_NO_PW = 8,        /* P2L_WFMT_PW weights, but the exact-fp32 1x1 kernel             */
-  P2L_FORM_NO_THIN = 16      /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
+  P2L_FORM_NO_THIN = 16,     /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
+  P2L_FORM_WINO_BF3 = 32     /* 16x16 Winograd kernel in the bf16 x 3 arithmetic, not fp16 x 2  */
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

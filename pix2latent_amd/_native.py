@@ -125,7 +125,7 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
 WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW, WFMT_BF16X3T = 0, 1, 2, 3, 4
 WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM = 0x10, 0x20, 0x40
 # P2LConv.form (per launch; the library has no switches of its own)
-FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN = 0, 1, 2, 4, 8, 16
+FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN, FORM_WINO_BF3 = 0, 1, 2, 4, 8, 16, 32
 
 
 def default_wfmt():

@@ -1062,9 +1062,16 @@ extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   return s;
 }
 
+// the 16x16 Winograd kernel in the fp16 x 2 arithmetic: 64 partial maxima per image in front of
+// the split-K slices
+static bool wino_h2(const P2LConv* d) {
+  return wino_shape(d) && d->H % 16 == 0 && d->W % 16 == 0 &&
+         !(d->form & (P2L_FORM_WINO_8X16 | P2L_FORM_WINO_BF3));
+}
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
-  if (d->splitk <= 1) return 0;
-  return (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
+  const size_t h2 = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  if (d->splitk <= 1) return h2;
+  return h2 + (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
 }
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
@@ -1151,8 +1158,17 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (k.splitk > k.nchunks) k.splitk = k.nchunks;
   k.chunks_per_split = cdiv(k.nchunks, k.splitk);
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
+  // fp16 x 2 Winograd: the partial maxima sit at the head of the workspace; a caller that gives
+  // none gets the bf16 x 3 arithmetic
+  const size_t h2_bytes = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  const bool use_h2 = h2_bytes && workspace &&
+                      ws_bytes >= h2_bytes + (k.splitk > 1 ? (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float) : 0);
+  if (use_h2) {
+    k.amax = (float*)workspace;
+    k.ws = (float*)workspace + (size_t)d->B * 64;
+  }
   if (k.splitk > 1) {
-    const size_t need = (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
+    const size_t need = (use_h2 ? h2_bytes : 0) + (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
     if (!workspace || ws_bytes < need) return P2L_EWS;
     if (arb) k.arb_nblk = (d->H >> 1) * (d->W >> 1);    // finish kernel: one partial per quad
   }
@@ -1201,6 +1217,10 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (wino_shape(d)) {
     ConvK kw = k;                    // (arb_nblk keeps the 128-pixel tiling of the caller's buffer)
     kw.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
+    if (use_h2) {
+      kw.w += p2l_wino_weight_floats(d->Cout, d->Cin);
+      kw.w_tail = reinterpret_cast<const unsigned*>(kw.w + (size_t)d->Cout * d->Cin * 16);
+    }
     kw.tiles_x = d->W / 16; kw.tiles_y = d->H / 8;
     kw.n_mtiles = d->B * kw.tiles_x * kw.tiles_y;
     kw.n_ntiles = d->Cout / 64;
@@ -1568,7 +1588,7 @@ extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int w
   if (wfmt == P2L_WFMT_PW) return direct + direct * 3 / 2;     // fp32 layout + bf16x3 image
   size_t n = direct * 3 / 2;
   if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
-    n += p2l_wino_weight_floats(N_pad, K_pad);
+    n += p2l_wino_weight_floats(N_pad, K_pad) + p2l_wino_h2_weight_floats(N_pad, K_pad);
   if (wfmt == P2L_WFMT_BF16X3T && taps == 9) n += p2l_thin_weight_floats(N_pad, K_pad);
   return n;
 }

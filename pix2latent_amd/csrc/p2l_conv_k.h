@@ -47,6 +47,10 @@ struct ConvK {
   // 2-way bank conflict: rows 16 apart share a bank window for the 96-byte row).
   int hp;
   int form;  // P2LConv.form of this launch (kernel-form choice of the launchers)
+  // fp16 x 2 arithmetic of the 16x16 Winograd kernel (p2l_wino.hip): [B][64] partial maxima of
+  // |input| per image (written by the pass in front of the launch), bits of max |weight|
+  float* amax;
+  const unsigned* w_tail;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -393,6 +397,7 @@ int p2l_thinout_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);
 extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad);
 extern "C" int p2l_wino_split_factor(int H, int W, int Cin, int Cout);
+extern "C" size_t p2l_wino_h2_weight_floats(int N_pad, int K_pad);
 int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
                   float* dst, hipStream_t st);
 int p2l_wino_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

@@ -344,7 +344,35 @@ constexpr TxTable kTx{};
 // ABL (lab builds only, -DP2L_LAB): timing ablations -- results are wrong when set.
 //   1 weights loaded once | 2 no input transform | 4 no barriers in the loop | 8 no m / l pieces
 //   16 no MFMAs | 32 fragment values read once | 64 no patch loads / writes
-template <int PRO, int ABL = 0>
+// H2: the fp16 x 2 arithmetic (include/p2l.h, P2L_WFMT_BF16X3W): the staged patch is scaled by the
+// image's power of two, a fragment is split into two fp16 pieces (cvt_pk | 2 v_fma_mix | cvt_pk per
+// pair: 4 instructions instead of 11) and multiplied by three MFMAs per N-tile instead of six.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// Transform micro-operations of the H2 form: MFMA gap G = 6 * step + gap; every gap behind the
+// patch barrier (gap 3 of step 0) carries one of the 20.
+struct TxTableH {
+  int slot[24];
+  constexpr TxTableH() : slot{} {
+    constexpr int seq[20] = {0 * 8 + 0, 0 * 8 + 1, 0 * 8 + 2, 0 * 8 + 3,
+                             1 * 8 + 0, 1 * 8 + 1, 1 * 8 + 2, 1 * 8 + 3, 1 * 8 + 4, 1 * 8 + 5,
+                             2 * 8 + 0, 2 * 8 + 1, 2 * 8 + 2, 2 * 8 + 3,
+                             3 * 8 + 0, 3 * 8 + 1, 3 * 8 + 2, 3 * 8 + 3, 3 * 8 + 4, 3 * 8 + 5};
+    for (int g = 0; g < 24; ++g) slot[g] = g < 4 ? -1 : seq[g - 4];
+  }
+};
+constexpr TxTableH kTxH{};
+// power-of-two scale that puts max |x| (bits `mx`, grown 4x by the input transform) below 2^15,
+// and its inverse
+__device__ __forceinline__ void h2_scales(unsigned mx, float& scale, float& inv) {
+  int E = (int)((mx >> 23) & 0xffu);
+  E = E < 40 ? 40 : (E > 254 ? 254 : E);
+  scale = __builtin_bit_cast(float, (unsigned)(266 - E) << 23);      // 2^(139 - E)
+  inv = __builtin_bit_cast(float, (unsigned)(E - 12) << 23);         // 2^(E - 139)
+}
+
+template <int PRO, int ABL = 0, bool H2 = false>
 __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;
@@ -369,6 +397,18 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int z = blockIdx.y;
   const int c_lo = z * k.chunks_per_split;
   const int nchunks = min(k.chunks_per_split, k.nchunks - c_lo);
+
+  // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
+  float x_scale = 1.f, out_scale = 1.f;
+  if (H2) {
+    float a = k.amax[b * 64 + lane];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    float inv_x, sw, inv_w;
+    h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
+    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
+    out_scale = inv_x * inv_w;
+  }
 
   // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
   constexpr int A_ITERS = 3;
@@ -420,6 +460,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       }
     }
     if (PRO != P2L_PRO_NONE && !((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // padding is 0 AFTER the prologue
+    if (H2) v = v * x_scale;
     *reinterpret_cast<f32x4*>(raw + a_loff0 + it * 128 * WN_RAW_PITCH) = v;
   };
 
@@ -472,17 +513,18 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   // (buffer resource over the whole image: lane offset in a register, everything else scalar)
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(k.w))), 0,
-      __builtin_amdgcn_readfirstlane(k.Cout * k.nchunks * (16 * 96)), 0x00020000);
+      __builtin_amdgcn_readfirstlane(k.Cout * k.nchunks * (16 * (H2 ? 64 : 96))), 0x00020000);
   const int w_lane = lane * 16;
-  f32x4 bw[2][2][3];                                   // [set][N-tile][piece]
+  constexpr int NP = H2 ? 2 : 3;                       // pieces of a weight
+  f32x4 bw[2][2][NP];                                  // [set][N-tile][piece]
   auto load_b = [&](int c, int fi, int set) {
-    const int base = (((c_lo + c) * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (3 * 64 * 16);
+    const int base = (((c_lo + c) * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (NP * 64 * 16);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < NP; ++p)
         bw[set][j][p] = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane + p * 1024, base + j * 3072, 0));
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane + p * 1024, base + j * (NP * 1024), 0));
   };
 
   f32x16 acc[2][2][2];                                 // [freq][M-tile][N-tile]
@@ -622,6 +664,77 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     P2L_TR(1 + s, c);
   };
 
+  // ---- fp16 x 2 form of the step: 6 MFMAs per fragment ------------------------------------
+  //   M0 h b1 (N-tile 0) | gaps 0-3: the m pieces pair by pair (2 v_fma_mix + 1 cvt_pk each), the
+  //   patch write of step 0 | M1 h b1 (1) | M2 h b2 (0) | M3 h b2 (1) | [step 0: patch barrier]
+  //   next fragment requested | M4 m b1 (0) | gap 4: loads | M5 m b1 (1) | gap 5: next h pieces.
+  //   The transform of the next chunk rides in every gap behind the patch barrier (kTxH).
+  h16x2 hhH[4], mmH[4];
+  auto hstageH = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      hhH[p] = __builtin_convertvector(rr[p], h16x2);
+      asm volatile("" : "+v"(hhH[p]));
+    }
+  };
+  auto cat8H = [](const h16x2 (&q)[4]) {
+    const h16x4 lo = __builtin_shufflevector(q[0], q[1], 0, 1, 2, 3);
+    const h16x4 hi = __builtin_shufflevector(q[2], q[3], 0, 1, 2, 3);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  // v - piece as one v_fma_mix_f32 per value (fp16 source widened inside the instruction; it
+  // shares the MFMA shadow like a plain VALU instruction: tools/micro/issue_rate.hip "fma_mix")
+  // (written as fma(float(piece), -1, v) hipcc emits cvt + cvt_sdwa + 2 sub instead)
+  auto residH = [&](const f32x2 v, const h16x2 piece) {
+    f32x2 r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(piece), "s"(-1.f), "v"(v.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(piece), "s"(-1.f), "v"(v.y));
+    return r;
+  };
+#define P2L_MFH(A, FI, J, P, M)                                                               \
+  acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                     \
+      A, __builtin_bit_cast(h16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                    \
+  P2L_SB()
+#define P2L_TXH(G)                                                                            \
+  if (more && kTxH.slot[G] >= 0) tx(kTxH.slot[G] >> 3, kTxH.slot[G] & 7, Vn)
+  auto stepH = [&](auto S_, auto MORE_, const float* Vc, float* Vn, int c) {
+    constexpr int s = decltype(S_)::value;
+    constexpr bool more = decltype(MORE_)::value;
+    constexpr int fi = s >> 1, m = s & 1;
+    const h16x8 a1 = cat8H(hhH);
+    P2L_MFH(a1, fi, 0, 0, m);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      rr[p] = residH(rr[p], hhH[p]);
+      mmH[p] = __builtin_convertvector(rr[p], h16x2);
+      P2L_PIN(mmH[p]);
+      if (s == 0 && p < 3 && more) write_raw1(p);
+      P2L_TXH(6 * s + p);
+      P2L_SB();
+      if (p == 0) { P2L_MFH(a1, fi, 1, 0, m); }
+      if (p == 1) { P2L_MFH(a1, fi, 0, 1, m); }
+      if (p == 2) { P2L_MFH(a1, fi, 1, 1, m); }
+    }
+    const h16x8 a2 = cat8H(mmH);
+    if (s == 0) __syncthreads();             // the patch of chunk c+1 becomes visible
+    if (s + 1 < 4) lda(Vc, s + 1);           // (the residuals are dead)
+    P2L_SB();
+    P2L_MFH(a2, fi, 0, 0, m);
+    // gap 4: weight fragments / next patch
+    if (s == 0) load_b(c, 1, 1);
+    else if (s == 2 && more) load_b(c + 1, 0, 0);
+    else if (s == 1 && more) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
+    P2L_TXH(6 * s + 4);
+    P2L_SB();
+    P2L_MFH(a2, fi, 1, 0, m);
+    // gap 5: h pieces of the next fragment
+    if (s + 1 < 4) hstageH();
+    P2L_TXH(6 * s + 5);
+    P2L_SB();
+  };
+#undef P2L_TXH
+#undef P2L_MFH
+
   load_raw(0);
   load_b(0, 0, 0);
 #pragma unroll
@@ -641,12 +754,21 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
     P2L_TR(0, c);
-    if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstage(); }
-    P2L_SB();
-    step(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
-    step(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
-    step(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
-    step(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
+    if constexpr (H2) {
+      lda(Vc, 0); hstageH();
+      P2L_SB();
+      stepH(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
+    } else {
+      if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstage(); }
+      P2L_SB();
+      step(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
+      step(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
+      step(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
+      step(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
+    }
     if (!(ABL & 4)) __syncthreads();    // V(c+1) complete; every read of V(c) and of the patch done
     P2L_TR(5, c);
   }
@@ -654,12 +776,21 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     const int c = nchunks - 1;
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     lda(Vc, 0);
-    hstage();
-    P2L_SB();
-    step(std::integral_constant<int, 0>{}, F_{}, Vc, Vc, c);
-    step(std::integral_constant<int, 1>{}, F_{}, Vc, Vc, c);
-    step(std::integral_constant<int, 2>{}, F_{}, Vc, Vc, c);
-    step(std::integral_constant<int, 3>{}, F_{}, Vc, Vc, c);
+    if constexpr (H2) {
+      hstageH();
+      P2L_SB();
+      stepH(std::integral_constant<int, 0>{}, F_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 1>{}, F_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 2>{}, F_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 3>{}, F_{}, Vc, Vc, c);
+    } else {
+      hstage();
+      P2L_SB();
+      step(std::integral_constant<int, 0>{}, F_{}, Vc, Vc, c);
+      step(std::integral_constant<int, 1>{}, F_{}, Vc, Vc, c);
+      step(std::integral_constant<int, 2>{}, F_{}, Vc, Vc, c);
+      step(std::integral_constant<int, 3>{}, F_{}, Vc, Vc, c);
+    }
     __syncthreads();
   }
 #undef P2L_TX
@@ -674,7 +805,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int ety = e_t >> 3, etx = e_t & 7;
   float* red = raw;                                      // [2 kinds][8 waves][32]
   const bool split = k.splitk > 1;
-  const float alpha = split ? 1.f : k.alpha;             // (the finish kernel scales the sum)
+  const float alpha = (split ? 1.f : k.alpha) * out_scale;   // (the finish kernel scales the sum)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -789,11 +920,91 @@ __global__ void wino_pack_kernel(const float* w, float* dst, int O, int I, int N
   out[0] = p1; out[64] = p2; out[128] = p3;
 }
 
+// ---- fp16 x 2 image of the same U: scaled by the layer's power of two, two fp16 pieces -------
+// tail[0] = bits of max |w| over the layer (|U| <= 2.25 max |w|: the scale leaves that headroom)
+__global__ void wino_wmax_kernel(const float* w, size_t n, unsigned* tail) {
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(tail, __builtin_bit_cast(unsigned, mx));   // (>= 0: bit order = value order)
+}
+__global__ void wino_pack_h2_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
+                                    int transpose_flip, const unsigned* tail) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n_t32 = N_pad >> 5;
+  const size_t total = (size_t)(K_pad >> 4) * 16 * n_t32 * 64;
+  if (idx >= total) return;
+  float scale, inv;
+  h2_scales(tail[0], scale, inv);
+  const int lane = (int)(idx & 63);
+  size_t q = idx >> 6;
+  const int jn = (int)(q % n_t32); q /= n_t32;
+  const int f = (int)(q & 15);
+  const int cc = (int)(q >> 4);
+  const int n = jn * 32 + (lane & 31);
+  const int fi = f >> 2, fj = f & 3;
+  const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  h16x8 p1, p2;
+  for (int e = 0; e < 8; ++e) {
+    const int kk = cc * 16 + (lane >> 5) * 8 + e;
+    double u = 0.0;
+    if (n < N && kk < K) {
+      for (int a = 0; a < 3; ++a)
+        for (int bb = 0; bb < 3; ++bb) {
+          const float g = transpose_flip ? w[(((size_t)kk * I + n) * 3 + (2 - a)) * 3 + (2 - bb)]
+                                         : w[(((size_t)n * I + kk) * 3 + a) * 3 + bb];
+          u += G[fi][a] * (double)g * G[fj][bb];
+        }
+    }
+    const float x = (float)u * scale;                  // (rounded to fp32 first, like the bf16 x 3 image)
+    const _Float16 h = (_Float16)x;
+    p1[e] = h; p2[e] = (_Float16)(x - (float)h);
+  }
+  h16x8* out = reinterpret_cast<h16x8*>(dst) + ((((size_t)cc * 16 + f) * n_t32 + jn) * 2) * 64 + lane;
+  out[0] = p1; out[64] = p2;
+}
+
+// ---- fp16 x 2: max |x| of every image, 64 partial maxima each (the prologue applied) ---------
+template <int PRO>
+__global__ __launch_bounds__(256) void wino_amax_kernel(const ConvK k) {
+  const int b = blockIdx.y;
+  const int q4 = k.Cin >> 2;
+  const unsigned total = (unsigned)k.H * k.W * q4;
+  const float* xi = k.x + (size_t)b * k.H * k.W * k.x_ld;
+  float mx = 0.f;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += 64 * 256) {
+    const unsigned pix = i / q4, c4 = i - pix * q4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(xi + (size_t)pix * k.x_ld + c4 * 4);
+    if (PRO != P2L_PRO_NONE) {
+      const f32x4 sr = *reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride + c4 * 4);
+      const f32x4 tr = *reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride + c4 * 4);
+      v = v * sr + tr;                                 // (|.| below covers the ReLU form too)
+      if (PRO == P2L_PRO_AFFINE_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) k.amax[b * 64 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 }  // namespace
 
 // floats of the Winograd image for an N_pad x K_pad 3x3 conv (16 frequencies x 6 bytes)
 extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad) {
   return (size_t)N_pad * K_pad * 24;
+}
+// ... and of the fp16 x 2 image behind it (16 frequencies x 4 bytes, then 4 tail floats)
+extern "C" size_t p2l_wino_h2_weight_floats(int N_pad, int K_pad) {
+  return (size_t)N_pad * K_pad * 16 + 4;
 }
 
 // Small-grid layers (16 ... 63 blocks of 8x16x64 per image, H and W multiples of 16): the 16x16
@@ -825,6 +1036,15 @@ int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int t
   const size_t total = (size_t)(K_pad >> 4) * 16 * (N_pad >> 5) * 64;
   hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, dst, O,
                      I, N_pad, K_pad, transpose_flip);
+  // the fp16 x 2 image behind it
+  float* h2 = dst + p2l_wino_weight_floats(N_pad, K_pad);
+  unsigned* tail = reinterpret_cast<unsigned*>(h2 + (size_t)N_pad * K_pad * 16);
+  if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return P2L_ELAUNCH;
+  const size_t nw = (size_t)O * I * 9;
+  hipLaunchKernelGGL(wino_wmax_kernel, dim3((unsigned)(cdiv(nw, 256) < 256 ? cdiv(nw, 256) : 256)), dim3(256),
+                     0, st, w_oihw, nw, tail);
+  hipLaunchKernelGGL(wino_pack_h2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, h2, O,
+                     I, N_pad, K_pad, transpose_flip, tail);
   return p2l_check_launch();
 }
 
@@ -855,7 +1075,7 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL>), grid, block, W16_LDS_BYTES, st, k); \
     return p2l_check_launch();                                                               \
   }
-    if (pro == P2L_PRO_NONE) {
+    if (pro == P2L_PRO_NONE && k.amax == nullptr) {
       switch (g_lab_abl) {
         P2L_W16L(0) P2L_W16L(1) P2L_W16L(2) P2L_W16L(4) P2L_W16L(8) P2L_W16L(16) P2L_W16L(64)
         P2L_W16L(3) P2L_W16L(10) P2L_W16L(67) P2L_W16L(75) P2L_W16L(79) P2L_W16L(111)
@@ -874,6 +1094,24 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
   } while (0)
+#define P2L_W16H(PRO)                                                                        \
+  do {                                                                                       \
+    static std::atomic<bool> attr_set{false};                                                \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO, 0, true>,              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(wino_amax_kernel<PRO>, dim3(64, k.B), dim3(256), 0, st, k);           \
+    hipLaunchKernelGGL((wino16s_conv_kernel<PRO, 0, true>), grid, block, W16_LDS_BYTES, st, k); \
+  } while (0)
+    if (k.amax != nullptr) {                           // fp16 x 2 arithmetic (conv_launch_impl decides)
+      if (pro == P2L_PRO_NONE) P2L_W16H(P2L_PRO_NONE);
+      else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16H(P2L_PRO_AFFINE_RELU);
+      else P2L_W16H(P2L_PRO_AFFINE);
+      return p2l_check_launch();
+    }
+#undef P2L_W16H
     if (pro == P2L_PRO_NONE) P2L_W16S(P2L_PRO_NONE);
     else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16S(P2L_PRO_AFFINE_RELU);
     else P2L_W16S(P2L_PRO_AFFINE);

@@ -80,22 +80,23 @@ CONV_CASES = [
 # P2L_WFMT_BF16X3W (same arithmetic; eligible shapes run in the Winograd F(2x2,3x3) form)
 # P2L_WFMT_PW (1x1 convs: fp32 layout + bf16x3 image; layers >= 32x32 run in the bf16x3 arithmetic)
 # (4 = P2L_WFMT_BF16X3W again, with the 16x16-pixel / 8-wave Winograd kernel forced wherever H, W allow)
-WFMTS = [0, 1, 2, 3, 4]
-WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd', 'pw-bf16x3', 'bf16x3-winograd16']
+# (5 = P2L_WFMT_BF16X3W, 16x16-pixel kernel in its default fp16 x 2 arithmetic; 4 keeps bf16 x 3)
+WFMTS = [0, 1, 2, 3, 4, 5]
+WFMT_IDS = ['f32', 'bf16x3', 'bf16x3-winograd', 'pw-bf16x3', 'bf16x3-winograd16', 'f16x2-winograd16']
 
 
 def _skip_unless_format_applies(wfmt, taps, H=None, ups=False):
-    if (taps == 9 and wfmt == 3) or (taps != 9 and wfmt in (1, 2, 4)):
+    if (taps == 9 and wfmt == 3) or (taps != 9 and wfmt in (1, 2, 4, 5)):
         pytest.skip('weight format does not apply to this kernel size')
-    if wfmt == 4 and (ups or H is None or H % 16):
+    if wfmt in (4, 5) and (ups or H is None or H % 16):
         pytest.skip('the 16x16-pixel Winograd kernel does not take this shape')
 
 
 def _fmt(wfmt):
     """test id 4 -> the real weight format (2) with the 16x16-pixel block shape forced"""
-    if wfmt == 4:
+    if wfmt in (4, 5):
         from pix2latent_amd import _native as N, ops as O
-        O.DEFAULT_FORM = N.FORM_WINO_ANY
+        O.DEFAULT_FORM = N.FORM_WINO_ANY | (N.FORM_WINO_BF3 if wfmt == 4 else 0)
         return 2
     return wfmt
 
@@ -437,8 +438,8 @@ def test_two_host_threads_two_streams_bit_identical(dev, O):
 @pytest.mark.parametrize('arb', [False, True], ids=['forward', 'dgrad-fused-arb'])
 def test_winograd_block_shapes_bit_identical(dev, O, arb):
     """the 8x16-pixel / 4-wave and the 16x16-pixel / 8-wave Winograd kernels do the same
-    additions and products in the same order: which one a launch gets (a grid-size decision,
-    hence batch dependent) must not change a single bit of the result"""
+    additions and products in the same order when both run the bf16 x 3 arithmetic: not a single
+    bit differs"""
     from pix2latent_amd import _native as N
     g = torch.Generator().manual_seed(21)
     B, H, Cin, Cout = 3, 32, 48, 128
@@ -450,7 +451,7 @@ def test_winograd_block_shapes_bit_identical(dev, O, arb):
     bias = (0.1 * torch.randn(Cout, generator=g)).to(dev)
     res = torch.randn(B, H, H, Cout, generator=g).to(dev)
     xa = torch.randn(B, H, H, Cout, generator=g).to(dev)
-    for form in (N.FORM_WINO_ANY | N.FORM_WINO_8X16, N.FORM_WINO_ANY):
+    for form in (N.FORM_WINO_ANY | N.FORM_WINO_8X16, N.FORM_WINO_ANY | N.FORM_WINO_BF3, N.FORM_WINO_ANY):
         O.DEFAULT_FORM = form
         if not arb:
             wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=2)
@@ -464,8 +465,11 @@ def test_winograd_block_shapes_bit_identical(dev, O, arb):
                                           skip=res, skip_C=Cout)
             outs.append((dx.clone(), ds.clone(), dt.clone()))
     torch.cuda.synchronize()
-    for a, b in zip(*outs):
+    for a, b, h in zip(*outs):
         assert torch.equal(a, b)
+        # the 16x16 kernel's default arithmetic (fp16 x 2, per-image power-of-two scales) is a
+        # different rounding of the same fp32-grade products
+        assert (h - a).abs().max().item() <= 2e-5 * a.abs().max().item()
 
 
 def test_arb_finish_deferred_group(dev, O):

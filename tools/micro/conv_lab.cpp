@@ -166,7 +166,8 @@ int main(int argc, char** argv) {
   struct { int H, Cin, Cout; } layers[] = {{64, 256, 256}, {32, 512, 512}, {128, 128, 128}, {256, 64, 64},
                                           {32, 256, 256}, {16, 512, 512}};
   const Form forms[] = {{"direct", P2L_WFMT_BF16X3, 0}, {"wino8", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY | P2L_FORM_WINO_8X16},
-                        {"wino16", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY}};
+                        {"wino16", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY | P2L_FORM_WINO_BF3},
+                        {"wino16 f16x2", P2L_WFMT_BF16X3W, P2L_FORM_WINO_ANY}};
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto L : layers) {
@@ -197,14 +198,16 @@ int main(int argc, char** argv) {
       d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = pro;
       d.pro_bstride = Cin; d.alpha = 1.f; d.act = P2L_ACT_NONE; d.pool = P2L_POOL_NONE; d.y_ld = Cout;
       d.n_store = Cout; d.splitk = 1; d.wfmt = f.wfmt; d.form = f.form;
+      const size_t wsb = p2l_conv_workspace_bytes(&d);
+      void* dws = nullptr; if (wsb) CK(hipMalloc(&dws, wsb));
       CK(hipMemsetAsync(dy, 0xff, ny * 4, st));
       for (int i = 0; i < (pass == 0 && &f == &forms[0] ? 300 : 5); ++i)   // (idle clocks settle first)
-        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, dws, wsb, st));
       CK(hipStreamSynchronize(st));
       const int reps = 30;
       CK(hipEventRecord(e0, st));
       for (int i = 0; i < reps; ++i)
-        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+        PK(p2l_conv_fwd(&d, dx, dwp, nullptr, dsv, dtv, nullptr, nullptr, dy, nullptr, dws, wsb, st));
       CK(hipEventRecord(e1, st));
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
@@ -216,10 +219,10 @@ int main(int argc, char** argv) {
         md = fmax(md, fabs((double)out[i] - ref[i])); mx = fmax(mx, fabs((double)ref[i]));
       }
       const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
-      printf("p%d %2dx%3d^2 %3d->%3d pro%d %-12s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", pass, B, H, Cin, Cout, pro,
+      printf("p%d %2dx%3d^2 %3d->%3d pro%d %-13s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", pass, B, H, Cin, Cout, pro,
              f.name, ms, fl / ms / 1e9, md / (mx + 1e-30), nbad);
       fflush(stdout);
-      CK(hipFree(dwp));
+      CK(hipFree(dwp)); if (dws) CK(hipFree(dws));
     }
     CK(hipFree(dx)); CK(hipFree(dwo)); CK(hipFree(dy)); CK(hipFree(dref)); CK(hipFree(dsv)); CK(hipFree(dtv));
   }

@@ -26,6 +26,22 @@ __device__ __forceinline__ void filler(unsigned& a, unsigned& b, f32x2& p, f32x2
   else if (TYPE == 7) asm volatile("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(p.x) : "v"(a), "s"(0x0000BF80u));
   else if (TYPE == 9) asm volatile("v_dot2c_f32_bf16 %0, 0xbf800000, %1" : "+v"(p.x) : "v"(a));
   else if (TYPE == 10) asm volatile("v_dot2c_f32_bf16 %0, -1.0, %1" : "+v"(p.x) : "v"(a));
+  else if (TYPE == 11) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(p.x), "v"(p.y));
+  else if (TYPE == 12) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(p.x) : "v"(a));
+  else if (TYPE == 13) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p.x) : "v"(a), "v"(q.x));
+  else if (TYPE == 14) {                                 // fp16 x 2 split of a pair, cvt + sub form: 5 per call
+    const int m = i % 5;
+    if (m == 0) asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(q.x) : "v"(a));
+    else if (m == 1) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(q.y) : "v"(a));
+    else if (m == 2) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(p.x) : "v"(q.x));
+    else if (m == 3) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(p.y) : "v"(q.y));
+    else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(p.x), "v"(p.y));
+  } else if (TYPE == 15) {                               // fp16 x 2 split of a pair, v_fma_mix form: 3 per call
+    const int m = i % 3;
+    if (m == 0) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(p.x) : "v"(a), "v"(q.x));
+    else if (m == 1) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p.y) : "v"(a), "v"(q.x));
+    else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(p.x), "v"(p.y));
+  }
   else if (TYPE == 8) {                                  // the split stage with v_dot2c residuals, one of 3 per call
     const int m = i % 3;
     if (m == 0) asm volatile("v_dot2c_f32_bf16 %0, %2, %1" : "+v"(p.x) : "v"(a), "s"(0x0000BF80u));
@@ -91,6 +107,6 @@ int main() {
   // warm the clocks
   for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<0, 4, true>), dim3(256), dim3(512), 0, 0, d, c, 2000);
   hipDeviceSynchronize();
-  ROW(0, "v_and") ROW(1, "cvt_pk") ROW(2, "pk_add") ROW(3, "v_sub") ROW(4, "splitmix") ROW(5, "s_nop") ROW(6, "s_add") ROW(7, "dot2c") ROW(8, "dotmix") ROW(9, "dot2c_lit") ROW(10, "dot2c_inl")
+  ROW(0, "v_and") ROW(1, "cvt_pk") ROW(2, "pk_add") ROW(3, "v_sub") ROW(4, "splitmix") ROW(5, "s_nop") ROW(6, "s_add") ROW(7, "dot2c") ROW(8, "dotmix") ROW(9, "dot2c_lit") ROW(10, "dot2c_inl") ROW(11, "cvt_pk_f16") ROW(12, "cvt_f32_f16") ROW(13, "fma_mix") ROW(14, "h2split5") ROW(15, "h2split3")
   return 0;
 }
