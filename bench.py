@@ -252,9 +252,9 @@ def extra_configs(dev, n_steps=3):
                 opt.step(variables, optimize=True)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            f, m, c, b, x = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
-                             (C.c_double * 2)())
-            N.check(lib.p2l_prof_end3(f, m, c, b, x), 'p2l_prof_end3')
+            f, m, c, b, x, mf = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
+                                 (C.c_double * 2)(), (C.c_double * 2)())
+            N.check(lib.p2l_prof_end4(f, m, c, b, x, mf), 'p2l_prof_end4')
             opt.use_graph = saved
             if m[0] > 0:
                 tf = f[0] / (m[0] * 1e-3) / 1e12
@@ -263,7 +263,8 @@ def extra_configs(dev, n_steps=3):
                     'time_share_of_step': round(4 * m[0] * 1e-3 / el, 3),
                     'achieved_tflops_algorithmic': round(tf, 1),
                     'frac_of_bf16x3_ceiling': round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 3),
-                    'frac_executed_of_bf16_peak': round(6 * x[0] / (m[0] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 3),
+                    'mfma_products_per_fp32_product': round(mf[0] / x[0], 2) if x[0] > 0 else None,
+                    'frac_executed_of_bf16_peak': round(mf[0] / (m[0] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 3),
                     'rocprof': profile}
         del opt, variables, loss_fn
         torch.cuda.empty_cache()
@@ -436,7 +437,8 @@ def main():
     cnt = (C.c_int32 * 2)()
     abytes = (C.c_double * 2)()
     xflops = (C.c_double * 2)()
-    N.check(lib.p2l_prof_end3(flops, ms, cnt, abytes, xflops), 'p2l_prof_end3')
+    mflops = (C.c_double * 2)()
+    N.check(lib.p2l_prof_end4(flops, ms, cnt, abytes, xflops, mflops), 'p2l_prof_end4')
     last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()
@@ -458,6 +460,10 @@ def main():
         gflop_eval = GFLOP_PER_EVAL if args.lpips_net == 'vgg' else 2 * (58.80 + 1.737)
         conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         exec_tflops = xflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        # 16-bit MFMA FLOP/s issued, and the MFMA products per fp32 product of the launch mix
+        # (6 = bf16 x 3, 3 = fp16 x 2 launches; weighted by executed FLOPs)
+        mfma_tflops = mflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        prod_mix = mflops[0] / xflops[0] if xflops[0] > 0 else 6.0
         conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
         bf3 = N.default_wfmt() != N.WFMT_F32
         # PMC counters cannot be read from inside the timed process: `traffic` is the
@@ -487,9 +493,11 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': ('f32 (convolutions >= 32x32 and the self-attention: fp32-equivalent 3-way bf16 '
-                      'operand split on the bf16 MFMA pipe, 6 products, fp32 accumulate; small '
-                      'layers, dense layers, reductions and elementwise work exact fp32)'
+            'dtype': ('f32 (fp32 tensors everywhere; convolutions >= 32x32 and the self-attention multiply on '
+                      'the 16-bit MFMA pipe with fp32-grade operand splits and fp32 accumulate: the 16x16 '
+                      'Winograd 3x3 kernel on power-of-two scaled operands in 2 fp16 pieces, 3 products; the '
+                      'other kernels on 3 bf16 pieces, 6 products; small layers, dense layers, reductions '
+                      'and elementwise work exact fp32)'
                       if bf3 else 'f32'),
             'data': 'synthetic',
             'config': {
@@ -514,34 +522,40 @@ def main():
                 'last_losses': [round(x, 6) for x in last_loss],
             },
             'roofline': {
-                'kernel': ('every 3x3 conv launch of the step, bf16x3 arithmetic (6 x '
-                           'v_mfma_f32_32x32x16_bf16 per 16 channels on 3-way split fp32 operands): '
-                           'wino16s_conv_kernel / wino_conv_kernel (Winograd F(2x2,3x3), 16x16 hand-scheduled '
-                           '| 8x16 pixel blocks), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel), '
-                           'conv_thinin/thinout_kernel (3-channel image convs)'
+                'kernel': ('every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
+                           '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
+                           'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product) + wino_amax_kernel (its '
+                           'max-|x| pass), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel) and '
+                           'conv_thinin/thinout_kernel (3-channel image convs) in the bf16 x 3 arithmetic (6 x '
+                           'v_mfma_f32_32x32x16_bf16 per product on 3-way split fp32 operands)'
                            if bf3 else
                            'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                 'bound': 'mfma',
                 'achieved': round(conv_tflops, 2),
-                # bf16x3: 6 bf16 MFMA products per fp32 product -> the matrix-pipe ceiling in
-                # algorithmic (fp32-equivalent) FLOP/s is the dense bf16 peak / 6
-                'peak': round(BF16_MFMA_PEAK_TFLOPS / 6, 1) if bf3 else FP32_MFMA_PEAK_TFLOPS,
+                # 6 (bf16 x 3) or 3 (fp16 x 2) 16-bit MFMA products per fp32 product -> the matrix-pipe
+                # ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense 16-bit peak / the
+                # products per fp32 product of the launch mix (weighted by executed FLOPs)
+                'peak': round(BF16_MFMA_PEAK_TFLOPS / prod_mix, 1) if bf3 else FP32_MFMA_PEAK_TFLOPS,
+                'peak_basis': {'dense_16bit_mfma_tflops': BF16_MFMA_PEAK_TFLOPS,
+                               'mfma_products_per_fp32_product': round(prod_mix, 3),
+                               'bf16x3_only_ceiling': round(BF16_MFMA_PEAK_TFLOPS / 6, 1)},
                 'unit': 'TFLOP/s',
-                'frac': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
+                'frac': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix if bf3
                                              else FP32_MFMA_PEAK_TFLOPS), 4),
+                'frac_of_bf16x3_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6), 4) if bf3 else None,
                 'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
                 # `achieved` is ALGORITHMIC: sub-pixel (upsample-fused) launches are priced at the
                 # 9 taps of upsample-then-convolve on the high-resolution grid and the 3-channel
                 # image convs at 3 channels.  What the matrix pipe EXECUTES for the same launches
                 # (4 phase-taps; channels padded to 16 / 32) is reported next to it:
                 'executed': {'fp32_equiv_tflops': round(exec_tflops, 2),
-                             'bf16_mfma_tflops_issued': round(6 * exec_tflops, 1) if bf3 else None,
-                             'frac_of_peak': round(exec_tflops / (BF16_MFMA_PEAK_TFLOPS / 6 if bf3
+                             'bf16_mfma_tflops_issued': round(mfma_tflops, 1) if bf3 else None,
+                             'frac_of_peak': round(exec_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix if bf3
                                                                   else FP32_MFMA_PEAK_TFLOPS), 4)},
                 # the matrix-pipe utilisation proper: bf16 MFMA FLOP/s issued / dense bf16 peak.
                 # `frac` above is ALGORITHMIC FLOPs against peak/6: Winograd and sub-pixel launches
                 # issue 16/36 of the direct products, so its ceiling is up to 2.25, not 1
-                'frac_executed': round((6 * exec_tflops if bf3 else exec_tflops) /
+                'frac_executed': round((mfma_tflops if bf3 else exec_tflops) /
                                        (BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS), 4),
                 'algorithmic_ceiling_of_frac': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
                 'traffic': traffic,

@@ -156,6 +156,12 @@ int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[
  * the upsample-then-convolve definition) */
 int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
                   double exec_flops[2]);
+/* same, plus the 16-bit MFMA FLOPs issued for those launches: exec_flops x the products per fp32
+ * product of each launch's arithmetic (6 = bf16 x 3, 3 = fp16 x 2; a launch on the fp32 MFMA
+ * counts 16, its cost in 16-bit-MFMA time) -- mfma_flops / time / dense 16-bit peak is the
+ * fraction of the time the matrix pipe is busy */
+int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                  double exec_flops[2], double mfma_flops[2]);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
  * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;

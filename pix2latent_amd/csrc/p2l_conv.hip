@@ -62,6 +62,7 @@ struct ConvProf {
   std::vector<hipEvent_t> ev;
   std::vector<double> flops;    // algorithmic (direct convolution on the real channels)
   std::vector<double> xflops;   // executed on the matrix pipe (padded channels, 4 phase-taps)
+  std::vector<int> nprod;       // 16-bit MFMA products per fp32 product: 6 bf16x3 | 3 fp16x2 | 16 = fp32 MFMA
   std::vector<double> bytes;
   std::vector<int> kind;
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
@@ -1195,6 +1196,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     g_prof.xflops[prof_slot] =
         2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * (d->ups >= 2 ? 4 : d->taps);
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
+    g_prof.nprod[prof_slot] = (d->wfmt == P2L_WFMT_F32 || (d->taps == 1 && !pw_shape(d))) ? 16 : 6;
     g_prof.shape[prof_slot] = {d->taps, d->B, d->H, d->W, d->Cin, d->Cout, d->ups, d->pro,
                                arb ? (arb->skip ? 2 : 1) : 0, d->splitk};
     {
@@ -1241,6 +1243,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
     if (prof_slot >= 0) {
       g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * 4;   // 16 per quad
+      if (use_h2) g_prof.nprod[prof_slot] = 3;
       (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     }
     return rc;
@@ -1432,13 +1435,15 @@ extern "C" int p2l_conv_arb_nblk_ws(const P2LConv* d) {
   return effective_splitk(d) > 1 ? (d->H >> 1) * (d->W >> 1) : p2l_conv_arb_nblk(d);
 }
 
+static int dgrad_arb_unsplit(const P2LConv* d, const P2LArb* arb, const float* dy, const float* w,
+                             float* dx, void* workspace, size_t ws_bytes, void* stream);
 extern "C" int p2l_conv_dgrad_arb_ws(const P2LConv* d, const P2LArb* arb, const float* dy,
                                      const float* w, float* dx, void* workspace, size_t ws_bytes,
                                      void* stream) {
   if (!d || !arb || !dx) return P2L_EINVAL;
   P2LConv dd = *d;
   if (dd.ups == 3) dd.pool = P2L_POOL_NONE;
-  if (effective_splitk(&dd) <= 1) return p2l_conv_dgrad_arb(d, arb, dy, w, dx, stream);
+  if (effective_splitk(&dd) <= 1) return dgrad_arb_unsplit(d, arb, dy, w, dx, workspace, ws_bytes, stream);
   const bool pooled = dd.pool == P2L_POOL_SUM;
   int rc = conv_launch_impl(&dd, arb, nullptr, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
                             pooled ? nullptr : dx, pooled ? dx : nullptr, workspace, ws_bytes,
@@ -1448,19 +1453,24 @@ extern "C" int p2l_conv_dgrad_arb_ws(const P2LConv* d, const P2LArb* arb, const 
                         arb->dsdt_bstride, stream);
 }
 
-extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
-                                  const float* w, float* dx, void* stream) {
+// (the workspace of an unsplit launch only serves the fp16 x 2 Winograd form: wino_h2)
+static int dgrad_arb_unsplit(const P2LConv* d, const P2LArb* arb, const float* dy, const float* w,
+                             float* dx, void* workspace, size_t ws_bytes, void* stream) {
   if (!d || !arb || !dx) return P2L_EINVAL;
   P2LConv dd = *d;
   dd.splitk = 1;
   if (dd.ups == 3) dd.pool = P2L_POOL_NONE;
   const bool pooled = dd.pool == P2L_POOL_SUM;
   int rc = conv_launch_impl(&dd, arb, nullptr, dy, w, nullptr, nullptr, nullptr, nullptr, nullptr,
-                            pooled ? nullptr : dx, pooled ? dx : nullptr, nullptr, 0, stream);
+                            pooled ? nullptr : dx, pooled ? dx : nullptr, workspace, ws_bytes, stream);
   if (rc) return rc;
   const int nblk = p2l_conv_arb_nblk(&dd);
   return p2l_arb_finish(arb->partial, arb->ds, arb->dt, dd.B, nblk, dd.Cout,
                         arb->dsdt_bstride, stream);
+}
+extern "C" int p2l_conv_dgrad_arb(const P2LConv* d, const P2LArb* arb, const float* dy,
+                                  const float* w, float* dx, void* stream) {
+  return dgrad_arb_unsplit(d, arb, dy, w, dx, nullptr, 0, stream);
 }
 
 extern "C" int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
@@ -1500,6 +1510,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
   }
   g_prof.flops.assign(max_launches, 0.0);
   g_prof.xflops.assign(max_launches, 0.0);
+  g_prof.nprod.assign(max_launches, 6);
   g_prof.bytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
   g_prof.shape.assign(max_launches, {});
@@ -1534,7 +1545,13 @@ extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], do
 
 extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
                              double exec_flops[2]) {
+  return p2l_prof_end4(flops, ms, count, bytes, exec_flops, nullptr);
+}
+
+extern "C" int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                             double exec_flops[2], double mfma_flops[2]) {
   if (exec_flops) exec_flops[0] = exec_flops[1] = 0.0;
+  if (mfma_flops) mfma_flops[0] = mfma_flops[1] = 0.0;
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = false;
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
@@ -1550,13 +1567,14 @@ extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], do
     const int k = g_prof.kind[i];
     flops[k] += g_prof.flops[i];
     if (exec_flops) exec_flops[k] += g_prof.xflops[i];
+    if (mfma_flops) mfma_flops[k] += g_prof.xflops[i] * g_prof.nprod[i];
     if (bytes) bytes[k] += g_prof.bytes[i];
     ms[k] += t;
     count[k] += 1;
     if (dump) {
       const auto& sh = g_prof.shape[i];
-      fprintf(dump, "%d %d %d %d %d %d %d %d %d %d %.6e %.6e %.6f\n", sh[0], sh[1], sh[2], sh[3],
-              sh[4], sh[5], sh[6], sh[7], sh[8], sh[9], g_prof.flops[i], g_prof.bytes[i], t);
+      fprintf(dump, "%d %d %d %d %d %d %d %d %d %d %.6e %.6e %.6f %d\n", sh[0], sh[1], sh[2], sh[3],
+              sh[4], sh[5], sh[6], sh[7], sh[8], sh[9], g_prof.flops[i], g_prof.bytes[i], t, g_prof.nprod[i]);
     }
   }
   if (dump) fclose(dump);

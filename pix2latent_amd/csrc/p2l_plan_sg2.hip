@@ -31,6 +31,7 @@ struct SgLayout {
   size_t ds[P2L_SG2_MAX_CONVS], dd[P2L_SG2_MAX_CONVS];
   size_t rs[P2L_SG2_MAX_RGBS], rds[P2L_SG2_MAX_RGBS], skip[P2L_SG2_MAX_RGBS];
   size_t x0, zeros, ubuf, upbuf, g_a, g_b, g_c, g_d, gs_a, gs_b, part, part2, strips, scratch;
+  size_t cws, cws_floats;   // conv workspace: the per-image maxima of the fp16 x 2 Winograd form
   size_t total;
 };
 
@@ -82,6 +83,8 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   L.part2 = a.take(max_part2);
   L.strips = a.take(max_strips);
   L.scratch = a.take((size_t)B * max_c * 2);
+  L.cws_floats = (size_t)B * 64;
+  L.cws = a.take(L.cws_floats);
   L.total = a.off;
   return P2L_OK;
 }
@@ -99,16 +102,16 @@ P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
 // input-gradient conv + modulation backward (dx = dx' * s + extra ; ds = sum_p dx' * x)
 int dgrad_scale(P2LConv& d, const float* gin, const float* w, const float* x, const float* s,
                 int C, const float* extra, float* dx, float* ds, float* tmp, float* part,
-                float* scratch, int B, int Hout, void* st) {
+                float* scratch, int B, int Hout, float* cws, size_t cws_floats, void* st) {
   if (p2l_conv_arb_fusable(&d)) {
     P2LArb a{};
     a.x = x; a.x_ld = C; a.s = s; a.t = s; a.st_bstride = C;
     a.skip = extra; a.skip_ld = C; a.skip_C = extra ? C : 0; a.skip_ups = 0;
     a.ds = ds; a.dt = scratch; a.dsdt_bstride = C; a.partial = part; a.nomask = 1;
-    return p2l_conv_dgrad_arb(&d, &a, gin, w, dx, st);
+    return p2l_conv_dgrad_arb_ws(&d, &a, gin, w, dx, cws, cws_floats * sizeof(float), st);
   }
   RET_IF(p2l_conv_fwd(&d, gin, w, nullptr, nullptr, nullptr, nullptr, nullptr, tmp, nullptr,
-                      nullptr, 0, st));
+                      cws, cws_floats * sizeof(float), st));
   return p2l_scale_bwd(tmp, C, x, C, s, C, extra, C, extra ? C : 0, dx, C, ds, scratch, C, part, B,
                        Hout, Hout, C, st);
 }
@@ -200,7 +203,7 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
       P2LConvExtra ex{};
       ex.oscale = W + L.d[l]; ex.oscale_bstride = c.cout; ex.noise = nz; ex.noise_w = c.noise_w;
       RET_IF(p2l_conv_fwd_ex(&d, &ex, x, c.w, c.act_b, W + L.s[l], W + L.zeros, nullptr, nullptr,
-                             W + L.y[l], nullptr, nullptr, 0, st));
+                             W + L.y[l], nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
     } else {
       d.ups = 2; d.ext = 1;
       RET_IF(p2l_conv_fwd(&d, x, c.w, nullptr, W + L.s[l], W + L.zeros, nullptr, nullptr,
@@ -264,7 +267,7 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       t.algo_flops = 2.0 * B * r.res * r.res * (double)r.cin * 3;
       RET_IF(dgrad_scale(t, gs_cur, r.wt, W + L.y[l], W + L.rs[rj], r.cin,
                          have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, part, scratch, B, r.res,
-                         st));
+                         W + L.cws, L.cws_floats, st));
       if (rj > 0) {
         RET_IF(p2l_sg2_rgb_up_bwd(gs_cur, gs_prev, B, r.res / 2, r.res / 2, 0, st));
         float* t2 = gs_cur; gs_cur = gs_prev; gs_prev = t2;
@@ -287,11 +290,11 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       d.ups = 3; d.ext = 1;
       // unfused temp must not alias the conv input (tmp): use gd
       RET_IF(dgrad_scale(d, tmp, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], gd, part,
-                         scratch, B, res_in, st));
+                         scratch, B, res_in, W + L.cws, L.cws_floats, st));
     } else {
       P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
       RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, part,
-                         scratch, B, res_in, st));
+                         scratch, B, res_in, W + L.cws, L.cws_floats, st));
     }
     if (gout != gx) { float* t2 = gy; gy = gx; gx = t2; }   // keep "gx = gradient for layer l-1"
     have_next = true;

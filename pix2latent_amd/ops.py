@@ -288,8 +288,8 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
         a.skip, a.skip_ld, a.skip_C, a.skip_ups = skip.data_ptr(), skip.shape[-1], skip_C, int(skip_ups)
     a.ds, a.dt, a.dsdt_bstride = ds.data_ptr(), dt.data_ptr(), Cout
     a.partial = part.data_ptr()
-    if splitk > 1:
-        wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
+    wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
+    if splitk > 1 or wsb:
         ws = torch.empty(max(wsb // 4, 1), device=dy.device)
         N.check(_lib().p2l_conv_dgrad_arb_ws(C.byref(d), C.byref(a), N.ptr(dy), N.ptr(wt_packed),
                                              N.ptr(dx), N.ptr(ws), C.c_size_t(wsb), N.stream()),

@@ -335,6 +335,44 @@ def test_pointwise_bf16x3_dgrad_fused_affine_relu_bwd(dev, O, skip, C, Co):
     assert relerr(dt.cpu(), t.grad) < 5e-5
 
 
+def test_winograd_f16x2_scales(dev, O):
+    """the fp16 x 2 arithmetic of the 16x16 Winograd kernel lives on per-image (activations) and
+    per-layer (weights) power-of-two scales: images of wildly different magnitude in one launch
+    (zeros, gradient-sized 1e-12, 1e+6, one with a 1e4 outlier pixel), tiny and huge weights --
+    every image meets the tolerance of the fp32-grade kernels RELATIVE TO ITS OWN output, an
+    all-zero image gives exact zeros, and no image's bits depend on what else is in the batch."""
+    from pix2latent_amd import _native as N
+    O.DEFAULT_FORM = N.FORM_WINO_ANY                  # 16x16 kernel, default (fp16 x 2) arithmetic
+    g = torch.Generator().manual_seed(5)
+    H, Cin, Cout = 32, 64, 64
+    x = torch.randn(5, Cin, H, H, generator=g)
+    x[0] = 0.0
+    x[1] *= 1e-12
+    x[2] *= 1e6
+    x[3, 7, 11, 13] = 1e4
+    x[4] = x[4].abs() * 3.0                           # (a ReLU-like image)
+    for wscale in (1.0, 1e-4, 1e3):
+        w = wscale * torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        ref = F.conv2d(x.double(), w.double(), None, padding=1)
+        wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
+        y, _ = O.conv(nhwc(x, dev), wp, 5, H, H, Cin, Cout, 9, wfmt=2)
+        y = nchw(y).double()
+        assert torch.isfinite(y).all()
+        assert (y[0] == 0).all()
+        for b in range(1, 5):
+            err = (y[b] - ref[b]).abs().max().item() / ref[b].abs().max().item()
+            assert err < 1e-5, (wscale, b, err)
+        for b in (1, 3):
+            y1, _ = O.conv(nhwc(x[b:b + 1], dev), wp, 1, H, H, Cin, Cout, 9, wfmt=2)
+            assert torch.equal(nchw(y1)[0].double(), y[b]), 'result depends on the batch composition'
+    # the same launch in the bf16 x 3 arithmetic: the two agree to fp32 rounding of the products
+    O.DEFAULT_FORM = N.FORM_WINO_ANY | N.FORM_WINO_BF3
+    y3, _ = O.conv(nhwc(x, dev), wp, 5, H, H, Cin, Cout, 9, wfmt=2)
+    y3 = nchw(y3).double()
+    for b in range(1, 5):
+        assert (y3[b] - y[b]).abs().max().item() <= 1e-5 * ref[b].abs().max().item()
+
+
 @pytest.mark.parametrize('shape', [(32, 256, 256, 2), (16, 512, 512, 4), (32, 512, 256, 2)],
                          ids=['32x32-256to256', '16x16-512to512', '32x32-512to256'])
 def test_winograd_k_sliced_small_grid_layers(dev, O, shape):

@@ -54,15 +54,15 @@ def main():
     rows = collections.OrderedDict()
     for line in open(DUMP):
         v = line.split()
-        key = tuple(int(x) for x in v[:10])
+        key = tuple(int(x) for x in v[:10]) + (int(v[13]) if len(v) > 13 else 6,)
         fl, by, ms = float(v[10]), float(v[11]), float(v[12])
         r = rows.setdefault(key, [0, 0.0, 0.0, 0.0])
         r[0] += 1; r[1] += fl; r[2] += by; r[3] += ms
     tot = sum(r[3] for r in rows.values())
     print('candidates %d: %.2f ms/step, conv launches %.2f ms/step' % (pop, step_ms, tot / steps))
-    print('taps   B    H    W   Cin  Cout ups pro arb sk | n/step  ms/step   TFLOP/s    GB/s  share')
+    print('taps   B    H    W   Cin  Cout ups pro arb sk mm | n/step  ms/step   TFLOP/s    GB/s  share   (mm: 16-bit MFMA products per fp32 product: 6 bf16x3, 3 fp16x2, 16 = fp32 MFMA)')
     for key, r in sorted(rows.items(), key=lambda kv: -kv[1][3]):
-        print('%4d %3d %4d %4d %5d %5d %3d %3d %3d %2d | %5.1f %8.3f %9.1f %8.0f %5.1f%%' % (
+        print('%4d %3d %4d %4d %5d %5d %3d %3d %3d %2d %2d | %5.1f %8.3f %9.1f %8.0f %5.1f%%' % (
             key + (r[0] / steps, r[3] / steps, r[1] / r[3] / 1e9, r[2] / r[3] / 1e6, 100 * r[3] / tot)))
     for taps in (9, 1, 4, 16):
         sel = [r for k, r in rows.items() if k[0] == taps]
