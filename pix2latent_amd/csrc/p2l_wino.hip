@@ -692,11 +692,12 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     return r;
   };
 #define P2L_MFH(A, FI, J, P, M)                                                               \
-  acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                     \
-      A, __builtin_bit_cast(h16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                    \
+  if (!(ABL & 16))                                                                            \
+    acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
+        A, __builtin_bit_cast(h16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                  \
   P2L_SB()
 #define P2L_TXH(G)                                                                            \
-  if (more && kTxH.slot[G] >= 0) tx(kTxH.slot[G] >> 3, kTxH.slot[G] & 7, Vn)
+  if (more && !(ABL & 2) && kTxH.slot[G] >= 0) tx(kTxH.slot[G] >> 3, kTxH.slot[G] & 7, Vn)
   auto stepH = [&](auto S_, auto MORE_, const float* Vc, float* Vn, int c) {
     constexpr int s = decltype(S_)::value;
     constexpr bool more = decltype(MORE_)::value;
@@ -705,10 +706,12 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     P2L_MFH(a1, fi, 0, 0, m);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      rr[p] = residH(rr[p], hhH[p]);
-      mmH[p] = __builtin_convertvector(rr[p], h16x2);
-      P2L_PIN(mmH[p]);
-      if (s == 0 && p < 3 && more) write_raw1(p);
+      if (!(ABL & 8)) {
+        rr[p] = residH(rr[p], hhH[p]);
+        mmH[p] = __builtin_convertvector(rr[p], h16x2);
+        P2L_PIN(mmH[p]);
+      } else mmH[p] = hhH[p];
+      if (s == 0 && p < 3 && more && !(ABL & 64)) write_raw1(p);
       P2L_TXH(6 * s + p);
       P2L_SB();
       if (p == 0) { P2L_MFH(a1, fi, 1, 0, m); }
@@ -716,25 +719,27 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       if (p == 2) { P2L_MFH(a1, fi, 1, 1, m); }
     }
     const h16x8 a2 = cat8H(mmH);
-    if (s == 0) __syncthreads();             // the patch of chunk c+1 becomes visible
-    if (s + 1 < 4) lda(Vc, s + 1);           // (the residuals are dead)
+    if (s == 0 && !(ABL & 4)) __syncthreads();   // the patch of chunk c+1 becomes visible
+    if (s + 1 < 4 && !(ABL & 32)) lda(Vc, s + 1);   // (the residuals are dead)
     P2L_SB();
     P2L_MFH(a2, fi, 0, 0, m);
     // gap 4: weight fragments / next patch
-    if (s == 0) load_b(c, 1, 1);
-    else if (s == 2 && more) load_b(c + 1, 0, 0);
-    else if (s == 1 && more) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
+    if (s == 0 && !(ABL & 1)) load_b(c, 1, 1);
+    else if (s == 2 && more && !(ABL & 1)) load_b(c + 1, 0, 0);
+    else if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
     P2L_TXH(6 * s + 4);
     P2L_SB();
     P2L_MFH(a2, fi, 1, 0, m);
     // gap 5: h pieces of the next fragment
-    if (s + 1 < 4) hstageH();
+    if (s + 1 < 4 && !(ABL & 32)) hstageH();
     P2L_TXH(6 * s + 5);
     P2L_SB();
+    P2L_TR(1 + s, c);
   };
 #undef P2L_TXH
 #undef P2L_MFH
 
+  P2L_TR(0, 63);                                       // (lab) block phases: start | loop | epilogue | pass 1 | end
   load_raw(0);
   load_b(0, 0, 0);
 #pragma unroll
@@ -750,12 +755,13 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   __syncthreads();
   using T_ = std::true_type; using F_ = std::false_type;
   if (ABL & 1) load_b(0, 1, 1);
+  P2L_TR(1, 63);
   for (int c = 0; c + 1 < nchunks; ++c) {
     float* Vc = Vs + (c & 1) * W16_V_FLOATS;
     float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
     P2L_TR(0, c);
     if constexpr (H2) {
-      lda(Vc, 0); hstageH();
+      if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstageH(); }
       P2L_SB();
       stepH(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
       stepH(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
@@ -793,8 +799,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     }
     __syncthreads();
   }
+  P2L_TR(2, 63); P2L_TR(0, 62);
 #undef P2L_TX
-#undef P2L_TR
 #undef P2L_PIN
 #undef P2L_MF
 #undef P2L_SB
@@ -817,7 +823,9 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
           const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           dump[((2 * wave + fi) * 64 + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
         }
+    if (j == 0) { P2L_TR(1, 62); }
     __syncthreads();
+    if (j == 0) { P2L_TR(2, 62); }
     const int nb = n0 + j * 32;
     EpiSums S;
     if (nb + e_c4 * 4 < k.n_store) {
@@ -837,6 +845,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
         v[2 * i + 0] = ((T[i][0] + T[i][1]) + T[i][2]) * alpha;
         v[2 * i + 1] = ((T[i][1] - T[i][2]) - T[i][3]) * alpha;
       }
+      if (j == 0) { P2L_TR(3, 62); }
       if (split) {
         const size_t pix = ((size_t)b * k.H + y0 + 2 * ety) * k.W + x0 + 2 * etx;
         float* wp = k.ws + (((size_t)z * k.B * k.H * k.W + pix) * k.Cout + nb + e_c4 * 4);
@@ -848,6 +857,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
         epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
       }
     }
+    if (j == 0) { P2L_TR(4, 62); }
     if (k.arb_x != nullptr && !split) {
       f32x4 sgx = S.sgx, sg = S.sg;
 #pragma unroll
@@ -874,7 +884,9 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       }
     }
     __syncthreads();
+    P2L_TR(3 + j, 63);
   }
+#undef P2L_TR
 }
 
 // ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
@@ -1075,6 +1087,22 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL>), grid, block, W16_LDS_BYTES, st, k); \
     return p2l_check_launch();                                                               \
   }
+    if (pro == P2L_PRO_NONE && k.amax != nullptr) {
+#define P2L_W16LH(ABL)                                                                       \
+  case ABL: {                                                                                \
+    (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, ABL, true>,     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    hipLaunchKernelGGL(wino_amax_kernel<P2L_PRO_NONE>, dim3(64, k.B), dim3(256), 0, st, k);  \
+    hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL, true>), grid, block, W16_LDS_BYTES, st, k); \
+    return p2l_check_launch();                                                               \
+  }
+      switch (g_lab_abl) {
+        P2L_W16LH(0) P2L_W16LH(1) P2L_W16LH(2) P2L_W16LH(4) P2L_W16LH(8) P2L_W16LH(16) P2L_W16LH(64)
+        P2L_W16LH(3) P2L_W16LH(10) P2L_W16LH(67) P2L_W16LH(75) P2L_W16LH(79) P2L_W16LH(111)
+        default: return P2L_EINVAL;
+      }
+#undef P2L_W16LH
+    }
     if (pro == P2L_PRO_NONE && k.amax == nullptr) {
       switch (g_lab_abl) {
         P2L_W16L(0) P2L_W16L(1) P2L_W16L(2) P2L_W16L(4) P2L_W16L(8) P2L_W16L(16) P2L_W16L(64)

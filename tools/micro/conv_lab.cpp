@@ -42,8 +42,13 @@ static int lab_main(int B) {
   P2LConv d; memset(&d, 0, sizeof d);
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.taps = 9; d.x_ld = Cin; d.pro = P2L_PRO_NONE;
   d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = P2L_WFMT_BF16X3W; d.form = P2L_FORM_WINO_ANY;
+  void* dws; CK(hipMalloc(&dws, (size_t)B * 64 * 4));
+  const size_t wsb = (size_t)B * 64 * 4;
+  for (int arith = 0; arith < 2; ++arith) {
+  d.form = P2L_FORM_WINO_ANY | (arith == 0 ? P2L_FORM_WINO_BF3 : 0);
+  printf("---- %s\n", arith == 0 ? "bf16 x 3" : "fp16 x 2 (times include the max-|x| pass)");
   const struct { int abl; const char* what; } A[] = {
-      {0, "full"}, {1, "weights once"}, {2, "no transform"}, {4, "no barriers"}, {8, "no m/l pieces"},
+      {0, "full"}, {1, "weights once"}, {2, "no transform"}, {4, "no barriers"}, {8, "no m (/l) pieces"},
       {16, "no MFMAs"}, {64, "no patch traffic"}, {3, "weights once, no transform"},
       {10, "no transform, no m/l"}, {67, "no weights/transform/patch"},
       {75, "no weights/transform/patch/ml"}, {79, "... and no barriers"}, {111, "MFMAs + epilogue only"},
@@ -51,17 +56,17 @@ static int lab_main(int B) {
   // the clocks of an idle GPU take tens of milliseconds to settle: warm up, then two passes
   PK(p2l_lab_set(0, nullptr));
   for (int i = 0; i < 400; ++i)
-    PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+    PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, dws, wsb, st));
   CK(hipStreamSynchronize(st));
   for (int pass = 0; pass < 2; ++pass)
   for (auto a : A) {
     PK(p2l_lab_set(a.abl, nullptr));
     for (int i = 0; i < 3; ++i)
-      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, dws, wsb, st));
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < 20; ++i)
-      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+      PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, dws, wsb, st));
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("pass %d abl %4d  %.4f ms   %s\n", pass, a.abl, ms / 20, a.what);
@@ -69,7 +74,7 @@ static int lab_main(int B) {
   // phase trace of the full kernel
   CK(hipMemset(dtr, 0, 8 * 64 * 8 * 8));
   PK(p2l_lab_set(0, dtr));
-  PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, nullptr, 0, st));
+  PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, dws, wsb, st));
   CK(hipStreamSynchronize(st));
   PK(p2l_lab_set(0, nullptr));
   std::vector<unsigned long long> t(8 * 64 * 8);
@@ -85,6 +90,15 @@ static int lab_main(int B) {
   double per = 0; int n = 0;
   for (int w = 0; w < 8; ++w) for (int c = 1; c + 2 < nch; ++c) { per += (double)(t[(w * 64 + c + 1) * 8] - t[(w * 64 + c) * 8]); ++n; }
   printf("mean chunk period %.0f ticks\n", per / n);
+  for (int w : {0, 4}) {
+    const unsigned long long* a = &t[(w * 64 + 63) * 8];
+    printf("block phases w%d (ticks): prologue %lld | %d chunks %lld | epilogue pass 0 %lld | pass 1 %lld\n", w,
+           (long long)(a[1] - a[0]), nch, (long long)(a[2] - a[1]), (long long)(a[3] - a[2]), (long long)(a[4] - a[3]));
+    const unsigned long long* e = &t[(w * 64 + 62) * 8];
+    printf("   pass 0: dump writes %lld | barrier %lld | reads + output transform %lld | epilogue item + stores %lld | to the end of the pass %lld\n",
+           (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(a[3] - e[4]));
+  }
+  }
   return 0;
 }
 #endif
@@ -219,7 +233,7 @@ int main(int argc, char** argv) {
         md = fmax(md, fabs((double)out[i] - ref[i])); mx = fmax(mx, fabs((double)ref[i]));
       }
       const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
-      printf("p%d %2dx%3d^2 %3d->%3d pro%d %-13s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", pass, B, H, Cin, Cout, pro,
+      printf("p%d %2dx%3d^2 %3d->%3d pro%d %-14s %.4f ms %6.1f TFLOP/s  max|d|/max|ref| %.2e  nan %zu\n", pass, B, H, Cin, Cout, pro,
              f.name, ms, fl / ms / 1e9, md / (mx + 1e-30), nbad);
       fflush(stdout);
       CK(hipFree(dwp)); if (dws) CK(hipFree(dws));
