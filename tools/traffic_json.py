@@ -14,11 +14,21 @@ KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'wino_conv_kernel', 'wi
            'conv_thinin_kernel', 'conv_thinout_kernel')
 
 
+# kernels that belong to a conv launch without being one: the max-|x| pass in front of an fp16 x 2
+# Winograd launch, the finish of a split-K / K-sliced launch (the few 1x1 split-K layers of 4^2 ... 16^2
+# pixels share that kernel: a slight over-count).  Their bytes are added, their dispatches are not.
+AUX = ('wino_amax_kernel', 'conv_splitk_finish')
+
+
 def per_launch(path, counter):
     calls, total = 0, 0.0
     for r in csv.DictReader(open(path)):
-        if r['Counter'] == counter and any(k in r['Kernel_Name'] for k in KERNELS):
+        if r['Counter'] != counter:
+            continue
+        if any(k in r['Kernel_Name'] for k in KERNELS):
             calls += int(r['Dispatches'])
+            total += float(r['Sum'])
+        elif any(k in r['Kernel_Name'] for k in AUX):
             total += float(r['Sum'])
     return calls, (total / calls if calls else 0.0)
 
@@ -27,7 +37,8 @@ nf, f = per_launch(sys.argv[1], 'FETCH_SIZE')
 nw, w = per_launch(sys.argv[2], 'WRITE_SIZE')
 out = {
     'kernel': '3x3 conv launches: conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
-              'wino16s_conv_kernel + conv_thinin/thinout_kernel',
+              'wino16s_conv_kernel + conv_thinin/thinout_kernel; the bytes of wino_amax_kernel (max-|x| pass of '
+              'the fp16 x 2 Winograd launches) and conv_splitk_finish* are included, per conv launch',
     'commit': sys.argv[4] if len(sys.argv) > 4 else None,
     'box': sys.argv[5] if len(sys.argv) > 5 else None,
     'command': sys.argv[6] if len(sys.argv) > 6 else None,
