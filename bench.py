@@ -508,7 +508,7 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
-                'conv3x3_arithmetic': 'bf16x3' if bf3 else 'f32',
+                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel) + bf16x3 (every other >= 32x32 kernel)' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,

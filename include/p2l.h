@@ -227,8 +227,8 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *     16x16-pixel Winograd kernel: every operand is scaled by a power of two (weights: per layer,
  *     at pack time; activations: per image, from a max-|x| pass in front of the launch) so that
  *     its largest value sits at 2^13..2^15, and split into TWO round-to-nearest fp16 pieces
- *     (x = h + m to 1 ulp of fp32; elements more than 2^29 below the maximum of their image lose
- *     relative precision, 2^-40 of the maximum in absolute terms); the product is accumulated in
+ *     (x = h + m to 1 ulp of fp32; elements more than 2^15 below the maximum of their image get a
+ *     denormal second piece and lose relative precision -- 2^-37 of the maximum in absolute terms); the product is accumulated in
  *     fp32 from THREE v_mfma_f32_32x32x16_f16 cross terms (h h, h m, m h) and un-scaled exactly in
  *     the epilogue: half the matrix work and a third of the split instructions of bf16 x 3.
  *     [K_pad/16][16][N_pad/32][2 pieces][64 lanes] x 16 B, then 4 floats (the bits of max |w|).
