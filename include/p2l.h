@@ -111,6 +111,18 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
  *   g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ; ds[b,c] = sum g*x ; dt[b,c] = sum g
  * Usable when p2l_conv_arb_fusable(d) (one image per tile, no split-K); `partial`
  * needs 2*B*p2l_conv_arb_nblk(d)*Cout floats. */
+/* Per-image maxima of |tensor|, handed from the conv that WRITES a tensor to the conv that reads
+ * it, so that an fp16 x 2 Winograd launch (P2L_WFMT_BF16X3W) does not need its own pass over the
+ * input.  Producer: `out` (and `outp` for the pooled output) receive one partial maximum per block,
+ * [B][p2l_conv_amax_slots(d)] floats each; a launch that cannot produce them (slots == 0) ignores
+ * the fields.  Consumer: `in` = the partial maxima of the tensor it reads as x ([B][in_n], the RAW
+ * tensor: a fused prologue x*s+t is bounded by max|s| max|x| + max|t| inside the kernel); NULL =
+ * the launch reduces max|x| itself.  The caller guarantees that nothing else wrote the tensor in
+ * between.  All NULL / 0 = not used. */
+typedef struct P2LAmax {
+  float* out; float* outp;
+  const float* in; int32_t in_n;
+} P2LAmax;
 typedef struct P2LArb {
   const float* x; int32_t x_ld;              /* pre-activation input of the forward conv */
   const float* s; const float* t; int32_t st_bstride;
@@ -118,6 +130,7 @@ typedef struct P2LArb {
   float* ds; float* dt; int32_t dsdt_bstride;
   float* partial;
   int32_t nomask;                            /* 1: plain scale backward g = da (StyleGAN2) */
+  P2LAmax amax;                              /* maxima of dy (in) / of the written dx (out)  */
 } P2LArb;
 int p2l_conv_arb_fusable(const P2LConv* d);
 int p2l_conv_arb_nblk(const P2LConv* d);
@@ -182,7 +195,10 @@ typedef struct P2LConvExtra {
   int32_t oscale_bstride;
   const float* noise;       /* [B][H*W] per-pixel noise, or NULL                  */
   float noise_w;
+  P2LAmax amax;             /* maxima of x (in) / of the written y, yp (out, outp) */
 } P2LConvExtra;
+/* partial maxima per image a launch of d writes into P2LAmax.out / outp (0: it writes none) */
+int p2l_conv_amax_slots(const P2LConv* d);
 int p2l_conv_fwd_ex(const P2LConv* d, const P2LConvExtra* ex, const float* x,
                     const float* w, const float* bias, const float* pro_s,
                     const float* pro_t, const float* res, const float* mask, float* y,

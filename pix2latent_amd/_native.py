@@ -26,17 +26,21 @@ class P2LConv(C.Structure):
                 ('wfmt', C.c_int32), ('form', C.c_int32), ('algo_flops', C.c_double)]
 
 
+class P2LAmax(C.Structure):
+    _fields_ = [('out', C.c_void_p), ('outp', C.c_void_p), ('in_', C.c_void_p), ('in_n', C.c_int32)]
+
+
 class P2LArb(C.Structure):
     _fields_ = [('x', C.c_void_p), ('x_ld', C.c_int32), ('s', C.c_void_p), ('t', C.c_void_p),
                 ('st_bstride', C.c_int32), ('skip', C.c_void_p), ('skip_ld', C.c_int32),
                 ('skip_C', C.c_int32), ('skip_ups', C.c_int32), ('ds', C.c_void_p),
                 ('dt', C.c_void_p), ('dsdt_bstride', C.c_int32), ('partial', C.c_void_p),
-                ('nomask', C.c_int32)]
+                ('nomask', C.c_int32), ('amax', P2LAmax)]
 
 
 class P2LConvExtra(C.Structure):
     _fields_ = [('oscale', C.c_void_p), ('oscale_bstride', C.c_int32), ('noise', C.c_void_p),
-                ('noise_w', C.c_float)]
+                ('noise_w', C.c_float), ('amax', P2LAmax)]
 
 
 class P2LGemm(C.Structure):
@@ -199,7 +203,7 @@ PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 # every symbol include/p2l.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
-    'p2l_conv_workspace_bytes', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
+    'p2l_conv_workspace_bytes', 'p2l_conv_amax_slots', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
     'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 
     'p2l_pack_conv_weight_bf3t',

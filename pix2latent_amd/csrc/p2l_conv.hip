@@ -1069,6 +1069,25 @@ static bool wino_h2(const P2LConv* d) {
   return wino_shape(d) && d->H % 16 == 0 && d->W % 16 == 0 &&
          !(d->form & (P2L_FORM_WINO_8X16 | P2L_FORM_WINO_BF3));
 }
+// P2LAmax producers: launches whose blocks each cover one tile of ONE image and end in the shared
+// epilogue -- the unsplit 16x16 Winograd kernel (16x16 pixels x 64 channels) and the kernels that
+// go through epilogue_vec (direct 3x3, sub-pixel forward: 4 phases, 1x1 in both arithmetics:
+// 128 pixels x 32 / 64 channels).  Split-K launches (finish kernel), the 8x16 Winograd kernel, the
+// three-channel image kernels and tiles that span images write none.
+static int effective_splitk(const P2LConv* d);
+extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
+  if (!d) return 0;
+  if (wino_shape(d)) {
+    if (d->H % 16 || d->W % 16 || (d->form & P2L_FORM_WINO_8X16)) return 0;
+    if (d->splitk > 1 && wino_split(d) == d->splitk) return 0;
+    return (d->H / 16) * (d->W / 16) * (d->Cout / 64);
+  }
+  if (thin_shape(d) >= 0 || d->ups > 2 || effective_splitk(d) > 1) return 0;
+  ConvK k{};
+  if (choose_tile(d, k) != P2L_OK || k.tb_log != 0 || k.partial) return 0;
+  const int nnt = pw_shape(d) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
+  return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1);
+}
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
   const size_t h2 = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;
   if (d->splitk <= 1) return h2;
@@ -1168,6 +1187,12 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.amax = (float*)workspace;
     k.ws = (float*)workspace + (size_t)d->B * 64;
   }
+  {
+    const P2LAmax* am = ex ? &ex->amax : (arb ? &arb->amax : nullptr);
+    if (am && use_h2 && am->in && am->in_n > 0) { k.amax_in = am->in; k.amax_in_n = am->in_n; }
+    const int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
+    if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
+  }
   if (k.splitk > 1) {
     const size_t need = (use_h2 ? h2_bytes : 0) + (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
     if (!workspace || ws_bytes < need) return P2L_EWS;
@@ -1262,7 +1287,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   // ---- 3-channel image convs ----
   {
     const int tm = thin_shape(d);
-    const bool geom = k.tw_log == 4 && k.th_log == 3 && k.tb_log == 0 && !k.partial && !ex;
+    const bool geom = k.tw_log == 4 && k.th_log == 3 && k.tb_log == 0 && !k.partial && !(ex && (ex->oscale || ex->noise));
     if (tm == 1 && geom) {
       ConvK kt = k;
       kt.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;

@@ -51,6 +51,11 @@ struct ConvK {
   // |input| per image (written by the pass in front of the launch), bits of max |weight|
   float* amax;
   const unsigned* w_tail;
+  // maxima handed between launches (P2LAmax): partial maxima of the RAW input tensor from the launch
+  // that wrote it [B][amax_in_n]; this launch's own partial maxima of what it stores to y / yp, one
+  // per block [B][amax_out_n]
+  const float* amax_in; int amax_in_n;
+  float* amax_out; float* amax_outp; int amax_out_n;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -202,7 +207,11 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
 // osh = 1: sub-pixel forward, the block writes phase (ph_y, ph_x) of the output buffer.
 struct EpiSums {
   f32x4 sgx = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
+  float amax = 0.f, amaxp = 0.f;   // max |value stored to y| / |... to yp| (k.amax_out)
 };
+__device__ __forceinline__ float absmax4(float m, const f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 
 // ARBM: -1 = decided at run time (k.arb_x), 0 / 1 = known at compile time
 template <int ARBM = -1>
@@ -243,6 +252,7 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
         t.z = m.z > 0.f ? t.z : 0.f; t.w = m.w > 0.f ? t.w : 0.f;
       }
       if (k.y) st4(k.y, pix * (unsigned)k.y_ld + (unsigned)n, t);
+      if (k.amax_out) S.amax = absmax4(S.amax, t);
       v[s] = t;
     }
     if (k.pool) {
@@ -256,6 +266,7 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
         p = (v[0] + v[1]) + (v[2] + v[3]);
       }
       st4(k.yp, ppix * (unsigned)k.yp_ld + (unsigned)n, p);
+      if (k.amax_outp) S.amaxp = absmax4(S.amaxp, p);
     }
   } else {
     const f32x4 s4 = ld4(k.arb_s, (unsigned)(b * k.arb_bstride + n));
@@ -293,6 +304,7 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
           }
         }
         st4(dst, pix * dld + (unsigned)n, o);
+        if (k.amax_out || k.amax_outp) { if (pool_sum) S.amaxp = absmax4(S.amaxp, o); else S.amax = absmax4(S.amax, o); }
         S.sgx += g * xv;
         S.sg += g;
       }
@@ -377,6 +389,25 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
   if (k.arb_x != nullptr)
     epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
                              (size_t)b0 * k.arb_nblk + tile_in_image, n0);
+  // this block's partial maxima of what it stored, for the launch that reads the tensor next
+  // (P2LAmax; the launcher only sets the pointers for tiles inside one image)
+  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+    float m = S.amax, mp = S.amaxp;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+    __syncthreads();                      // (tile dumps / partial sums read)
+    if (lane == 0) { smem[wave * 2] = m; smem[wave * 2 + 1] = mp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(smem[0], smem[2]), fmaxf(smem[4], smem[6]));
+      mp = fmaxf(fmaxf(smem[1], smem[3]), fmaxf(smem[5], smem[7]));
+      const int nph = osh ? 4 : 1;
+      const size_t slot = (size_t)b0 * k.amax_out_n +
+                          ((size_t)tile_in_image * k.n_ntiles + n0 / COLS) * nph + (osh ? ph_y * 2 + ph_x : 0);
+      if (k.amax_out != nullptr) k.amax_out[slot] = m;
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
+    }
+  }
 }
 
 

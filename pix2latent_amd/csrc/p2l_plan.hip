@@ -61,6 +61,7 @@ struct ConvCall {
   const float* x = nullptr; const float* w = nullptr; const float* bias = nullptr;
   const float* ps = nullptr; const float* pt = nullptr; const float* res = nullptr;
   const float* mask = nullptr; float* y = nullptr; float* yp = nullptr;
+  bool want_amax = false;   // the next reader of y / yp is a 3x3 conv: leave its maxima (P2LAmax)
 };
 // weight format of the 3x3 convs of the model whose plan is running on this thread
 // (set at every extern "C" entry from the model struct's wfmt)
@@ -82,10 +83,81 @@ size_t conv_ws_floats(ConvCall& c) {
   c.d.splitk = p2l_conv_suggest_splitk(&c.d);
   return p2l_conv_workspace_bytes(&c.d) / sizeof(float);
 }
+
+// ---------------------------------------------------------------------------
+// Maxima handed from the conv that writes a tensor to the conv that reads it (P2LAmax): the
+// bookkeeping of ONE plan run, on the stack of the entry point (thread_local pointer: a plan runs
+// on the calling thread).  A tensor is known by its address and extents; its entry dies when
+// another conv writes the buffer (run_conv), when a non-conv kernel writes it (amax_drop at that
+// call site) or when its slot set comes round again in the ring.
+// ---------------------------------------------------------------------------
+struct AmaxReg {
+  static constexpr int NSETS = 6, NENT = 8;
+  float* ring = nullptr; size_t set_floats = 0; int next = 0;
+  struct Ent { const float* t = nullptr; int B = 0, H = 0, W = 0, C = 0; const float* slots = nullptr; int n = 0, set = -1; };
+  Ent e[NENT];
+  float* take(int* set) {
+    *set = next % NSETS; ++next;
+    for (Ent& x : e) if (x.set == *set) x = Ent();
+    return ring + (size_t)*set * set_floats;
+  }
+  void drop(const float* t) { if (t) for (Ent& x : e) if (x.t == t) x = Ent(); }
+  void put(const float* t, int B, int H, int W, int C, const float* slots, int n, int set) {
+    drop(t);
+    Ent* f = &e[0];
+    for (Ent& x : e) if (!x.t) { f = &x; break; }
+    f->t = t; f->B = B; f->H = H; f->W = W; f->C = C; f->slots = slots; f->n = n; f->set = set;
+  }
+  bool get(const float* t, int B, int H, int W, int C, const float** slots, int32_t* n) const {
+    for (const Ent& x : e)
+      if (x.t == t && t && x.B == B && x.H == H && x.W == W && x.C == C) { *slots = x.slots; *n = x.n; return true; }
+    return false;
+  }
+};
+thread_local AmaxReg* g_amax = nullptr;
+struct AmaxScope {                                     // one per plan entry point
+  AmaxReg reg;
+  AmaxScope(float* ring, size_t set_floats) {
+    reg.ring = ring; reg.set_floats = set_floats;
+#ifdef P2L_NO_AMAX_HANDOVER                            // (A/B build: tools/ab_build.sh p2l_plan -DP2L_NO_AMAX_HANDOVER)
+    set_floats = 0;
+#endif
+    g_amax = set_floats ? &reg : nullptr;
+  }
+  ~AmaxScope() { g_amax = nullptr; }
+};
+inline void amax_drop(const float* t) { if (g_amax) g_amax->drop(t); }
+inline void amax_clear() { if (g_amax) for (auto& x : g_amax->e) x = AmaxReg::Ent(); }
+// slots per image a plan has to provide for this conv's maxima (ring sizing)
+int conv_amax_slots(ConvCall& c) {
+  c.d.splitk = p2l_conv_suggest_splitk(&c.d);
+  return p2l_conv_amax_slots(&c.d);
+}
+
 int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
   c.d.splitk = p2l_conv_suggest_splitk(&c.d);
-  return p2l_conv_fwd(&c.d, c.x, c.w, c.bias, c.ps, c.pt, c.res, c.mask, c.y, c.yp, skws,
-                      skws_floats * sizeof(float), st);
+  AmaxReg* R = g_amax;
+  P2LConvExtra ex{};
+  float *so = nullptr, *sop = nullptr;
+  int ns = 0, set_o = -1, set_p = -1;
+  if (R) {
+    if (c.d.ups == 0 && c.d.x_ld == c.d.Cin)
+      R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n);
+    R->drop(c.y); R->drop(c.yp);                       // this launch overwrites them
+    ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
+    if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.n_store == c.d.Cout) {
+      if (c.y && c.d.y_ld == c.d.Cout) so = R->take(&set_o);
+      if (c.yp && c.d.yp_ld == c.d.Cout) sop = R->take(&set_p);
+      ex.amax.out = so; ex.amax.outp = sop;
+    }
+  }
+  const int rc = p2l_conv_fwd_ex(&c.d, &ex, c.x, c.w, c.bias, c.ps, c.pt, c.res, c.mask, c.y, c.yp, skws,
+                                 skws_floats * sizeof(float), st);
+  if (rc == P2L_OK && R) {
+    if (so) R->put(c.y, c.d.B, c.d.H, c.d.W, c.d.Cout, so, ns, set_o);
+    if (sop) R->put(c.yp, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cout, sop, ns, set_p);
+  }
+  return rc;
 }
 
 // input-gradient conv + backward of the consumer's affine+ReLU; fused in the conv
@@ -108,10 +180,26 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
     arb.x = a.x; arb.x_ld = a.x_ld; arb.s = a.s; arb.t = a.t; arb.st_bstride = a.st_bstride;
     arb.skip = a.skip; arb.skip_ld = a.skip_ld; arb.skip_C = a.skip_C; arb.skip_ups = a.skip_ups;
     arb.ds = a.ds; arb.dt = a.dt; arb.dsdt_bstride = a.dsdt_bstride; arb.partial = part;
-    return p2l_conv_dgrad_arb_ws(&c.d, &arb, c.x, c.w, dx, skws, skws_floats * sizeof(float), st);
+    AmaxReg* R = g_amax;
+    float* so = nullptr;
+    int ns = 0, set_o = -1;
+    if (R) {
+      if (c.d.ups == 0 && c.d.x_ld == c.d.Cin)
+        R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &arb.amax.in, &arb.amax.in_n);
+      R->drop(dx);
+      ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
+      if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.ups == 0) {
+        so = R->take(&set_o);
+        if (pooled) arb.amax.outp = so; else arb.amax.out = so;
+      }
+    }
+    const int rc = p2l_conv_dgrad_arb_ws(&c.d, &arb, c.x, c.w, dx, skws, skws_floats * sizeof(float), st);
+    if (rc == P2L_OK && so) R->put(dx, c.d.B, Ho, Wo, c.d.Cout, so, ns, set_o);
+    return rc;
   }
   if (pooled) { c.yp = tmp; c.y = nullptr; } else { c.y = tmp; c.yp = nullptr; }
   RET_IF(run_conv(c, skws, skws_floats, st));
+  amax_drop(dx);
   return p2l_affine_relu_bwd(tmp, c.d.Cout, a.x, a.x_ld, a.s, a.t, a.st_bstride, a.skip,
                              a.skip_ld, a.skip_C, a.skip_ups, dx, c.d.Cout, a.ds, a.dt,
                              a.dsdt_bstride, part, c.d.B, Ho, Wo, c.d.Cout, st);
@@ -139,6 +227,7 @@ struct BGLayout {
   size_t arb_partial, tail_pf;
   size_t d_theta, d_phi_p, d_phi, d_g_p, d_g, d_ag;
   size_t skws; size_t skws_floats;
+  size_t amax_ring, amax_set_floats;   // AmaxReg: NSETS sets of [B][max slots per image]
   size_t total;
   int out_res;
 };
@@ -164,10 +253,13 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   // every activation-backward of the backward pass gets its own partial-sum buffer: their
   // second reduction stage is deferred and runs as one launch (p2l_arb_defer_*)
   size_t sum_partial = 0, max_sk = 0;
+  int max_slots = 0;
   auto upd_sk = [&](int Hc, int Cin, int Cout, int taps) {
     ConvCall c = mk_conv(B, Hc, Hc, Cin, Cout, taps);
     const size_t f = conv_ws_floats(c);
     if (f > max_sk) max_sk = f;
+    const int ns = conv_amax_slots(c);
+    if (ns > max_slots) max_slots = ns;
   };
   for (int i = 0; i < m->n_blocks; ++i) {
     if (i == m->attn_before) {
@@ -272,6 +364,8 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   L.arb_partial = a.take(sum_partial);
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
+  L.amax_set_floats = (size_t)B * max_slots;
+  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_floats + 64);
   L.total = a.off;
   return P2L_OK;
 }
@@ -367,6 +461,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
   float* W = (float*)ws;
   const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
   float* skws = W + L.skws;
+  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats);
 
   RET_IF(p2l_concat2(z, c, W + L.cond, B, m->z_dim, m->c_dim, st));
   RET_IF(p2l_linear_fwd(W + L.cond, m->cbn_w, nullptr, W + L.raw, B, cond, 2 * CT, st));
@@ -431,6 +526,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c0.x = x; c0.w = g.w[0]; c0.bias = g.b[0]; c0.y = W + o.h1;
     c0.d.pro = P2L_PRO_AFFINE_RELU; c0.d.pro_bstride = CT;
     c0.ps = W + L.s + g.cbn_off[0]; c0.pt = W + L.t + g.cbn_off[0];
+    c0.want_amax = !g.up;                              // (an up block's conv_1 takes the sub-pixel form)
     RET_IF(run_conv(c0, skws, L.skws_floats, st));
     // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
     ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
@@ -438,6 +534,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     if (g.up && g.w1_sp && o.H >= 16) { c1.d.ups = 2; c1.w = g.w1_sp; }   // sub-pixel form
     c1.d.pro = P2L_PRO_AFFINE_RELU; c1.d.pro_bstride = CT;
     c1.ps = W + L.s + g.cbn_off[1]; c1.pt = W + L.t + g.cbn_off[1];
+    c1.want_amax = true;
     RET_IF(run_conv(c1, skws, L.skws_floats, st));
     ConvCall c2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     c2.x = W + o.h2; c2.w = g.w[2]; c2.bias = g.b[2]; c2.y = W + o.h3;
@@ -478,6 +575,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
   const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
   float* skws = W + L.skws;
   float* part = W + L.arb_partial;
+  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats);
   // ds / dt of the ~50 activation-backwards are only needed by the conditioning gradient at
   // the very end: record their second reduction stage and run it as ONE launch
   struct ArbDefer {
@@ -519,6 +617,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     d3.x = ga; d3.w = g.wt[3];
     ArbArgs a3{W + o.h3, mid, W + L.s + g.cbn_off[3], W + L.t + g.cbn_off[3], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[3], W + L.dt + g.cbn_off[3], CT};
+    d3.want_amax = true;
     RET_IF(run_dgrad_arb(d3, a3, gb, gd, part, skws, L.skws_floats, st));
     part += o.pf;
     // conv_2
@@ -526,6 +625,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     d2.x = gb; d2.w = g.wt[2];
     ArbArgs a2{W + o.h2, mid, W + L.s + g.cbn_off[2], W + L.t + g.cbn_off[2], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[2], W + L.dt + g.cbn_off[2], CT};
+    d2.want_amax = true;
     RET_IF(run_dgrad_arb(d2, a2, gc, gd, part, skws, L.skws_floats, st));
     part += o.pf;
     // conv_1 (+ nearest-x2 backward = 2x2 sum pool fused in the epilogue)
@@ -549,6 +649,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
 
     if (i == m->attn_before) {
       // ---- SelfAttn backward; ga = d out [B,H,H,C] ------------------------
+      amax_clear();                                    // (gb is a scratch matrix of the attention kernels)
       const int C = m->attn_ch, H = L.att_H, P = H * H;
       const float* x = (i == 0) ? W + L.x0 : W + L.blk[i - 1].y;
       (void)x;
@@ -616,6 +717,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       ConvCall t3 = mk_conv(B, H, H, C / 2, C, 1);
       t3.x = W + L.d_g; t3.w = m->att_wt[2]; t3.y = ga; t3.res = ga; t3.d.res_ld = C;
       RET_IF(run_conv(t3, skws, L.skws_floats, st));
+      amax_clear();
     }
   }
   // ga = d gen_z output [B, 16*16*ch]; conditioning gradients
@@ -654,6 +756,7 @@ struct PLLayout {
   size_t gs;           // per-sample gradient scale
   size_t ga, gb, gtap; // backward scratch
   size_t skws, skws_floats;
+  size_t amax_ring, amax_set_floats;   // AmaxReg
   size_t total;
 };
 
@@ -661,7 +764,7 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
   if (B < 1 || H < 32 || W < 32 || !is_pow2(H) || !is_pow2(W)) return P2L_EINVAL;
   Arena a;
   size_t max_act = 0, max_sk = 0;
-  int pi = 0;
+  int pi = 0, max_slots = 0;
   for (int i = 0; i < 13; ++i) {
     const int h = H / kVggDiv[i], w = W / kVggDiv[i];
     const size_t n = (size_t)B * h * w * kVggCout[i];
@@ -674,6 +777,9 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
     size_t s2 = conv_ws_floats(d);
     if (s1 > max_sk) max_sk = s1;
     if (s2 > max_sk) max_sk = s2;
+    const int n1 = conv_amax_slots(f), n2 = conv_amax_slots(d);
+    if (n1 > max_slots) max_slots = n1;
+    if (n2 > max_slots) max_slots = n2;
   }
   L.tgt16 = a.take((size_t)B * H * W * 16);
   L.wsrc = a.take((size_t)B * H * W);
@@ -692,6 +798,8 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
   L.gtap = a.take(max_act);
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
+  L.amax_set_floats = (size_t)B * max_slots;
+  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_floats + 64);
   L.total = a.off;
   return P2L_OK;
 }
@@ -699,6 +807,7 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
 // VGG16 features forward on an NHWC16 image; y[i] = relu(conv_i), pooled copies.
 int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, float* Wk,
                 const PLLayout& L, void* st) {
+  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats);
   const float* x = img16;
   int pi = 0;
   for (int i = 0; i < 13; ++i) {
@@ -714,6 +823,7 @@ int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, f
     if (vgg_pool_after(i)) {
       c.d.pool = P2L_POOL_MAX; c.yp = Wk + L.yp[pi];
     }
+    c.want_amax = i < 12;
     RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
     if (vgg_pool_after(i)) { x = Wk + L.yp[pi]; ++pi; }
     else x = Wk + L.y[i];
@@ -841,6 +951,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
   if (!v) return P2L_EINVAL;
   // gs[b] = gloss[b] * beta / wsum[b]
   RET_IF(p2l_vec_scale_div(gloss, cache->wsum, Wk + L.gs, B, beta, st));
+  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats);
   float* ga = Wk + L.ga;   // gradient w.r.t. the PRE-ReLU output of conv i (masked)
   float* gb = Wk + L.gb;
   float* gtap = Wk + L.gtap;
@@ -861,6 +972,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
     if (!vgg_pool_after(prev)) {
       // input is relu(conv_{i-1}) directly: fuse its ReLU mask in the epilogue
       c.mask = Wk + L.y[prev]; c.d.mask_ld = kVggCout[prev];
+      c.want_amax = i > 1;
       RET_IF(run_conv(c, Wk + L.skws, L.skws_floats, st));
     } else {
       // input is maxpool(relu(conv_{i-1})); conv_{i-1} is also an LPIPS tap
@@ -870,6 +982,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
       const int P = hp * wp, C = kVggCout[prev];
       RET_IF(p2l_lpips_tap_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k],
                                cache->wt[k], P, Wk + L.gs, gtap, B, P, C, st));
+      amax_drop(ga);                                   // (written by a non-conv kernel)
       RET_IF(p2l_maxpool2_bwd(Wk + L.y[prev], C, gb, C, gtap, C, ga, C, B, hp, wp, C, 1, st));
       --pi;
       continue;  // ga already holds the masked gradient of conv_{i-1}

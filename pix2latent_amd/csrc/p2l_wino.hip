@@ -401,9 +401,35 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
   float x_scale = 1.f, out_scale = 1.f;
   if (H2) {
-    float a = k.amax[b * 64 + lane];
+    float a;
+    if (k.amax_in != nullptr) {
+      // maxima handed over by the launch that wrote x (P2LAmax): its per-block partials of this
+      // image; a fused prologue x*s+t (ReLU or not) is bounded by max|s| max|x| + max|t|
+      a = 0.f;
+      for (int i = tid; i < k.amax_in_n; i += W16_THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+      float ms = 0.f, mt = 0.f;
+      if (PRO != P2L_PRO_NONE) {
+        const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
+        const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
+        for (int c = tid; c < k.Cin; c += W16_THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
+      }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+      for (int o = 1; o < 64; o <<= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt = fmaxf(mt, __shfl_xor(mt, o, 64)); }
+      }
+      if (lane == 0) { raw[wave * 4 + 0] = a; raw[wave * 4 + 1] = ms; raw[wave * 4 + 2] = mt; }
+      __syncthreads();
+      a = 0.f; ms = 0.f; mt = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
+      __syncthreads();                                   // (the patch is staged there next)
+      if (PRO != P2L_PRO_NONE) a = (ms * a + mt) * 1.001f;
+    } else {
+      a = k.amax[b * 64 + lane];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    }
     float inv_x, sw, inv_w;
     h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
     h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
@@ -812,6 +838,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   float* red = raw;                                      // [2 kinds][8 waves][32]
   const bool split = k.splitk > 1;
   const float alpha = (split ? 1.f : k.alpha) * out_scale;   // (the finish kernel scales the sum)
+  float blk_amax = 0.f, blk_amaxp = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -828,6 +855,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     if (j == 0) { P2L_TR(2, 62); }
     const int nb = n0 + j * 32;
     EpiSums S;
+    S.amax = blk_amax; S.amaxp = blk_amaxp;
     if (nb + e_c4 * 4 < k.n_store) {
       f32x4 T[2][4];
 #pragma unroll
@@ -853,6 +881,14 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
         *reinterpret_cast<f32x4*>(wp + k.Cout) = v[1];
         *reinterpret_cast<f32x4*>(wp + (size_t)k.W * k.Cout) = v[2];
         *reinterpret_cast<f32x4*>(wp + (size_t)(k.W + 1) * k.Cout) = v[3];
+      } else if (ABL & 128) {                            // (lab) the result without the shared epilogue item: plain stores
+        float* yp0 = k.y + (((size_t)b * k.H + y0 + 2 * ety) * k.W + x0 + 2 * etx) * k.y_ld + nb + e_c4 * 4;
+        *reinterpret_cast<f32x4*>(yp0) = v[0];
+        *reinterpret_cast<f32x4*>(yp0 + k.y_ld) = v[1];
+        *reinterpret_cast<f32x4*>(yp0 + (size_t)k.W * k.y_ld) = v[2];
+        *reinterpret_cast<f32x4*>(yp0 + (size_t)(k.W + 1) * k.y_ld) = v[3];
+      } else if (ABL & 256) {                            // (lab) no stores at all
+        if (v[0].x == 123.456f) k.y[0] = v[1].x + v[2].x + v[3].x;
       } else {
         epi_item(k, v, b, y0 + 2 * ety, x0 + 2 * etx, nb + e_c4 * 4, 0, 0, 0, S);
       }
@@ -883,10 +919,29 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
         k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
       }
     }
+    blk_amax = S.amax; blk_amaxp = S.amaxp;
     __syncthreads();
     P2L_TR(3 + j, 63);
   }
 #undef P2L_TR
+  // this block's partial maxima of what it stored, for the launch that reads the tensor next (P2LAmax)
+  if ((k.amax_out != nullptr || k.amax_outp != nullptr) && !split) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      blk_amax = fmaxf(blk_amax, __shfl_xor(blk_amax, o, 64));
+      blk_amaxp = fmaxf(blk_amaxp, __shfl_xor(blk_amaxp, o, 64));
+    }
+    if (lane == 0) { red[wave * 2] = blk_amax; red[wave * 2 + 1] = blk_amaxp; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f, mp = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { m = fmaxf(m, red[w * 2]); mp = fmaxf(mp, red[w * 2 + 1]); }
+      const size_t slot = (size_t)b * k.amax_out_n + (size_t)tile_in_image * k.n_ntiles + (n0 >> 6);
+      if (k.amax_out != nullptr) k.amax_out[slot] = m;
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
+    }
+  }
 }
 
 // ---- weights: U = G g G^T per (cout, cin), split into 3 bf16 pieces, fragment order --------
@@ -1098,7 +1153,7 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
   }
       switch (g_lab_abl) {
         P2L_W16LH(0) P2L_W16LH(1) P2L_W16LH(2) P2L_W16LH(4) P2L_W16LH(8) P2L_W16LH(16) P2L_W16LH(64)
-        P2L_W16LH(3) P2L_W16LH(10) P2L_W16LH(67) P2L_W16LH(75) P2L_W16LH(79) P2L_W16LH(111)
+        P2L_W16LH(3) P2L_W16LH(10) P2L_W16LH(67) P2L_W16LH(75) P2L_W16LH(79) P2L_W16LH(111) P2L_W16LH(128) P2L_W16LH(256)
         default: return P2L_EINVAL;
       }
 #undef P2L_W16LH
@@ -1130,7 +1185,8 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
-    hipLaunchKernelGGL(wino_amax_kernel<PRO>, dim3(64, k.B), dim3(256), 0, st, k);           \
+    if (k.amax_in == nullptr)                                                                \
+      hipLaunchKernelGGL(wino_amax_kernel<PRO>, dim3(64, k.B), dim3(256), 0, st, k);         \
     hipLaunchKernelGGL((wino16s_conv_kernel<PRO, 0, true>), grid, block, W16_LDS_BYTES, st, k); \
   } while (0)
     if (k.amax != nullptr) {                           // fp16 x 2 arithmetic (conv_launch_impl decides)

@@ -41,7 +41,10 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
          splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0, wfmt=N.WFMT_F32,
-         form=None):
+         form=None, amax_in=None, want_amax=False):
+    """amax_in: [B, n] partial maxima of |x| from the launch that wrote x (P2LAmax.in);
+    want_amax: also return (amax_y, amax_yp) partial maxima of the outputs, or None when this launch
+    writes none (p2l_conv_amax_slots == 0)"""
     d = N.P2LConv()
     d.wfmt = wfmt
     d.form = DEFAULT_FORM if form is None else form
@@ -72,9 +75,22 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
         ex.oscale, ex.oscale_bstride = oscale.data_ptr(), oscale.shape[-1]
     if noise is not None:
         ex.noise, ex.noise_w = noise.data_ptr(), float(noise_w)
+    am_y = am_yp = None
+    if amax_in is not None:
+        ex.amax.in_, ex.amax.in_n = amax_in.data_ptr(), amax_in.shape[-1]
+    if want_amax:
+        ns = _lib().p2l_conv_amax_slots(C.byref(d))
+        if ns > 0:
+            am_y = torch.full((B, ns), -1.0, device=x.device)
+            ex.amax.out = am_y.data_ptr()
+            if pool:
+                am_yp = torch.full((B, ns), -1.0, device=x.device)
+                ex.amax.outp = am_yp.data_ptr()
     N.check(_lib().p2l_conv_fwd_ex(C.byref(d), C.byref(ex), N.ptr(x), N.ptr(w_packed), N.ptr(bias),
                                    N.ptr(pro_s), N.ptr(pro_t), N.ptr(res), N.ptr(mask), N.ptr(y),
                                    N.ptr(yp), N.ptr(ws), C.c_size_t(wsb), N.stream()), 'conv_fwd')
+    if want_amax:
+        return y, yp, (am_y, am_yp)
     return y, yp
 
 

@@ -373,6 +373,65 @@ def test_winograd_f16x2_scales(dev, O):
         assert (y3[b] - y[b]).abs().max().item() <= 1e-5 * ref[b].abs().max().item()
 
 
+def test_winograd_f16x2_maxima_handed_over(dev, O):
+    """P2LAmax: an (unsplit 16x16 Winograd) launch writes one partial maximum of |y| (and of the
+    pooled |yp|) per block; the launch that reads the tensor takes its per-image power of two from
+    them instead of running its own max-|x| pass.  The partials reduce to the exact per-image
+    maxima; a consumer without prologue gives the same bits either way; with a fused prologue it
+    scales by the bound max|s| max|x| + max|t| -- a different power of two at most, same values."""
+    from pix2latent_amd import _native as N
+    O.DEFAULT_FORM = N.FORM_WINO_ANY
+    g = torch.Generator().manual_seed(9)
+    B, H, C1, C2 = 3, 32, 64, 128
+    x = torch.randn(B, C1, H, H, generator=g)
+    x[1] *= 1e-5
+    w1 = torch.randn(C2, C1, 3, 3, generator=g) / math.sqrt(9 * C1)
+    w2 = torch.randn(C1, C2, 3, 3, generator=g) / math.sqrt(9 * C2)
+    b1 = 0.1 * torch.randn(C2, generator=g)
+    wp1 = O.pack_conv_weight(w1.to(dev), 9, C2, C1, wfmt=2)
+    wp2 = O.pack_conv_weight(w2.to(dev), 9, C1, C2, wfmt=2)
+    y, yp, (am, amp) = O.conv(nhwc(x, dev), wp1, B, H, H, C1, C2, 9, wfmt=2, bias=b1.to(dev), act=N.ACT_RELU,
+                              pool=N.POOL_MAX, want_amax=True)
+    assert am is not None and am.shape == (B, (H // 16) ** 2 * (C2 // 64))
+    assert torch.equal(am.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
+    assert torch.equal(amp.amax(dim=1), yp.abs().amax(dim=(1, 2, 3)))
+    # consumer without prologue: bit-identical with and without the hand-over
+    z0, _ = O.conv(y, wp2, B, H, H, C2, C1, 9, wfmt=2)
+    z1, _ = O.conv(y, wp2, B, H, H, C2, C1, 9, wfmt=2, amax_in=am)
+    assert torch.equal(z0, z1)
+    ref = F.conv2d(F.relu(F.conv2d(x, w1, b1, padding=1)), w2, None, padding=1)
+    assert relerr(nchw(z1), ref) < 2e-5
+    # consumer with a fused affine + ReLU prologue: the bound replaces the exact maximum
+    s = 0.5 + torch.rand(B, C2, generator=g)
+    t = 0.3 * torch.randn(B, C2, generator=g)
+    kw = dict(wfmt=2, pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=C2)
+    p0, _ = O.conv(y, wp2, B, H, H, C2, C1, 9, **kw)
+    p1, _ = O.conv(y, wp2, B, H, H, C2, C1, 9, amax_in=am, **kw)
+    assert (p0 - p1).abs().max().item() <= 1e-6 * p0.abs().max().item()
+    # the pooled tensor feeds a conv at half resolution (16^2: the 16x16 kernel under WINO_ANY)
+    q0, _ = O.conv(yp, wp2, B, H // 2, H // 2, C2, C1, 9, wfmt=2)
+    q1, _ = O.conv(yp, wp2, B, H // 2, H // 2, C2, C1, 9, wfmt=2, amax_in=amp)
+    assert torch.equal(q0, q1)
+    # other producers: the kernels that end in the vector epilogue -- 1x1 (bf16x3 pointwise and exact
+    # fp32), direct 3x3, sub-pixel (upsample-fused) 3x3 with its four output phases
+    w11 = torch.randn(C2, C1, 1, 1, generator=g) / math.sqrt(C1)
+    for wf in (3, 0):
+        wp11 = O.pack_conv_weight(w11.to(dev), 1, C2, C1, wfmt=wf)
+        y11, _, (am11, _) = O.conv(nhwc(x, dev), wp11, B, H, H, C1, C2, 1, wfmt=wf, bias=b1.to(dev), want_amax=True)
+        assert am11 is not None and torch.equal(am11.amax(dim=1), y11.abs().amax(dim=(1, 2, 3)))
+        r0, _ = O.conv(y11, wp2, B, H, H, C2, C1, 9, wfmt=2)
+        r1, _ = O.conv(y11, wp2, B, H, H, C2, C1, 9, wfmt=2, amax_in=am11)
+        assert torch.equal(r0, r1)
+    wpd = O.pack_conv_weight(w1.to(dev), 9, C2, C1, wfmt=1)
+    yd, _, (amd, _) = O.conv(nhwc(x, dev), wpd, B, H, H, C1, C2, 9, wfmt=1, act=N.ACT_RELU, want_amax=True,
+                             splitk=1)   # (a split-K launch ends in the finish kernel: no maxima)
+    assert amd is not None and torch.equal(amd.amax(dim=1), yd.abs().amax(dim=(1, 2, 3)))
+    xs = torch.randn(B, C1, H // 2, H // 2, generator=g)
+    yu, _, (amu, _) = O.conv(nhwc(xs, dev), wpd, B, H, H, C1, C2, 9, wfmt=1, ups=True, want_amax=True, splitk=1)
+    if amu is not None:
+        assert torch.equal(amu.amax(dim=1), yu.abs().amax(dim=(1, 2, 3)))
+
+
 @pytest.mark.parametrize('shape', [(32, 256, 256, 2), (16, 512, 512, 4), (32, 512, 256, 2)],
                          ids=['32x32-256to256', '16x16-512to512', '32x32-512to256'])
 def test_winograd_k_sliced_small_grid_layers(dev, O, shape):
