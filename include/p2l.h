@@ -420,6 +420,12 @@ int p2l_softmax_bwd(const float* P, const float* dP, float* dS, int64_t rows,
 int p2l_maxpool2_bwd(const float* y, int y_ld, const float* dyp, int dyp_ld,
                      const float* add, int add_ld, float* dy, int dy_ld, int Bn,
                      int H, int W, int C, int relu_mask, void* stream);
+/* same, and one partial maximum of |dy| per block for the conv that reads dy next (P2LAmax.in):
+ * amax_out [Bn][p2l_maxpool2_bwd_amax_slots(H, W, C)] floats, or NULL */
+int p2l_maxpool2_bwd_amax_slots(int H, int W, int C);
+int p2l_maxpool2_bwd_amax(const float* y, int y_ld, const float* dyp, int dyp_ld,
+                          const float* add, int add_ld, float* dy, int dy_ld, int Bn, int H,
+                          int W, int C, int relu_mask, float* amax_out, void* stream);
 /* dy = (y>0) ? g : 0  (plain ReLU mask, used where no pool follows) */
 int p2l_relu_mask(const float* y, int y_ld, const float* g, int g_ld, float* dy,
                   int dy_ld, int64_t P, int C, void* stream);

@@ -212,7 +212,7 @@ EXPORTS = [
     'p2l_attn_bwd_dv', 'p2l_attn_bwd_qk_ws_bytes', 'p2l_attn_bwd_qk',
     'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
-    'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd',
+    'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd', 'p2l_maxpool2_bwd_amax', 'p2l_maxpool2_bwd_amax_slots',
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',
     'p2l_weight_sum', 'p2l_weight_map', 'p2l_l1_loss_nblk', 'p2l_l1_loss_fwd',
     'p2l_l1_loss_bwd', 'p2l_lpips_normalize', 'p2l_lpips_tap_nblk', 'p2l_lpips_tap_fwd',

@@ -1082,9 +1082,14 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     if (d->splitk > 1 && wino_split(d) == d->splitk) return 0;
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64);
   }
-  if (thin_shape(d) >= 0 || d->ups > 2 || effective_splitk(d) > 1) return 0;
+  if (d->ups > 2 || effective_splitk(d) > 1) return 0;
   ConvK k{};
   if (choose_tile(d, k) != P2L_OK || k.tb_log != 0 || k.partial) return 0;
+  const int tm = thin_shape(d);
+  if (tm >= 0) {                                       // three-channel image convs: the thin-input kernel only
+    const bool geom = k.tw_log == 4 && k.th_log == 3;
+    return (tm == 1 && geom) ? k.tiles_x * k.tiles_y : 0;
+  }
   const int nnt = pw_shape(d) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
   return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1);
 }
@@ -1190,7 +1195,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   {
     const P2LAmax* am = ex ? &ex->amax : (arb ? &arb->amax : nullptr);
     if (am && use_h2 && am->in && am->in_n > 0) { k.amax_in = am->in; k.amax_in_n = am->in_n; }
-    const int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
+    int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
+    if (thin_shape(d) >= 0 && ex && (ex->oscale || ex->noise)) nslots = 0;   // (generic kernel then)
     if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
   }
   if (k.splitk > 1) {

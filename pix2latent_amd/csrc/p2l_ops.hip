@@ -334,21 +334,23 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* P, const 
 // ---------------------------------------------------------------------------
 // pooling / relu backward
 // ---------------------------------------------------------------------------
+// (grid.y = image: a block stays inside one image, so that it can leave ONE partial maximum of
+// what it wrote for the conv that reads dy next -- P2LAmax, amax_out[b][gridDim.x])
 __global__ void maxpool2_bwd_kernel(const float* y, int y_ld, const float* dyp,
                                     int dyp_ld, const float* add, int add_ld,
                                     float* dy, int dy_ld, int Bn, int H, int W,
-                                    int C, int relu_mask) {
+                                    int C, int relu_mask, float* amax_out) {
   // one thread per (quad, float4 channel)
   const int C4 = C >> 2, Hh = H >> 1, Wh = W >> 1;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t total = (size_t)Bn * Hh * Wh * C4;
-  if (idx >= total) return;
+  const size_t total = (size_t)Hh * Wh * C4;
+  const int b = blockIdx.y;
+  float mx = 0.f;
+  if (idx < total) {
   const int c = (int)(idx % C4) * 4;
   size_t q = idx / C4;
   const int qx = (int)(q % Wh);
-  q /= Wh;
-  const int qy = (int)(q % Hh);
-  const int b = (int)(q / Hh);
+  const int qy = (int)(q / Wh);
   const size_t pq = ((size_t)b * Hh + qy) * Wh + qx;
   const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + pq * dyp_ld + c);
   size_t pix[4];
@@ -381,6 +383,17 @@ __global__ void maxpool2_bwd_kernel(const float* y, int y_ld, const float* dyp,
       r.w = v[s].w > 0.f ? r.w : 0.f;
     }
     *reinterpret_cast<f32x4*>(dy + pix[s] * dy_ld + c) = r;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+  }
+  }
+  if (amax_out != nullptr) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      amax_out[(size_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -947,16 +960,27 @@ extern "C" int p2l_softmax_bwd(const float* P, const float* dP, float* dS,
   return p2l_check_launch();
 }
 
+extern "C" int p2l_maxpool2_bwd_amax_slots(int H, int W, int C) {
+  if (C % 4 || (H & 1) || (W & 1)) return 0;
+  return (int)cdiv((size_t)(H / 2) * (W / 2) * (C / 4), 256);
+}
+extern "C" int p2l_maxpool2_bwd_amax(const float* y, int y_ld, const float* dyp,
+                                     int dyp_ld, const float* add, int add_ld, float* dy,
+                                     int dy_ld, int Bn, int H, int W, int C,
+                                     int relu_mask, float* amax_out, void* stream) {
+  if (C % 4 || (H & 1) || (W & 1) || Bn < 1 || Bn > 65535) return P2L_EINVAL;
+  const size_t per_image = (size_t)(H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(cdiv(per_image, 256), Bn), dim3(256), 0,
+                     ST(stream), y, y_ld, dyp, dyp_ld, add, add_ld, dy, dy_ld, Bn, H,
+                     W, C, relu_mask, amax_out);
+  return p2l_check_launch();
+}
 extern "C" int p2l_maxpool2_bwd(const float* y, int y_ld, const float* dyp,
                                 int dyp_ld, const float* add, int add_ld, float* dy,
                                 int dy_ld, int Bn, int H, int W, int C,
                                 int relu_mask, void* stream) {
-  if (C % 4 || (H & 1) || (W & 1)) return P2L_EINVAL;
-  const size_t total = (size_t)Bn * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
-                     ST(stream), y, y_ld, dyp, dyp_ld, add, add_ld, dy, dy_ld, Bn, H,
-                     W, C, relu_mask);
-  return p2l_check_launch();
+  return p2l_maxpool2_bwd_amax(y, y_ld, dyp, dyp_ld, add, add_ld, dy, dy_ld, Bn, H, W, C, relu_mask,
+                               nullptr, stream);
 }
 extern "C" int p2l_relu_mask(const float* y, int y_ld, const float* g, int g_ld,
                              float* dy, int dy_ld, int64_t P, int C, void* stream) {

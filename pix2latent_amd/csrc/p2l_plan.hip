@@ -780,6 +780,10 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
     const int n1 = conv_amax_slots(f), n2 = conv_amax_slots(d);
     if (n1 > max_slots) max_slots = n1;
     if (n2 > max_slots) max_slots = n2;
+    if (vgg_pool_after(i) && i >= 1) {
+      const int n3 = p2l_maxpool2_bwd_amax_slots(h, w, kVggCout[i]);
+      if (n3 > max_slots) max_slots = n3;
+    }
   }
   L.tgt16 = a.take((size_t)B * H * W * 16);
   L.wsrc = a.take((size_t)B * H * W);
@@ -982,8 +986,14 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
       const int P = hp * wp, C = kVggCout[prev];
       RET_IF(p2l_lpips_tap_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k],
                                cache->wt[k], P, Wk + L.gs, gtap, B, P, C, st));
-      amax_drop(ga);                                   // (written by a non-conv kernel)
-      RET_IF(p2l_maxpool2_bwd(Wk + L.y[prev], C, gb, C, gtap, C, ga, C, B, hp, wp, C, 1, st));
+      // (written by a non-conv kernel, which leaves its own maxima for the dgrad that reads ga next)
+      amax_drop(ga);
+      float* so = nullptr;
+      int set_o = -1;
+      const int ns = p2l_maxpool2_bwd_amax_slots(hp, wp, C);
+      if (g_amax && prev >= 1 && ns > 0 && (size_t)ns * B <= g_amax->set_floats) so = g_amax->take(&set_o);
+      RET_IF(p2l_maxpool2_bwd_amax(Wk + L.y[prev], C, gb, C, gtap, C, ga, C, B, hp, wp, C, 1, so, st));
+      if (so) g_amax->put(ga, B, hp, wp, C, so, ns, set_o);
       --pi;
       continue;  // ga already holds the masked gradient of conv_{i-1}
     }

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const Con
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int p = 0; p < 3; ++p) bw[ks][p] = wq[(ks * 3 + p) * 64];
+  float blk_amax = 0.f, blk_amaxp = 0.f;                   // (P2LAmax: maxima of what this block stores)
   for (int nt = 0; nt < ntiles; ++nt) {
     f32x16 acc;
 #pragma unroll
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const Con
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     EpiSums S;
+    S.amax = blk_amax; S.amaxp = blk_amaxp;
     const int n = nt * 32 + c4 * 4;
     if (n < k.n_store) {
       f32x4 v[4];
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const Con
         v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * 36 + c4 * 4) * k.alpha;
       epi_item<ARB ? 1 : 0>(k, v, b, y0 + 2 * wave, x0 + 2 * q, n, 0, 0, 0, S);
     }
+    blk_amax = S.amax; blk_amaxp = S.amaxp;
     __builtin_amdgcn_wave_barrier();
     if (arb) {                                            // (block-uniform)
       f32x4 sgx = S.sgx, sg = S.sg;
@@ -167,6 +170,22 @@ __global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const Con
         k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
       }
       __syncthreads();
+    }
+  }
+  // this block's partial maxima of what it stored, for the conv that reads the tensor next (P2LAmax)
+  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      blk_amax = fmaxf(blk_amax, __shfl_xor(blk_amax, o, 64));
+      blk_amaxp = fmaxf(blk_amaxp, __shfl_xor(blk_amaxp, o, 64));
+    }
+    __syncthreads();
+    if (lane == 0) { red[wave * 2] = blk_amax; red[wave * 2 + 1] = blk_amaxp; }
+    __syncthreads();
+    if (tid == 0) {
+      const size_t slot = (size_t)b * k.amax_out_n + tile_in_image;
+      if (k.amax_out != nullptr) k.amax_out[slot] = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
     }
   }
 }

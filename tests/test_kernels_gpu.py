@@ -430,6 +430,21 @@ def test_winograd_f16x2_maxima_handed_over(dev, O):
     yu, _, (amu, _) = O.conv(nhwc(xs, dev), wpd, B, H, H, C1, C2, 9, wfmt=1, ups=True, want_amax=True, splitk=1)
     if amu is not None:
         assert torch.equal(amu.amax(dim=1), yu.abs().amax(dim=(1, 2, 3)))
+    # the three-channel image conv (first VGG conv) and the max-pool backward kernel leave theirs too
+    x3 = torch.randn(B, 3, H, H, generator=g)
+    w3 = torch.randn(C1, 3, 3, 3, generator=g) / math.sqrt(27)
+    wp3 = O.pack_conv_weight(w3.to(dev), 9, C1, 16, wfmt=4)
+    y3, _, (am3, _) = O.conv(_pad_c(x3, 16).to(dev), wp3, B, H, H, 16, C1, 9, wfmt=4, act=N.ACT_RELU, want_amax=True)
+    assert am3 is not None and am3.shape[1] == (H // 8) * (H // 16)
+    assert torch.equal(am3.amax(dim=1), y3.abs().amax(dim=(1, 2, 3)))
+    dyp = torch.randn(B, H // 2, H // 2, C2, generator=g).to(dev)
+    ns = N.lib().p2l_maxpool2_bwd_amax_slots(H, H, C2)
+    amm = torch.full((B, ns), -1.0, device=dev)
+    dy = torch.empty(B, H, H, C2, device=dev)
+    N.check(N.lib().p2l_maxpool2_bwd_amax(N.ptr(y), C2, N.ptr(dyp), C2, None, 0, N.ptr(dy), C2, B, H, H, C2, 1,
+                                          N.ptr(amm), N.stream()), 'maxpool2_bwd_amax')
+    assert torch.equal(amm.amax(dim=1), dy.abs().amax(dim=(1, 2, 3)))
+    assert torch.equal(dy, O.maxpool2_bwd(y, dyp, relu_mask=True))
 
 
 @pytest.mark.parametrize('shape', [(32, 256, 256, 2), (16, 512, 512, 4), (32, 512, 256, 2)],
