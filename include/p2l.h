@@ -113,7 +113,7 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
  * needs 2*B*p2l_conv_arb_nblk(d)*Cout floats. */
 /* Per-image maxima of |tensor|, handed from the conv that WRITES a tensor to the conv that reads
  * it, so that an fp16 x 2 Winograd launch (P2L_WFMT_BF16X3W) does not need its own pass over the
- * input.  Producer: `out` (and `outp` for the pooled output) receive one partial maximum per block,
+ * input.  Producer: `out` (and `outp` for the pooled output) receive one partial maximum per wave of every block,
  * [B][p2l_conv_amax_slots(d)] floats each; a launch that cannot produce them (slots == 0) ignores
  * the fields.  Consumer: `in` = the partial maxima of the tensor it reads as x ([B][in_n], the RAW
  * tensor: a fused prologue x*s+t is bounded by max|s| max|x| + max|t| inside the kernel); NULL =
@@ -420,7 +420,7 @@ int p2l_softmax_bwd(const float* P, const float* dP, float* dS, int64_t rows,
 int p2l_maxpool2_bwd(const float* y, int y_ld, const float* dyp, int dyp_ld,
                      const float* add, int add_ld, float* dy, int dy_ld, int Bn,
                      int H, int W, int C, int relu_mask, void* stream);
-/* same, and one partial maximum of |dy| per block for the conv that reads dy next (P2LAmax.in):
+/* same, and one partial maximum of |dy| per wave for the conv that reads dy next (P2LAmax.in):
  * amax_out [Bn][p2l_maxpool2_bwd_amax_slots(H, W, C)] floats, or NULL */
 int p2l_maxpool2_bwd_amax_slots(int H, int W, int C);
 int p2l_maxpool2_bwd_amax(const float* y, int y_ld, const float* dyp, int dyp_ld,

@@ -1072,7 +1072,7 @@ static bool wino_h2(const P2LConv* d) {
 // P2LAmax producers: launches whose blocks each cover one tile of ONE image and end in the shared
 // epilogue -- the unsplit 16x16 Winograd kernel (16x16 pixels x 64 channels) and the kernels that
 // go through epilogue_vec (direct 3x3, sub-pixel forward: 4 phases, 1x1 in both arithmetics:
-// 128 pixels x 32 / 64 channels).  Split-K launches (finish kernel), the 8x16 Winograd kernel, the
+// 128 pixels x 32 / 64 channels); every WAVE of a block writes its own partial.  Split-K launches (finish kernel), the 8x16 Winograd kernel, the
 // three-channel image kernels and tiles that span images write none.
 static int effective_splitk(const P2LConv* d);
 extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
@@ -1080,7 +1080,7 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   if (wino_shape(d)) {
     if (d->H % 16 || d->W % 16 || (d->form & P2L_FORM_WINO_8X16)) return 0;
     if (d->splitk > 1 && wino_split(d) == d->splitk) return 0;
-    return (d->H / 16) * (d->W / 16) * (d->Cout / 64);
+    return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
   if (d->ups > 2 || effective_splitk(d) > 1) return 0;
   ConvK k{};
@@ -1088,10 +1088,10 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   const int tm = thin_shape(d);
   if (tm >= 0) {                                       // three-channel image convs: the thin-input kernel only
     const bool geom = k.tw_log == 4 && k.th_log == 3;
-    return (tm == 1 && geom) ? k.tiles_x * k.tiles_y : 0;
+    return (tm == 1 && geom) ? k.tiles_x * k.tiles_y * 4 : 0;
   }
   const int nnt = pw_shape(d) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
-  return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1);
+  return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1) * 4;
 }
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
   const size_t h2 = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;

@@ -389,21 +389,16 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
   if (k.arb_x != nullptr)
     epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
                              (size_t)b0 * k.arb_nblk + tile_in_image, n0);
-  // this block's partial maxima of what it stored, for the launch that reads the tensor next
-  // (P2LAmax; the launcher only sets the pointers for tiles inside one image)
+  // this block's partial maxima of what it stored (one per wave), for the launch that reads the
+  // tensor next (P2LAmax; the launcher only sets the pointers for tiles inside one image)
   if (k.amax_out != nullptr || k.amax_outp != nullptr) {
     float m = S.amax, mp = S.amaxp;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
-    __syncthreads();                      // (tile dumps / partial sums read)
-    if (lane == 0) { smem[wave * 2] = m; smem[wave * 2 + 1] = mp; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      m = fmaxf(fmaxf(smem[0], smem[2]), fmaxf(smem[4], smem[6]));
-      mp = fmaxf(fmaxf(smem[1], smem[3]), fmaxf(smem[5], smem[7]));
+    if (lane == 0) {                                   // one partial per WAVE: no block reduction
       const int nph = osh ? 4 : 1;
       const size_t slot = (size_t)b0 * k.amax_out_n +
-                          ((size_t)tile_in_image * k.n_ntiles + n0 / COLS) * nph + (osh ? ph_y * 2 + ph_x : 0);
+                          (((size_t)tile_in_image * k.n_ntiles + n0 / COLS) * nph + (osh ? ph_y * 2 + ph_x : 0)) * 4 + wave;
       if (k.amax_out != nullptr) k.amax_out[slot] = m;
       if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
     }

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* P, const 
 // pooling / relu backward
 // ---------------------------------------------------------------------------
 // (grid.y = image: a block stays inside one image, so that it can leave ONE partial maximum of
-// what it wrote for the conv that reads dy next -- P2LAmax, amax_out[b][gridDim.x])
+// what it wrote per wave for the conv that reads dy next -- P2LAmax, amax_out[b][gridDim.x * 4])
 __global__ void maxpool2_bwd_kernel(const float* y, int y_ld, const float* dyp,
                                     int dyp_ld, const float* add, int add_ld,
                                     float* dy, int dy_ld, int Bn, int H, int W,
@@ -386,14 +386,11 @@ __global__ void maxpool2_bwd_kernel(const float* y, int y_ld, const float* dyp,
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
   }
   }
-  if (amax_out != nullptr) {
-    __shared__ float red[4];
+  if (amax_out != nullptr) {                           // one partial per wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      amax_out[(size_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if ((threadIdx.x & 63) == 0)
+      amax_out[((size_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = mx;
   }
 }
 
@@ -962,7 +959,7 @@ extern "C" int p2l_softmax_bwd(const float* P, const float* dP, float* dS,
 
 extern "C" int p2l_maxpool2_bwd_amax_slots(int H, int W, int C) {
   if (C % 4 || (H & 1) || (W & 1)) return 0;
-  return (int)cdiv((size_t)(H / 2) * (W / 2) * (C / 4), 256);
+  return (int)cdiv((size_t)(H / 2) * (W / 2) * (C / 4), 256) * 4;
 }
 extern "C" int p2l_maxpool2_bwd_amax(const float* y, int y_ld, const float* dyp,
                                      int dyp_ld, const float* add, int add_ld, float* dy,

@@ -172,20 +172,18 @@ __global__ __launch_bounds__(256, ARB ? 3 : 4) void conv_thinin_kernel(const Con
       __syncthreads();
     }
   }
-  // this block's partial maxima of what it stored, for the conv that reads the tensor next (P2LAmax)
+  // this block's partial maxima of what it stored (one per wave), for the conv that reads the tensor
+  // next (P2LAmax)
   if (k.amax_out != nullptr || k.amax_outp != nullptr) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       blk_amax = fmaxf(blk_amax, __shfl_xor(blk_amax, o, 64));
       blk_amaxp = fmaxf(blk_amaxp, __shfl_xor(blk_amaxp, o, 64));
     }
-    __syncthreads();
-    if (lane == 0) { red[wave * 2] = blk_amax; red[wave * 2 + 1] = blk_amaxp; }
-    __syncthreads();
-    if (tid == 0) {
-      const size_t slot = (size_t)b * k.amax_out_n + tile_in_image;
-      if (k.amax_out != nullptr) k.amax_out[slot] = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
-      if (k.amax_outp != nullptr) k.amax_outp[slot] = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    if (lane == 0) {
+      const size_t slot = (size_t)b * k.amax_out_n + (size_t)tile_in_image * 4 + wave;
+      if (k.amax_out != nullptr) k.amax_out[slot] = blk_amax;
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = blk_amaxp;
     }
   }
 }

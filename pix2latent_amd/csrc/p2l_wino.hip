@@ -924,22 +924,18 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     P2L_TR(3 + j, 63);
   }
 #undef P2L_TR
-  // this block's partial maxima of what it stored, for the launch that reads the tensor next (P2LAmax)
+  // this block's partial maxima of what it stored (one per wave), for the launch that reads the tensor
+  // next (P2LAmax)
   if ((k.amax_out != nullptr || k.amax_outp != nullptr) && !split) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       blk_amax = fmaxf(blk_amax, __shfl_xor(blk_amax, o, 64));
       blk_amaxp = fmaxf(blk_amaxp, __shfl_xor(blk_amaxp, o, 64));
     }
-    if (lane == 0) { red[wave * 2] = blk_amax; red[wave * 2 + 1] = blk_amaxp; }
-    __syncthreads();
-    if (tid == 0) {
-      float m = 0.f, mp = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) { m = fmaxf(m, red[w * 2]); mp = fmaxf(mp, red[w * 2 + 1]); }
-      const size_t slot = (size_t)b * k.amax_out_n + (size_t)tile_in_image * k.n_ntiles + (n0 >> 6);
-      if (k.amax_out != nullptr) k.amax_out[slot] = m;
-      if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
+    if (lane == 0) {
+      const size_t slot = (size_t)b * k.amax_out_n + ((size_t)tile_in_image * k.n_ntiles + (n0 >> 6)) * 8 + wave;
+      if (k.amax_out != nullptr) k.amax_out[slot] = blk_amax;
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = blk_amaxp;
     }
   }
 }

@@ -392,7 +392,7 @@ def test_winograd_f16x2_maxima_handed_over(dev, O):
     wp2 = O.pack_conv_weight(w2.to(dev), 9, C1, C2, wfmt=2)
     y, yp, (am, amp) = O.conv(nhwc(x, dev), wp1, B, H, H, C1, C2, 9, wfmt=2, bias=b1.to(dev), act=N.ACT_RELU,
                               pool=N.POOL_MAX, want_amax=True)
-    assert am is not None and am.shape == (B, (H // 16) ** 2 * (C2 // 64))
+    assert am is not None and am.shape == (B, (H // 16) ** 2 * (C2 // 64) * 8)      # (one partial per wave)
     assert torch.equal(am.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
     assert torch.equal(amp.amax(dim=1), yp.abs().amax(dim=(1, 2, 3)))
     # consumer without prologue: bit-identical with and without the hand-over
@@ -435,7 +435,7 @@ def test_winograd_f16x2_maxima_handed_over(dev, O):
     w3 = torch.randn(C1, 3, 3, 3, generator=g) / math.sqrt(27)
     wp3 = O.pack_conv_weight(w3.to(dev), 9, C1, 16, wfmt=4)
     y3, _, (am3, _) = O.conv(_pad_c(x3, 16).to(dev), wp3, B, H, H, 16, C1, 9, wfmt=4, act=N.ACT_RELU, want_amax=True)
-    assert am3 is not None and am3.shape[1] == (H // 8) * (H // 16)
+    assert am3 is not None and am3.shape[1] == (H // 8) * (H // 16) * 4
     assert torch.equal(am3.amax(dim=1), y3.abs().amax(dim=(1, 2, 3)))
     dyp = torch.randn(B, H // 2, H // 2, C2, generator=g).to(dev)
     ns = N.lib().p2l_maxpool2_bwd_amax_slots(H, H, C2)
