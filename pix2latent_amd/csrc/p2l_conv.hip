@@ -1194,7 +1194,11 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   {
     const P2LAmax* am = ex ? &ex->amax : (arb ? &arb->amax : nullptr);
-    if (am && use_h2 && am->in && am->in_n > 0) { k.amax_in = am->in; k.amax_in_n = am->in_n; }
+    // consumers: the fp16 x 2 Winograd launch (instead of its own max-|x| pass) and the pointwise
+    // kernel (which takes the fp16 x 2 form only with handed-over maxima)
+    if (am && am->in && am->in_n > 0 && (use_h2 || (pw_shape(d) && !(d->form & P2L_FORM_WINO_BF3)))) {
+      k.amax_in = am->in; k.amax_in_n = am->in_n;
+    }
     int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
     if (thin_shape(d) >= 0 && ex && (ex->oscale || ex->noise)) nslots = 0;   // (generic kernel then)
     if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
@@ -1283,11 +1287,18 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (pw_shape(d)) {
     ConvK kp = k;
     kp.w = w + (size_t)d->Cout * d->Cin;
+    if (k.amax_in != nullptr) {                          // fp16 x 2 image behind the bf16 x 3 one
+      kp.w += (size_t)d->Cout * d->Cin * 3 / 2;
+      kp.w_tail = reinterpret_cast<const unsigned*>(kp.w + (size_t)d->Cout * d->Cin);
+    }
     kp.n_ntiles = d->Cout / 64;
     kp.nchunks = d->Cin / 64;
     kp.splitk = 1;
     rc = p2l_pw_launch(kp, d->pro, st);
-    if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    if (prof_slot >= 0) {
+      if (k.amax_in != nullptr) g_prof.nprod[prof_slot] = 3;
+      (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+    }
     return rc;
   }
   // ---- 3-channel image convs ----
@@ -1634,7 +1645,8 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
 extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int wfmt) {
   const size_t direct = (size_t)taps * N_pad * K_pad;
   if (wfmt == P2L_WFMT_F32) return direct;
-  if (wfmt == P2L_WFMT_PW) return direct + direct * 3 / 2;     // fp32 layout + bf16x3 image
+  if (wfmt == P2L_WFMT_PW)                                      // fp32 layout + bf16x3 image + fp16x2 image
+    return direct + direct * 3 / 2 + p2l_pw_h2_weight_floats(N_pad, K_pad);
   size_t n = direct * 3 / 2;
   if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
     n += p2l_wino_weight_floats(N_pad, K_pad) + p2l_wino_h2_weight_floats(N_pad, K_pad);
@@ -1652,7 +1664,10 @@ extern "C" int p2l_pack_conv_weight_pw(const float* w_oihw, int O, int I, int N_
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, w_oihw, w_packed + total, O, I, 1, N_pad, K_pad, 16,
                      transpose_flip, 1);
-  return p2l_check_launch();
+  rc = p2l_check_launch();
+  if (rc) return rc;
+  return p2l_pw_pack_h2(w_oihw, O, I, N_pad, K_pad, transpose_flip, w_packed + total + total * 3 / 2,
+                        (hipStream_t)stream);
 }
 
 // P2L_WFMT_BF16X3T: the direct bf16x3 image followed by the thin image of a conv with three real

@@ -60,6 +60,18 @@ struct ConvK {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// fp16 x 2 arithmetic (16x16 Winograd kernel, pointwise kernel: include/p2l.h P2L_WFMT_BF16X3W / _PW)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// power-of-two scale that puts max |x| (bits `mx`; 4x headroom for the Winograd input transform)
+// below 2^15, and its inverse
+__device__ __forceinline__ void h2_scales(unsigned mx, float& scale, float& inv) {
+  int E = (int)((mx >> 23) & 0xffu);
+  E = E < 40 ? 40 : (E > 254 ? 254 : E);
+  scale = __builtin_bit_cast(float, (unsigned)(266 - E) << 23);      // 2^(139 - E)
+  inv = __builtin_bit_cast(float, (unsigned)(E - 12) << 23);         // 2^(E - 139)
+}
 
 __device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
   if (act == P2L_ACT_RELU) {
@@ -424,6 +436,8 @@ extern "C" size_t p2l_wino_weight_floats(int N_pad, int K_pad);
 extern "C" int p2l_wino_weight_ok(int N_pad, int K_pad);
 extern "C" int p2l_wino_split_factor(int H, int W, int Cin, int Cout);
 extern "C" size_t p2l_wino_h2_weight_floats(int N_pad, int K_pad);
+extern "C" size_t p2l_pw_h2_weight_floats(int N_pad, int K_pad);
+int p2l_pw_pack_h2(const float* w_oihw, int O, int I, int N_pad, int K_pad, int flip, float* dst, hipStream_t st);
 int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
                   float* dst, hipStream_t st);
 int p2l_wino_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

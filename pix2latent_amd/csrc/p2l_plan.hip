@@ -514,6 +514,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
       ConvCall oc = mk_conv(B, H, H, C / 2, C, 1);
       oc.x = W + L.att_ag; oc.w = m->att_w[3]; oc.y = W + L.att_y;
       oc.d.alpha = m->gamma; oc.res = x; oc.d.res_ld = C;
+      oc.want_amax = true;
       RET_IF(run_conv(oc, skws, L.skws_floats, st));
       x = W + L.att_y;
     }
@@ -526,7 +527,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c0.x = x; c0.w = g.w[0]; c0.bias = g.b[0]; c0.y = W + o.h1;
     c0.d.pro = P2L_PRO_AFFINE_RELU; c0.d.pro_bstride = CT;
     c0.ps = W + L.s + g.cbn_off[0]; c0.pt = W + L.t + g.cbn_off[0];
-    c0.want_amax = !g.up;                              // (an up block's conv_1 takes the sub-pixel form)
+    c0.want_amax = !g.up;                              // (an up block's conv_1 takes the sub-pixel, bf16 x 3 form)
     RET_IF(run_conv(c0, skws, L.skws_floats, st));
     // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
     ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
@@ -540,6 +541,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c2.x = W + o.h2; c2.w = g.w[2]; c2.bias = g.b[2]; c2.y = W + o.h3;
     c2.d.pro = P2L_PRO_AFFINE_RELU; c2.d.pro_bstride = CT;
     c2.ps = W + L.s + g.cbn_off[2]; c2.pt = W + L.t + g.cbn_off[2];
+    c2.want_amax = true;                               // (conv_3 is a pointwise conv: fp16 x 2 with the maxima)
     RET_IF(run_conv(c2, skws, L.skws_floats, st));
     // conv_3 : 1x1 mid -> cout, + shortcut (channel-truncated, nearest x2)
     ConvCall c3 = mk_conv(B, o.Ho, o.Ho, mid, g.cout, 1);
@@ -547,6 +549,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c3.d.pro = P2L_PRO_AFFINE_RELU; c3.d.pro_bstride = CT;
     c3.ps = W + L.s + g.cbn_off[3]; c3.pt = W + L.t + g.cbn_off[3];
     c3.res = x; c3.d.res_ld = g.cin; c3.d.res_ups = g.up;
+    c3.want_amax = true;                               // (the next block's conv_0)
     RET_IF(run_conv(c3, skws, L.skws_floats, st));
     x = W + o.y;
     Cx = g.cout;
@@ -635,6 +638,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     else if (g.up) d1.d.pool = P2L_POOL_SUM;
     ArbArgs a1{W + o.h1, mid, W + L.s + g.cbn_off[1], W + L.t + g.cbn_off[1], CT, nullptr, 0,
                0, 0, W + L.ds + g.cbn_off[1], W + L.dt + g.cbn_off[1], CT};
+    d1.want_amax = true;
     RET_IF(run_dgrad_arb(d1, a1, gb, gd, part, skws, L.skws_floats, st));
     part += o.pf;
     // conv_0, + relu(cbn_0) backward + shortcut gradient from dy (= ga)
@@ -643,6 +647,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     const int skipC = (g.cin != g.cout) ? g.cin / 2 : g.cin;
     ArbArgs a0{xin, g.cin, W + L.s + g.cbn_off[0], W + L.t + g.cbn_off[0], CT, ga, g.cout,
                skipC, g.up, W + L.ds + g.cbn_off[0], W + L.dt + g.cbn_off[0], CT};
+    d0.want_amax = true;
     RET_IF(run_dgrad_arb(d0, a0, gc, gd, part, skws, L.skws_floats, st));
     part += o.pf;
     { float* tmp = ga; ga = gc; gc = tmp; }

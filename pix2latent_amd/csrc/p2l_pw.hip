@@ -182,7 +182,231 @@ __global__ __launch_bounds__(256, KS == 64 ? 2 : 4) void pw_bf3_kernel(const Con
 }
 
 
+// ---- fp16 x 2 form (include/p2l.h, P2L_WFMT_PW): the launch that wrote x handed its per-image
+// maxima over (P2LAmax), so the image's power of two is known without a pass over the input.
+// Same block, same stages; rows of 64 B ([h k0-7 | h k8-15 | m k0-7 | m k8-15], 16-byte chunk
+// index XOR bits 2-3 of the row: 16 consecutive rows hit 16 different bank groups), the split of
+// a value is cvt_pk | fma_mix | cvt_pk, three MFMAs per 32x32 tile and 16 channels instead of six.
+constexpr int PWH_SUB = 2;                                // 32-channel stages
+constexpr int PWH_A_FLOATS = PWH_SUB * 128 * 16, PWH_B_FLOATS = PWH_SUB * 64 * 16;
+constexpr int PWH_EPI_FLOATS = 4 * 32 * (64 + 4);         // the vector epilogue's tile dumps (epilogue_vec<2>)
+constexpr size_t PWH_LDS_BYTES =
+    (size_t)(PWH_A_FLOATS + PWH_B_FLOATS > PWH_EPI_FLOATS ? PWH_A_FLOATS + PWH_B_FLOATS : PWH_EPI_FLOATS) * sizeof(float);
+__device__ __forceinline__ int h2_chunk(int c, int row) { return c ^ ((row >> 2) & 3); }
+__device__ __forceinline__ void pw_store_split_h2(float* As, int row, int q4, const f32x4 x) {
+  const h16x4 h = __builtin_convertvector(x, h16x4);
+  const f32x4 w = __builtin_convertvector(h, f32x4);
+  const h16x4 m = __builtin_convertvector(x - w, h16x4);
+  char* rb = reinterpret_cast<char*>(As) + row * 64 + (q4 & 1) * 8;
+  *reinterpret_cast<h16x4*>(rb + h2_chunk(q4 >> 1, row) * 16) = h;
+  *reinterpret_cast<h16x4*>(rb + h2_chunk(2 + (q4 >> 1), row) * 16) = m;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
+  constexpr int KS = 32, VPP = KS / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + PWH_A_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int TW = 1 << k.tw_log, TH = 1 << k.th_log;
+  const int swz = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
+  const int tiles_per_image = k.tiles_x * k.tiles_y;
+  const int b0 = mt / tiles_per_image;                   // one image per tile (launcher)
+  const int tile_in_image = mt - b0 * tiles_per_image;
+  const int ty = tile_in_image / k.tiles_x, tx = tile_in_image - ty * k.tiles_x;
+  const int n0 = nt * 64;
+  const int y0 = ty << k.th_log, x0 = tx << k.tw_log;
+
+  // ---- the image's power of two from the handed-over maxima (bound for a fused prologue) ----
+  float x_scale, out_scale;
+  {
+    float a = 0.f, ms = 0.f, mt_ = 0.f;
+    for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b0 * k.amax_in_n + i]);
+    if (PRO != P2L_PRO_NONE) {
+      const float* ps = k.pro_s + (size_t)b0 * k.pro_bstride;
+      const float* pt = k.pro_t + (size_t)b0 * k.pro_bstride;
+      for (int c = tid; c < k.Cin; c += 256) { ms = fmaxf(ms, fabsf(ps[c])); mt_ = fmaxf(mt_, fabsf(pt[c])); }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      a = fmaxf(a, __shfl_xor(a, o, 64));
+      if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
+    }
+    if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mt_; }
+    __syncthreads();
+    a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
+    ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
+    mt_ = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
+    __syncthreads();                                     // (the first stage is staged there next)
+    if (PRO != P2L_PRO_NONE) a = (ms * a + mt_) * 1.001f;
+    float inv_x, sw, inv_w;
+    h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
+    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
+    out_scale = inv_x * inv_w;
+  }
+
+  // ---- A staging: 128 pixels x 8 float4 per stage = 4 items per thread ----------------------
+  constexpr int A_ITERS = 128 * VPP / 256;
+  const int av = tid & (VPP - 1);
+  int a_goff[A_ITERS];
+#pragma unroll
+  for (int it = 0; it < A_ITERS; ++it) {
+    const int p = (tid + 256 * it) / VPP;
+    const int Q = p >> 2, s = p & 3;
+    const int qx = Q & ((TW >> 1) - 1);
+    const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
+    const int iy = y0 + 2 * qy + (s >> 1), ix = x0 + 2 * qx + (s & 1);
+    a_goff[it] = ((b0 * k.H + iy) * k.W + ix) * k.x_ld + av * 4;
+  }
+  const int s_off = b0 * k.pro_bstride + av * 4;
+  // ---- B staging: [sub][64 rows][4 x 16 B] = 512 items per stage, 2 per thread; the packed image
+  // is [chunk][32-channel tile][32 rows][64 B]: the 2 tiles of this block are one 4 KB run
+  constexpr int B_ITERS = PWH_SUB * 256 / 256;
+  int b_goff[B_ITERS];
+#pragma unroll
+  for (int it = 0; it < B_ITERS; ++it) {
+    const int j = tid + 256 * it;
+    const int sub = j / 256, within = j - sub * 256;
+    b_goff[it] = (sub * (k.Cout >> 5) + (n0 >> 5)) * 32 * 16 + within * 4;
+  }
+  const int b_stage = PWH_SUB * (k.Cout >> 5) * 32 * 16;   // floats per stage of the image
+
+  f32x4 xr[A_ITERS], wr[B_ITERS], sr, tr;
+  auto load_regs = [&](int st) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it)
+      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + st * KS);
+    if (PRO != P2L_PRO_NONE) {
+      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + st * KS);
+      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + st * KS);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it)
+      wr[it] = *reinterpret_cast<const f32x4*>(k.w + (size_t)st * b_stage + b_goff[it]);
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      f32x4 v = xr[it];
+      if (PRO != P2L_PRO_NONE) {
+        v = v * sr + tr;
+        if (PRO == P2L_PRO_AFFINE_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      const int p = (tid + 256 * it) / VPP;
+      pw_store_split_h2(As + (av >> 2) * (128 * 16), p, av & 3, v * x_scale);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it)
+      *reinterpret_cast<f32x4*>(Bs + (tid + 256 * it) * 4) = wr[it];     // image copy
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int a_row = wave * 32 + l31;
+  const int a_h = h2_chunk(lhi, a_row) * 4, a_m = h2_chunk(2 + lhi, a_row) * 4;
+  const int b_h = h2_chunk(lhi, l31) * 4, b_m = h2_chunk(2 + lhi, l31) * 4;
+  const int nstages = k.Cin / KS;
+  load_regs(0);
+  write_lds();
+  __syncthreads();
+  for (int st = 0; st < nstages; ++st) {
+    const bool more = st + 1 < nstages;
+    if (more) load_regs(st + 1);
+#pragma unroll
+    for (int sub = 0; sub < PWH_SUB; ++sub) {
+      const float* ar = As + (sub * 128 + a_row) * 16;
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(ar + a_h);
+      const h16x8 am = *reinterpret_cast<const h16x8*>(ar + a_m);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float* br = Bs + (sub * 64 + j * 32 + l31) * 16;
+        const h16x8 bh = *reinterpret_cast<const h16x8*>(br + b_h);
+        const h16x8 bm = *reinterpret_cast<const h16x8*>(br + b_m);
+        f32x16 t = acc[j];                               // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, t, 0, 0, 0);
+        acc[j] = t;
+      }
+    }
+    __syncthreads();
+    if (more) write_lds();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] *= out_scale;  // (exact: a power of two)
+  epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
+}
+
+// fp16 x 2 image of a 1x1 weight: [K_pad/16][N_pad/32][32 rows][64 B], scaled by the layer's power
+// of two; tail[0] = bits of max |w|
+__global__ void pw_wmax_kernel(const float* w, size_t n, unsigned* tail) {
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(tail, __builtin_bit_cast(unsigned, mx));
+}
+__global__ void pw_pack_h2_kernel(const float* w, float* dst, int O, int I, int N_pad, int K_pad,
+                                  int flip, const unsigned* tail) {
+  // one thread per (chunk, 32-channel tile, row, k half): 8 values -> two 16-byte pieces
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)(K_pad >> 4) * N_pad * 2;
+  if (idx >= total) return;
+  float scale, inv;
+  h2_scales(tail[0], scale, inv);
+  const int kh = (int)(idx & 1);
+  size_t q = idx >> 1;
+  const int n = (int)(q % N_pad);
+  const int cc = (int)(q / N_pad);
+  const int N = flip ? I : O, K = flip ? O : I;
+  h16x8 ph, pm;
+  for (int e = 0; e < 8; ++e) {
+    const int kk = cc * 16 + kh * 8 + e;
+    float v = 0.f;
+    if (n < N && kk < K) v = flip ? w[(size_t)kk * I + n] : w[(size_t)n * I + kk];
+    const float x = v * scale;
+    const _Float16 h = (_Float16)x;
+    ph[e] = h; pm[e] = (_Float16)(x - (float)h);
+  }
+  const int row = n & 31;
+  char* rb = reinterpret_cast<char*>(dst) + (((size_t)cc * (N_pad >> 5) + (n >> 5)) * 32 + row) * 64;
+  *reinterpret_cast<h16x8*>(rb + h2_chunk(kh, row) * 16) = ph;
+  *reinterpret_cast<h16x8*>(rb + h2_chunk(2 + kh, row) * 16) = pm;
+}
+
 }  // namespace
+
+// floats of the fp16 x 2 image behind the bf16 x 3 image of a P2L_WFMT_PW buffer (+ 4 tail floats)
+extern "C" size_t p2l_pw_h2_weight_floats(int N_pad, int K_pad) { return (size_t)N_pad * K_pad + 4; }
+int p2l_pw_pack_h2(const float* w_oihw, int O, int I, int N_pad, int K_pad, int flip, float* dst,
+                   hipStream_t st) {
+  unsigned* tail = reinterpret_cast<unsigned*>(dst + (size_t)N_pad * K_pad);
+  if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return P2L_ELAUNCH;
+  const size_t nw = (size_t)O * I;
+  hipLaunchKernelGGL(pw_wmax_kernel, dim3((unsigned)(cdiv(nw, 256) < 256 ? cdiv(nw, 256) : 256)), dim3(256), 0, st,
+                     w_oihw, nw, tail);
+  const size_t total = (size_t)(K_pad >> 4) * N_pad * 2;
+  hipLaunchKernelGGL(pw_pack_h2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w_oihw, dst, O, I, N_pad,
+                     K_pad, flip, tail);
+  return p2l_check_launch();
+}
 
 int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
   dim3 grid(k.n_mtiles * k.n_ntiles), block(256);
@@ -196,6 +420,23 @@ int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL((pw_bf3_kernel<PRO, 32>), grid, block, PwCfg<32>::LDS_BYTES, st, k);  \
   } while (0)
+#define P2L_PWH(PRO)                                                                         \
+  do {                                                                                       \
+    static std::atomic<bool> attr_set{false};                                                \
+    if (!attr_set) {                                                                         \
+      (void)hipFuncSetAttribute((const void*)pw_h2_kernel<PRO>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+      attr_set = true;                                                                       \
+    }                                                                                        \
+    hipLaunchKernelGGL(pw_h2_kernel<PRO>, grid, block, PWH_LDS_BYTES, st, k);                \
+  } while (0)
+  if (k.amax_in != nullptr) {                          // fp16 x 2 (conv_launch_impl decides)
+    if (pro == P2L_PRO_NONE) P2L_PWH(P2L_PRO_NONE);
+    else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWH(P2L_PRO_AFFINE_RELU);
+    else P2L_PWH(P2L_PRO_AFFINE);
+    return p2l_check_launch();
+  }
+#undef P2L_PWH
   if (pro == P2L_PRO_NONE) P2L_PW(P2L_PRO_NONE);
   else if (pro == P2L_PRO_AFFINE_RELU) P2L_PW(P2L_PRO_AFFINE_RELU);
   else P2L_PW(P2L_PRO_AFFINE);

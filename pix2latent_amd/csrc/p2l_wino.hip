@@ -347,9 +347,6 @@ constexpr TxTable kTx{};
 // H2: the fp16 x 2 arithmetic (include/p2l.h, P2L_WFMT_BF16X3W): the staged patch is scaled by the
 // image's power of two, a fragment is split into two fp16 pieces (cvt_pk | 2 v_fma_mix | cvt_pk per
 // pair: 4 instructions instead of 11) and multiplied by three MFMAs per N-tile instead of six.
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 // Transform micro-operations of the H2 form: MFMA gap G = 6 * step + gap; every gap behind the
 // patch barrier (gap 3 of step 0) carries one of the 20.
 struct TxTableH {
@@ -363,15 +360,6 @@ struct TxTableH {
   }
 };
 constexpr TxTableH kTxH{};
-// power-of-two scale that puts max |x| (bits `mx`, grown 4x by the input transform) below 2^15,
-// and its inverse
-__device__ __forceinline__ void h2_scales(unsigned mx, float& scale, float& inv) {
-  int E = (int)((mx >> 23) & 0xffu);
-  E = E < 40 ? 40 : (E > 254 ? 254 : E);
-  scale = __builtin_bit_cast(float, (unsigned)(266 - E) << 23);      // 2^(139 - E)
-  inv = __builtin_bit_cast(float, (unsigned)(E - 12) << 23);         // 2^(E - 139)
-}
-
 template <int PRO, int ABL = 0, bool H2 = false>
 __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

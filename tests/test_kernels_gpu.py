@@ -412,6 +412,21 @@ def test_winograd_f16x2_maxima_handed_over(dev, O):
     q0, _ = O.conv(yp, wp2, B, H // 2, H // 2, C2, C1, 9, wfmt=2)
     q1, _ = O.conv(yp, wp2, B, H // 2, H // 2, C2, C1, 9, wfmt=2, amax_in=amp)
     assert torch.equal(q0, q1)
+    # a pointwise (1x1) consumer takes the fp16 x 2 form when -- and only when -- the maxima come with
+    # the tensor; without them it stays bf16 x 3; both fp32-grade
+    w21 = torch.randn(C1, C2, 1, 1, generator=g) / math.sqrt(C2)
+    wp21 = O.pack_conv_weight(w21.to(dev), 1, C1, C2, wfmt=3)
+    for kwp in (dict(), dict(pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=C2)):
+        u0, _ = O.conv(y, wp21, B, H, H, C2, C1, 1, wfmt=3, **kwp)
+        u1, _ = O.conv(y, wp21, B, H, H, C2, C1, 1, wfmt=3, amax_in=am, **kwp)
+        yin = F.relu(F.conv2d(x, w1, b1, padding=1))
+        if kwp:
+            yin = F.relu(yin * s.view(B, C2, 1, 1) + t.view(B, C2, 1, 1))
+        refu = F.conv2d(yin, w21)
+        for bb in range(B):
+            sc = refu[bb].abs().max().item()
+            assert (nchw(u1)[bb] - refu[bb]).abs().max().item() < 2e-5 * sc
+            assert (nchw(u0)[bb] - nchw(u1)[bb]).abs().max().item() < 1e-5 * sc
     # other producers: the kernels that end in the vector epilogue -- 1x1 (bf16x3 pointwise and exact
     # fp32), direct 3x3, sub-pixel (upsample-fused) 3x3 with its four output phases
     w11 = torch.randn(C2, C1, 1, 1, generator=g) / math.sqrt(C1)
