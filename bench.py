@@ -495,8 +495,8 @@ def main():
             'vs_baseline': None,
             'dtype': ('f32 (fp32 tensors everywhere; convolutions >= 32x32 and the self-attention multiply on '
                       'the 16-bit MFMA pipe with fp32-grade operand splits and fp32 accumulate: the 16x16 '
-                      'Winograd 3x3 kernel on power-of-two scaled operands in 2 fp16 pieces, 3 products; the '
-                      'other kernels on 3 bf16 pieces, 6 products; small layers, dense layers, reductions '
+                      'Winograd 3x3 kernel and the 1x1 kernel on power-of-two scaled operands in 2 fp16 pieces, '
+                      '3 products; the other kernels on 3 bf16 pieces, 6 products; small layers, dense layers, reductions '
                       'and elementwise work exact fp32)'
                       if bf3 else 'f32'),
             'data': 'synthetic',
@@ -508,7 +508,7 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
-                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel) + bf16x3 (every other >= 32x32 kernel)' if bf3 else 'f32',
+                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel; 1x1 kernel where the maxima are handed over) + bf16x3 (every other >= 32x32 kernel)' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
@@ -524,8 +524,9 @@ def main():
             'roofline': {
                 'kernel': ('every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
                            '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
-                           'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product) + wino_amax_kernel (its '
-                           'max-|x| pass), conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel) and '
+                           'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product; per-image maxima handed '
+                           'over by the launch that wrote the input, wino_amax_kernel where none did), '
+                           'conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel) and '
                            'conv_thinin/thinout_kernel (3-channel image convs) in the bf16 x 3 arithmetic (6 x '
                            'v_mfma_f32_32x32x16_bf16 per product on 3-way split fp32 operands)'
                            if bf3 else
@@ -572,6 +573,7 @@ def main():
                 # the 1x1 family is output-dominated: its roof is memory, and the WRITE rate of the
                 # part (4.4-4.9 TB/s, tools/micro/mem_rate.hip) rather than the 8 TB/s headline
                 'conv1x1': {'achieved': round(conv1_tflops, 2), 'unit': 'TFLOP/s',
+                            'mfma_products_per_fp32_product': round(mflops[1] / xflops[1], 2) if xflops[1] > 0 else None,
                             'sampled_launches': int(cnt[1]),
                             'launches_per_step': round(cnt[1] * period / args.steps, 1),
                             'time_share_of_step': round(period * ms[1] * 1e-3 / elapsed, 4),
