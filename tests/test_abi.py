@@ -44,6 +44,41 @@ def test_version_and_errors(lib):
     assert lib.p2l_l1_loss_nblk(256, 256) == 256
 
 
+def test_struct_layouts_match_the_compiled_header(tmp_path):
+    """sizes and member offsets of the ctypes mirrors against include/p2l.h compiled by gcc (the
+    structs that carry pointers next to 32-bit members: padding is where mirrors go wrong)"""
+    import shutil
+    import subprocess
+    from pix2latent_amd import _native as N
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    members = {
+        'P2LAmax': ['out', 'outp', 'in', 'in_n'],
+        'P2LConvExtra': ['oscale', 'oscale_bstride', 'noise', 'noise_w', 'amax'],
+        'P2LArb': ['x', 'x_ld', 's', 't', 'st_bstride', 'skip', 'skip_ld', 'skip_C', 'skip_ups', 'ds', 'dt',
+                   'dsdt_bstride', 'partial', 'nomask', 'amax'],
+        'P2LConv': ['wfmt', 'form', 'algo_flops'],
+    }
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "p2l.h"', 'int main(void) {']
+    for st, ms in members.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for m in ms:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, m, st, m))
+    src += ['return 0; }']
+    c = tmp_path / 'layout.c'
+    c.write_text('\n'.join(src))
+    exe = tmp_path / 'layout'
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    subprocess.check_call(['gcc', '-I', inc, str(c), '-o', str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for st, ms in members.items():
+        ct = getattr(N, st)
+        assert int(got[st]) == C.sizeof(ct), st
+        for m in ms:
+            f = getattr(ct, 'in_' if m == 'in' else m)
+            assert int(got['%s.%s' % (st, m)]) == f.offset, (st, m)
+
+
 def test_struct_layouts_match_c(lib):
     """sizes implied by include/p2l.h on LP64"""
     from pix2latent_amd import _native as N
