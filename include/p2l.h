@@ -259,9 +259,12 @@ int p2l_pack_conv_weight_subpix(const float* w_oihw, int O, int I, int N_pad,
  *   their 1x1 weight buffers are P2L_WFMT_PW buffers. */
 enum { P2L_WFMT_F32 = 0, P2L_WFMT_BF16X3 = 1, P2L_WFMT_BF16X3W = 2, P2L_WFMT_PW = 3,
        P2L_WFMT_BF16X3T = 4, P2L_WFMT_FLAG_PW = 0x10, P2L_WFMT_FLAG_THIN = 0x20,
-       P2L_WFMT_FLAG_ATTN_GEMM = 0x40 /* model descriptors: self-attention as GEMM + softmax   */
+       P2L_WFMT_FLAG_ATTN_GEMM = 0x40,/* model descriptors: self-attention as GEMM + softmax   */
                                       /* (the attention matrix is stored) instead of the fused  */
-                                      /* kernels of csrc/p2l_attn.hip                          */ };
+                                      /* kernels of csrc/p2l_attn.hip                          */
+       P2L_WFMT_FLAG_NO_AMAX = 0x80   /* model descriptors: no maxima handed between the convs  */
+                                      /* of the plan (P2LAmax): every fp16 x 2 Winograd launch  */
+                                      /* runs its own max-|x| pass, the 1x1 convs stay bf16 x 3 */ };
 /* P2L_WFMT_BF16X3T (3x3 convs with THREE real channels on one side, padded to N_pad == 32 or
  * K_pad == 16: conv_to_rgb, the first VGG conv and their input gradients): the BF16X3 image
  * followed by the image of p2l_thin.hip's kernels (27 tap-channel products as one K dimension

@@ -127,7 +127,7 @@ class P2LLossCache(C.Structure):
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
 WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW, WFMT_BF16X3T = 0, 1, 2, 3, 4
-WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM = 0x10, 0x20, 0x40
+WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM, WFMT_FLAG_NO_AMAX = 0x10, 0x20, 0x40, 0x80
 # P2LConv.form (per launch; the library has no switches of its own)
 FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN, FORM_WINO_BF3 = 0, 1, 2, 4, 8, 16, 32
 
@@ -157,6 +157,12 @@ def default_attn_gemm():
     """P2L_ATTN=0: self-attention of the generator as GEMM + softmax (the attention matrix is
     stored) instead of the fused kernels -- a MODEL descriptor flag, read here once"""
     return os.environ.get('P2L_ATTN', '1') == '0'
+
+
+def default_no_amax():
+    """P2L_AMAX=0: no maxima handed between the convs of a plan (P2LAmax) -- a MODEL descriptor
+    flag, read when a model is constructed"""
+    return os.environ.get('P2L_AMAX', '1') == '0'
 
 
 def default_pw():

@@ -122,6 +122,7 @@ struct AmaxScope {                                     // one per plan entry poi
 #ifdef P2L_NO_AMAX_HANDOVER                            // (A/B build: tools/ab_build.sh p2l_plan -DP2L_NO_AMAX_HANDOVER)
     set_floats = 0;
 #endif
+    if (g_plan_wfmt & P2L_WFMT_FLAG_NO_AMAX) set_floats = 0;   // (model descriptor flag)
     g_amax = set_floats ? &reg : nullptr;
   }
   ~AmaxScope() { g_amax = nullptr; }

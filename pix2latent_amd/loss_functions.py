@@ -103,7 +103,8 @@ class _VggLpipsParams(object):
         self.desc = N.P2LVggLpips()
         self.wfmt = N.default_wfmt()       # all 13 convs are 3x3
         thin = N.default_thin() and self.wfmt != N.WFMT_F32    # first conv: 3 real input channels
-        self.desc.wfmt = self.wfmt | (N.WFMT_FLAG_THIN if thin else 0)
+        self.desc.wfmt = (self.wfmt | (N.WFMT_FLAG_THIN if thin else 0) |
+                          (N.WFMT_FLAG_NO_AMAX if N.default_no_amax() else 0))
         inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
         for i, (cin, cout) in enumerate(synthetic.VGG_CONVS):
             w = weights['vgg.conv%d.weight' % i].float()
@@ -412,7 +413,7 @@ def _vgg_params(net, weights, device):
     if net not in ('vgg', 'alex'):
         raise NotImplementedError("lpips_net='%s': LPIPS networks with a native path are "
                                   "'alex' and 'vgg'" % net)
-    key = (net, id(weights), str(device), N.default_wfmt())
+    key = (net, id(weights), str(device), N.default_wfmt(), N.default_no_amax())
     if key not in _VGG_PARAMS:
         if weights is None:
             path = os.environ.get('P2L_LPIPS_%s_WEIGHTS' % net.upper())

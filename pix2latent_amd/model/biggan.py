@@ -125,7 +125,8 @@ class BigGAN(nn.Module):
         self._thin = N.default_thin() and self._wfmt != N.WFMT_F32
         self._desc.wfmt = (self._wfmt | (N.WFMT_FLAG_PW if self._pw else 0) |
                            (N.WFMT_FLAG_THIN if self._thin else 0) |
-                           (N.WFMT_FLAG_ATTN_GEMM if N.default_attn_gemm() else 0))
+                           (N.WFMT_FLAG_ATTN_GEMM if N.default_attn_gemm() else 0) |
+                           (N.WFMT_FLAG_NO_AMAX if N.default_no_amax() else 0))
         self._ws = None
         self._ws_B = -1
         self.ws_generation = 0

@@ -133,6 +133,36 @@ def test_full_step_gradients_and_ranking(setup, oracle_run, dev):
     grad_close(c.grad, oracle_run['dc'], oracle_run['f64']['dc'], 'dc')
 
 
+def test_maxima_handed_between_the_convs_change_nothing_but_rounding(setup, dev, monkeypatch):
+    """P2LAmax in the plans: with the per-image maxima handed from the conv that writes a tensor to
+    the conv that reads it (default) and with every launch reducing its own (P2L_AMAX=0: a model
+    descriptor flag; the 1x1 convs then also stay bf16 x 3) the pipeline gives the same image, loss
+    and latent gradients up to the rounding of fp32-grade products -- a stale or missing maximum
+    would show as inf / nan or as a gross error here."""
+    from pix2latent_amd.model.biggan import BigGAN
+    import pix2latent_amd.loss_functions as LF
+    s = setup
+
+    def run(model, loss_fn):
+        z = s['z'].to(dev).requires_grad_(True)
+        c = s['c'].to(dev).requires_grad_(True)
+        out = model(z=z, c=c)
+        loss = loss_fn(out, s['target'].to(dev), s['weight'].to(dev))
+        loss.mean().backward()
+        torch.cuda.synchronize()
+        return out.detach().cpu(), loss.detach().cpu(), z.grad.cpu(), c.grad.cpu()
+
+    a = run(s['model'], s['loss'])
+    monkeypatch.setenv('P2L_AMAX', '0')
+    b = run(BigGAN(weights=s['W']), LF.ProjectionLoss(lpips_net='vgg', weights=s['Wv']))
+    for t in a + b:
+        assert torch.isfinite(t).all()
+    assert (a[0] - b[0]).abs().max().item() < 1e-4          # pixels in [-1, 1]
+    assert (a[1] - b[1]).abs().max().item() < 1e-5
+    # (gradients: the two runs may sit on different sides of a ReLU / L1 sign here and there, §5)
+    assert _rel(a[2], b[2]) < 5e-3 and _rel(a[3], b[3]) < 5e-3
+
+
 def test_l1_only_config1(setup, oracle_run, dev):
     """BASELINE config 1: invert_biggan_adam, num_samples=1, L1 loss only."""
     import pix2latent_amd.loss_functions as LF
