@@ -287,7 +287,7 @@ enum {
   P2L_FORM_WINO_8X16 = 4,    /* the 8x16-pixel Winograd kernel even where 16x16 fits (tests)   */
   P2L_FORM_NO_PW = 8,        /* P2L_WFMT_PW weights, but the exact-fp32 1x1 kernel             */
   P2L_FORM_NO_THIN = 16,     /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
-  P2L_FORM_WINO_BF3 = 32     /* 16x16 Winograd kernel in the bf16 x 3 arithmetic, not fp16 x 2  */
+  P2L_FORM_WINO_BF3 = 32     /* bf16 x 3 arithmetic, not fp16 x 2: 16x16 Winograd and 1x1 kernels */
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

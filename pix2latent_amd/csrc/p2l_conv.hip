@@ -794,6 +794,19 @@ __global__ __launch_bounds__(256) void conv_splitk_finish4(const ConvK k) {
     *reinterpret_cast<f32x4*>(k.arb_partial + po) = S.sgx;
     *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + po) = S.sg;
   }
+  // one partial maximum per wave for the launch that reads the tensor next (P2LAmax; the launcher
+  // sets the pointers only when a wave's 64 items lie in one image: whole waves, no early exit)
+  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+    float m = S.amax, mp = S.amaxp;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+    if ((threadIdx.x & 63) == 0) {
+      const size_t per_image = (size_t)Hh * Wh * C4;
+      const size_t slot = (size_t)b * k.amax_out_n + (idx - (size_t)b * per_image) / 64;
+      if (k.amax_out != nullptr) k.amax_out[slot] = m;
+      if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
+    }
+  }
 }
 
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
@@ -1079,7 +1092,12 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   if (!d) return 0;
   if (wino_shape(d)) {
     if (d->H % 16 || d->W % 16 || (d->form & P2L_FORM_WINO_8X16)) return 0;
-    if (d->splitk > 1 && wino_split(d) == d->splitk) return 0;
+    if (d->splitk > 1 && wino_split(d) == d->splitk) {
+      // K-sliced launch: the float4 finish kernel writes the tensor, one partial per wave of 64
+      // (quad, 4 channels) items -- when a wave never straddles two images
+      const int per_image = (d->H / 2) * (d->W / 2) * (d->n_store / 4);
+      return (per_image % 64 == 0 && d->n_store % 4 == 0) ? per_image / 64 : 0;
+    }
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
   if (d->ups > 2 || effective_splitk(d) > 1) return 0;

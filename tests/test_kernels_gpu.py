@@ -487,9 +487,12 @@ def test_winograd_k_sliced_small_grid_layers(dev, O, shape):
     t = 0.3 * torch.randn(B, Cin, generator=g)
     ref = F.conv2d(F.relu(x * s.view(B, Cin, 1, 1) + t.view(B, Cin, 1, 1)), w, bias, padding=1)
     wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
-    y, _ = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, 9, wfmt=2, bias=bias.to(dev),
-                  pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin)
+    y, _, (am, _) = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, 9, wfmt=2, bias=bias.to(dev),
+                           pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin,
+                           want_amax=True)
     assert relerr(nchw(y), ref) < 2e-5
+    if slices > 1:      # (the finish kernel of a K-sliced launch leaves the maxima of what it wrote: P2LAmax)
+        assert am is not None and torch.equal(am.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
     y1, _ = O.conv(nhwc(x[1:2], dev), wp, 1, H, H, Cin, Cout, 9, wfmt=2, bias=bias.to(dev),
                    pro=N.PRO_AFFINE_RELU, pro_s=s[1:2].to(dev), pro_t=t[1:2].to(dev), pro_bstride=Cin)
     assert torch.equal(y1[0], y[1]), 'result depends on the batch composition'
