@@ -16,7 +16,7 @@ by = collections.OrderedDict()
 for r in rows:
     n = r['Kernel_Name']
     if 'conv_mfma' not in n and 'wino' not in n: continue
-    key = (int(r['Dispatch_Id']), ('wino16' if 'wino16s' in n else 'wino8' if 'wino_conv' in n else 'direct'), r['Grid_Size'])
+    key = (int(r['Dispatch_Id']), ('amax' if 'wino_amax' in n else 'wino16-f16x2' if ('wino16s' in n and 'true' in n) else 'wino16' if 'wino16s' in n else 'wino8' if 'wino_conv' in n else 'direct'), r['Grid_Size'])
     by.setdefault(key, {})[r['Counter_Name']] = float(r['Counter_Value'])
 print('disp kind grid  mfma_busy parked issue_stall issuing valu_share lds_busy lds_conf clk(GUI cycles)')
 for k, v in sorted(by.items()):
