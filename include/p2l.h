@@ -199,6 +199,9 @@ typedef struct P2LConvExtra {
 } P2LConvExtra;
 /* partial maxima per image a launch of d writes into P2LAmax.out / outp (0: it writes none) */
 int p2l_conv_amax_slots(const P2LConv* d);
+/* test hook, host logic only: the bookkeeping rules of the plans' per-run maxima registry
+ * (csrc/p2l_plan.hip AmaxReg); 0 = all hold */
+int p2l_selftest_amaxreg(void);
 int p2l_conv_fwd_ex(const P2LConv* d, const P2LConvExtra* ex, const float* x,
                     const float* w, const float* bias, const float* pro_s,
                     const float* pro_t, const float* res, const float* mask, float* y,

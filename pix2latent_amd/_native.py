@@ -209,7 +209,7 @@ PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 # every symbol include/p2l.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     'p2l_version', 'p2l_strerror', 'p2l_last_hip_error',
-    'p2l_conv_workspace_bytes', 'p2l_conv_amax_slots', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
+    'p2l_conv_workspace_bytes', 'p2l_conv_amax_slots', 'p2l_selftest_amaxreg', 'p2l_conv_suggest_splitk', 'p2l_conv_fwd', 'p2l_conv_fwd_ex',
     'p2l_pack_conv_weight', 'p2l_pack_conv_weight_subpix', 'p2l_pack_conv_weight_bf3',
     'p2l_pack_conv_weight_bf3w', 'p2l_packed_weight_floats', 
     'p2l_pack_conv_weight_bf3t',

@@ -135,6 +135,45 @@ int conv_amax_slots(ConvCall& c) {
   return p2l_conv_amax_slots(&c.d);
 }
 
+}  // namespace
+// test hook (host logic only, no GPU): the bookkeeping rules of AmaxReg; 0 = all hold, else the
+// number of the first rule that failed (tests/test_abi.py)
+extern "C" int p2l_selftest_amaxreg(void) {
+  static float ring[AmaxReg::NSETS * 8];
+  AmaxReg R;
+  R.ring = ring; R.set_floats = 8;
+  const float *slots = nullptr; int32_t n = 0;
+  float t1[1], t2[1], t3[1];
+  int set = -1;
+  float* s1 = R.take(&set);
+  R.put(t1, 2, 32, 32, 64, s1, 4, set);
+  if (!R.get(t1, 2, 32, 32, 64, &slots, &n) || slots != s1 || n != 4) return 1;   // found, same slots
+  if (R.get(t1, 2, 32, 32, 128, &slots, &n)) return 2;                            // other extents: a different tensor
+  if (R.get(t2, 2, 32, 32, 64, &slots, &n)) return 3;                             // other address
+  R.drop(t1);
+  if (R.get(t1, 2, 32, 32, 64, &slots, &n)) return 4;                             // dropped (someone else wrote it)
+  float* s2 = R.take(&set);
+  R.put(t2, 1, 16, 16, 64, s2, 2, set);
+  float* s3 = R.take(&set);
+  R.put(t2, 1, 16, 16, 64, s3, 2, set);                                           // re-written: one entry, new slots
+  if (!R.get(t2, 1, 16, 16, 64, &slots, &n) || slots != s3) return 5;
+  int live = 0;
+  for (const auto& e : R.e) live += e.t == t2;
+  if (live != 1) return 6;
+  for (int i = 0; i < AmaxReg::NSETS; ++i) (void)R.take(&set);                    // the ring comes round
+  if (R.get(t2, 1, 16, 16, 64, &slots, &n)) return 7;                             // its set was handed out again
+  for (int i = 0; i < AmaxReg::NENT + 3; ++i) {                                   // more tensors than entries
+    float* s = R.take(&set);
+    R.put(t3 + 0, i + 1, 16, 16, 64, s, 1, set);
+  }
+  if (!R.get(t3, AmaxReg::NENT + 3, 16, 16, 64, &slots, &n)) return 8;            // the latest is there
+  live = 0;
+  for (const auto& e : R.e) live += e.t != nullptr;
+  if (live > AmaxReg::NSETS) return 9;                                            // never more live entries than sets
+  return 0;
+}
+namespace {
+
 int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
   c.d.splitk = p2l_conv_suggest_splitk(&c.d);
   AmaxReg* R = g_amax;

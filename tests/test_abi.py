@@ -79,6 +79,13 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
             assert int(got['%s.%s' % (st, m)]) == f.offset, (st, m)
 
 
+def test_maxima_registry_rules(lib):
+    """P2LAmax in the plans: an entry is found only for the same address AND extents, dies when the
+    tensor is re-written or dropped or when its ring set is handed out again, and there are never
+    more live entries than slot sets (host logic of csrc/p2l_plan.hip, run through a test hook)"""
+    assert lib.p2l_selftest_amaxreg() == 0
+
+
 def test_struct_layouts_match_c(lib):
     """sizes implied by include/p2l.h on LP64"""
     from pix2latent_amd import _native as N
