@@ -18,6 +18,7 @@ from .search_loop import PopulationSampler, find_grad_free
 from ..utils.misc import cprint
 
 CMAEvolutionStrategy, CMA_BACKEND = backends.cma_strategy()
+CMA_EXTERNAL = not CMA_BACKEND.startswith('in-tree')
 
 
 class CMA(object):
@@ -67,6 +68,7 @@ class PycmaSampler(PopulationSampler):
         self.shape = tuple(np.shape(mu))
         self.es = CMA(np.asarray(mu, dtype=np.float64).reshape(-1), sigma=sigma, seed=seed)
         self.population = self.es.batch_size()
+        self._replica = False
 
     def _ask(self, n):
         assert n == self.population, 'PyCMA optimizer has fixed sample size'
@@ -75,6 +77,7 @@ class PycmaSampler(PopulationSampler):
 
     def draw(self, variables, shard=None):
         values = PopulationSampler.draw(self, variables, shard)
+        self._replica = bool(CMA_EXTERNAL and shard is not None and shard.enabled and shard.rank != 0)
         if shard is not None and shard.enabled:
             # every replica tells rank 0's population, so the replicas stay identical
             self._handle = values.reshape(len(values), -1)
@@ -88,6 +91,14 @@ class PycmaSampler(PopulationSampler):
         return values
 
     def _tell(self, asked, losses):
+        if self._replica:
+            # an INSTALLED pycma looks told solutions up in its archive of sent ones; a replica
+            # never sent rank 0's population, would take the geno / repair path and could drift
+            # away from rank 0.  Only rank 0's strategy is read (draw() broadcasts its ask), so
+            # the replicas of an external backend are simply not told.  The in-tree strategy
+            # (cma_es.py) is a pure function of what it is told and stays replicated: the gloo
+            # tests compare its traces on 1 / 2 / 3 ranks.
+            return
         self.es.tell(asked, losses)
 
 
@@ -111,7 +122,7 @@ class _BaseCMAOptimizer(object):
             self.cma_optimizers[(var_type, name)] = s
             self.num_samples = max(self.num_samples, s.population)
 
-        cprint('(cma-es) number of samples: {}'.format(self.num_samples), 'y')
+        cprint('(cma-es) number of samples: {}  [{}]'.format(self.num_samples, CMA_BACKEND), 'y')
 
         assert len(self.cma_optimizers.keys()) == 1, \
             'currently only a single input variable can be optimized via CMA ' + \

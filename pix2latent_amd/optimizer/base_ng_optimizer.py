@@ -37,7 +37,15 @@ class AskTellSampler(PopulationSampler):
         # every `.args` is the 1-tuple (array,): concatenation stacks them to [n, *shape]
         return np.concatenate([c.args for c in candidates]), candidates
 
+    def draw(self, variables, shard=None):
+        # (as PycmaSampler: with an INSTALLED nevergrad only rank 0's optimizer is authoritative --
+        #  an unseeded replica asks different candidates than the ones rank 0 broadcasts)
+        self._replica = bool(NG_EXTERNAL and shard is not None and shard.enabled and shard.rank != 0)
+        return PopulationSampler.draw(self, variables, shard)
+
     def _tell(self, candidates, losses):
+        if getattr(self, '_replica', False):
+            return
         for cand, value in zip(candidates, losses):
             self.opt.tell(cand, float(value))
 

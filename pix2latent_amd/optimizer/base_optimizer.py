@@ -85,6 +85,7 @@ class _BaseOptimizer(SearchLoopMixin):
     # `TRACK_RING` steps ago has not finished.  HBM cost: TRACK_RING x one step of the variable.
     TRACK_RING = 2
     TRACK_PIN_BYTES = 32 << 20      # larger steps go to pageable host memory (as the reference's do)
+    TRACK_PIN_TOTAL = 256 << 20     # ... and so does the history once this much of it is pinned
 
     @property
     def tracked(self):
@@ -108,6 +109,10 @@ class _BaseOptimizer(SearchLoopMixin):
         else:
             slot = {'dev': torch.empty_like(src), 'done': torch.cuda.Event()}
             if k < len(ring['slots']):
+                # the replaced snapshot may still be on its way to the host: its block must not
+                # return to the allocator of the compute stream before that copy has read it
+                ring['slots'][k]['dev'].record_stream(self._track_stream)
+                main.wait_event(ring['slots'][k]['done'])
                 ring['slots'][k] = slot
             else:
                 ring['slots'].append(slot)
@@ -115,7 +120,11 @@ class _BaseOptimizer(SearchLoopMixin):
         ready = torch.cuda.Event()
         ready.record(main)
         nbytes = src.numel() * src.element_size()
-        host = torch.empty(src.shape, dtype=src.dtype, pin_memory=nbytes <= self.TRACK_PIN_BYTES)
+        pinned = getattr(self, '_track_pinned', 0)
+        pin = nbytes <= self.TRACK_PIN_BYTES and pinned + nbytes <= self.TRACK_PIN_TOTAL
+        if pin:
+            self._track_pinned = pinned + nbytes
+        host = torch.empty(src.shape, dtype=src.dtype, pin_memory=pin)
         with torch.cuda.stream(self._track_stream):
             self._track_stream.wait_event(ready)
             host.copy_(slot['dev'], non_blocking=True)

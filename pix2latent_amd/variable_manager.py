@@ -232,12 +232,12 @@ class VariableManager():
             self.variable_info[variable_name][k] = v
         return True
 
-    @torch.no_grad()
     def release_pool(self):
         """forget the pooled device buffers (`reuse_buffers`): the tensors of the last
         `initialize()` then belong to their holder alone, the next call allocates anew"""
         self._pool = {}
 
+    @torch.no_grad()
     def initialize(self, num_samples):
         """
         Materialises `num_samples` samples of every registered variable and a

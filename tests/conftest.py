@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# golden traces and multi-rank trajectories are those of the in-tree samplers: a machine that has
+# pycma / nevergrad installed must not silently run the tests on other sampler numerics
+# (tests/test_backends.py exercises the external branch with recording fakes)
+os.environ.setdefault('P2L_SAMPLERS', 'intree')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -56,7 +56,9 @@ def test_installed_packages_are_preferred(fresh, monkeypatch):
     ng = fake_nevergrad()
     monkeypatch.setitem(sys.modules, 'cma', _fake_module('cma', CMAEvolutionStrategy=FakeCMAES))
     monkeypatch.setitem(sys.modules, 'nevergrad', _fake_module('nevergrad', optimizers=ng.optimizers, p=ng.p))
+    monkeypatch.delenv('P2L_SAMPLERS', raising=False)     # (tests/conftest.py pins the in-tree samplers)
     B, C, G = fresh()
+    assert C.CMA_EXTERNAL
     assert C.CMAEvolutionStrategy is FakeCMAES and C.CMA_BACKEND.startswith('pycma')
     assert G.NG_EXTERNAL and G.NG_BACKEND.startswith('nevergrad')
     # the facade drives the package exactly as the reference does: x0, sigma0, options
@@ -77,3 +79,30 @@ def test_environment_forces_the_in_tree_samplers(fresh, monkeypatch):
     B, C, G = fresh()
     from pix2latent_amd.optimizer import cma_es
     assert C.CMAEvolutionStrategy is cma_es.CMAEvolutionStrategy
+
+
+def test_replicas_of_an_external_backend_are_not_told(fresh, monkeypatch):
+    """sharded run with an INSTALLED pycma: rank 0's strategy is the only one that is read (its ask
+    is broadcast), a replica would tell solutions pycma never sent from there -- it is not told"""
+    monkeypatch.setitem(sys.modules, 'cma', _fake_module('cma', CMAEvolutionStrategy=FakeCMAES))
+    monkeypatch.delenv('P2L_SAMPLERS', raising=False)
+    B, C, G = fresh()
+
+    class Shard(object):
+        enabled = True
+        def __init__(self, rank): self.rank = rank
+        def broadcast_numpy(self, a, src=0): return a
+
+    import torch
+
+    for rank, told in ((0, True), (1, False)):
+        FakeCMAES.log = []
+        s = C.PycmaSampler('input', 'z', np.zeros(4), 1.0)
+        n = s.population
+        leaves = [torch.zeros(4) for _ in range(n)]
+        class V(dict):
+            num_samples = n
+        v = V(input={'z': types.SimpleNamespace(data=leaves)})
+        s.draw(v, Shard(rank))
+        s.report(np.arange(n, dtype=np.float64))
+        assert bool(FakeCMAES.log) == told
