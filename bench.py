@@ -471,7 +471,7 @@ def main():
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        for name in ('round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
+        for name in ('round4_traffic.json', 'round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
             tpath = os.path.join(prof_dir, name)
             if os.path.exists(tpath):
                 with open(tpath) as f:
@@ -532,33 +532,32 @@ def main():
                            if bf3 else
                            'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
                 'bound': 'mfma',
-                'achieved': round(conv_tflops, 2),
-                # 6 (bf16 x 3) or 3 (fp16 x 2) 16-bit MFMA products per fp32 product -> the matrix-pipe
-                # ceiling in algorithmic (fp32-equivalent) FLOP/s is the dense 16-bit peak / the
-                # products per fp32 product of the launch mix (weighted by executed FLOPs)
-                'peak': round(BF16_MFMA_PEAK_TFLOPS / prod_mix, 1) if bf3 else FP32_MFMA_PEAK_TFLOPS,
-                'peak_basis': {'dense_16bit_mfma_tflops': BF16_MFMA_PEAK_TFLOPS,
-                               'mfma_products_per_fp32_product': round(prod_mix, 3),
-                               'bf16x3_only_ceiling': round(BF16_MFMA_PEAK_TFLOPS / 6, 1)},
+                # achieved / peak / frac are what the matrix pipe EXECUTES --
+                # 16-bit MFMA FLOP/s issued by these launches (3 products per fp32 product for the
+                # fp16 x 2 launches, 6 for bf16 x 3; Winograd launches 16 instead of 36 products per
+                # output quad, sub-pixel launches 4 phase-taps, image convs their padded channels)
+                # over the dense 16-bit MFMA peak.  The algorithmic (fp32-equivalent, 9 taps on the
+                # output grid, 3 real image channels) rate of the same launches and its ratios are
+                # under `algorithmic`.
+                'achieved': round(mfma_tflops if bf3 else exec_tflops, 1),
+                'peak': BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
-                'frac': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix if bf3
-                                             else FP32_MFMA_PEAK_TFLOPS), 4),
-                'frac_of_bf16x3_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6), 4) if bf3 else None,
-                'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                # `achieved` is ALGORITHMIC: sub-pixel (upsample-fused) launches are priced at the
-                # 9 taps of upsample-then-convolve on the high-resolution grid and the 3-channel
-                # image convs at 3 channels.  What the matrix pipe EXECUTES for the same launches
-                # (4 phase-taps; channels padded to 16 / 32) is reported next to it:
-                'executed': {'fp32_equiv_tflops': round(exec_tflops, 2),
-                             'bf16_mfma_tflops_issued': round(mfma_tflops, 1) if bf3 else None,
-                             'frac_of_peak': round(exec_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix if bf3
-                                                                  else FP32_MFMA_PEAK_TFLOPS), 4)},
-                # the matrix-pipe utilisation proper: bf16 MFMA FLOP/s issued / dense bf16 peak.
-                # `frac` above is ALGORITHMIC FLOPs against peak/6: Winograd and sub-pixel launches
-                # issue 16/36 of the direct products, so its ceiling is up to 2.25, not 1
-                'frac_executed': round((mfma_tflops if bf3 else exec_tflops) /
-                                       (BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS), 4),
-                'algorithmic_ceiling_of_frac': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
+                'frac': round((mfma_tflops if bf3 else exec_tflops) /
+                              (BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS), 4),
+                'frac_is': 'executed 16-bit MFMA FLOP/s / dense 16-bit MFMA peak' if bf3
+                           else 'executed fp32 MFMA FLOP/s / fp32 MFMA peak',
+                'algorithmic': {
+                    'tflops': round(conv_tflops, 2),
+                    'gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),
+                    'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'mfma_products_per_fp32_product': round(prod_mix, 3),
+                    # algorithmic FLOP/s against (dense 16-bit peak / products per fp32 product of the
+                    # launch mix): a MIXED scale whose top is `ceiling_of_that_ratio`, not 1
+                    'vs_mix_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix), 4) if bf3 else None,
+                    'ceiling_of_that_ratio': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
+                    'vs_bf16x3_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6), 4) if bf3 else None,
+                    'executed_fp32_equiv_tflops': round(exec_tflops, 2),
+                },
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,
@@ -568,7 +567,6 @@ def main():
                 'launch_sampling': 'every %d-th conv launch timed (hipEvent pairs), phase rotating '
                                    'with the step' % period,
                 'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
-                'algo_gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),
                 'time_share_of_step': round(period * ms[0] * 1e-3 / elapsed, 4),
                 # the 1x1 family is output-dominated: its roof is memory, and the WRITE rate of the
                 # part (4.4-4.9 TB/s, tools/micro/mem_rate.hip) rather than the 8 TB/s headline

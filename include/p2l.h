@@ -688,6 +688,15 @@ int p2l_alexloss_bwd(const P2LAlexLpips* v, const float* img16, const float* tar
  * invert_transform). */
 int p2l_affine_grid_sample(const float* src, const float* theta, float* dst, int Bn,
                            int C, int H, int W, void* stream);
+/* Its backward, for the differentiable uses of SpatialTransform (reference
+ * pix2latent/loss_functions.py:30-38 invertibility_loss; autograd through
+ * spatial_transform.py:69-104): d src (gather form of the adjoint, may be NULL) and d theta [B][6]
+ * (may be NULL; needs src and p2l_affine_grid_sample_bwd_ws_bytes of workspace).  Fixed summation
+ * order, no atomics. */
+size_t p2l_affine_grid_sample_bwd_ws_bytes(int Bn, int H, int W);
+int p2l_affine_grid_sample_bwd(const float* src, const float* theta, const float* dout,
+                               float* dsrc, float* dtheta, int Bn, int C, int H, int W,
+                               void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* StyleGAN2 (rosinality) pieces; replace fused_bias_act / upfirdn2d and the   */

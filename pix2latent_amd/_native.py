@@ -223,7 +223,7 @@ EXPORTS = [
     'p2l_weight_sum', 'p2l_weight_map', 'p2l_l1_loss_nblk', 'p2l_l1_loss_fwd',
     'p2l_l1_loss_bwd', 'p2l_lpips_normalize', 'p2l_lpips_tap_nblk', 'p2l_lpips_tap_fwd',
     'p2l_lpips_tap_bwd', 'p2l_bilinear_adjoint', 'p2l_reduce_rows', 'p2l_adam_step',
-    'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
+    'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_affine_grid_sample_bwd', 'p2l_affine_grid_sample_bwd_ws_bytes', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_ws_lookup', 'p2l_projloss_prepare',
     'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_end4', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
@@ -263,7 +263,7 @@ def lib():
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
                      'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes',
-                     'p2l_packed_weight_floats', 'p2l_attn_fwd_ws_bytes',
+                     'p2l_packed_weight_floats', 'p2l_attn_fwd_ws_bytes', 'p2l_affine_grid_sample_bwd_ws_bytes',
                      'p2l_attn_bwd_dv_ws_bytes', 'p2l_attn_bwd_qk_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib

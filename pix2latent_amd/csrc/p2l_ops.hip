@@ -732,6 +732,117 @@ __global__ void affine_grid_sample_kernel(const float* src, const float* theta, 
   }
 }
 
+// ---- backward of the fused warp (differentiable uses of SpatialTransform on the device:
+// invertibility_loss, gradient-based search of t).  Both in fixed summation order.
+// d src: GATHER form of the adjoint.  Source pixel (sx, sy) receives from every output pixel whose
+// sampling position (ix, iy) lies in (sx-1, sx+1) x (sy-1, sy+1); that set is the pre-image of a
+// 2x2 box under the affine map, a parallelogram whose bounding box follows from the inverse of
+// theta's 2x2 part (the whole image when the map is singular).  Visited row-major: no atomics.
+__global__ void affine_grid_sample_bwd_src_kernel(const float* dout, const float* theta, float* dsrc,
+                                                  int Bn, int C, int H, int W) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Bn * H * W) return;
+  const int sx = (int)(idx % W);
+  const int sy = (int)((idx / W) % H);
+  const int b = (int)(idx / ((size_t)W * H));
+  const float* th = theta + b * 6;
+  // ix = ax*x + bx*y + cx, iy = ay*x + by*y + cy in PIXEL coordinates of the output grid
+  const float ax = th[0], bx = th[1] * (float)W / (float)H, ay = th[3] * (float)H / (float)W, by = th[4];
+  const float cx = 0.5f * ((th[0] * (1.f / W - 1.f) + th[1] * (1.f / H - 1.f) + th[2] + 1.f) * W - 1.f);
+  const float cy = 0.5f * ((th[3] * (1.f / W - 1.f) + th[4] * (1.f / H - 1.f) + th[5] + 1.f) * H - 1.f);
+  int x_lo = 0, x_hi = W - 1, y_lo = 0, y_hi = H - 1;
+  const float det = ax * by - bx * ay;
+  if (fabsf(det) > 1e-12f) {
+    // corners of the box (sx +- 1, sy +- 1) mapped back to the output grid
+    float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float u = (float)sx + ((k & 1) ? 1.f : -1.f) - cx, v = (float)sy + ((k & 2) ? 1.f : -1.f) - cy;
+      const float ox = (by * u - bx * v) / det, oy = (-ay * u + ax * v) / det;
+      mnx = fminf(mnx, ox); mxx = fmaxf(mxx, ox); mny = fminf(mny, oy); mxy = fmaxf(mxy, oy);
+    }
+    // (one pixel of slack against rounding of the inverse; every candidate is re-tested below)
+    x_lo = max(0, (int)floorf(fmaxf(mnx, -1.f)) - 1); x_hi = min(W - 1, (int)ceilf(fminf(mxx, (float)W)) + 1);
+    y_lo = max(0, (int)floorf(fmaxf(mny, -1.f)) - 1); y_hi = min(H - 1, (int)ceilf(fminf(mxy, (float)H)) + 1);
+  }
+  for (int c = 0; c < C; ++c) {
+    const float* g = dout + ((size_t)b * C + c) * H * W;
+    float acc = 0.f;
+    for (int y = y_lo; y <= y_hi; ++y)
+      for (int x = x_lo; x <= x_hi; ++x) {
+        // EXACTLY the forward kernel's arithmetic for this output pixel
+        const float gx0 = (2.f * x + 1.f) / W - 1.f, gy0 = (2.f * y + 1.f) / H - 1.f;
+        const float gx = th[0] * gx0 + th[1] * gy0 + th[2];
+        const float gy = th[3] * gx0 + th[4] * gy0 + th[5];
+        const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float wx1 = ix - fx, wy1 = iy - fy;
+        float wx = 0.f, wy = 0.f;
+        if (x0 == sx) wx = 1.f - wx1; else if (x0 + 1 == sx) wx = wx1; else continue;
+        if (y0 == sy) wy = 1.f - wy1; else if (y0 + 1 == sy) wy = wy1; else continue;
+        acc += g[(size_t)y * W + x] * (wy * wx);
+      }
+    dsrc[((size_t)b * C + c) * H * W + (size_t)sy * W + sx] = acc;
+  }
+}
+// d theta: per output pixel d L / d (ix, iy) summed over channels, chained through the affine grid;
+// block partials [B][nblk][6] in fixed shuffle order, then one thread per (image, entry) adds the
+// blocks in order.
+__global__ __launch_bounds__(256) void affine_grid_sample_bwd_theta_kernel(
+    const float* src, const float* theta, const float* dout, float* partial, int C, int H, int W) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  float v6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p < H * W) {
+    const int x = p % W, y = p / W;
+    const float* th = theta + b * 6;
+    const float gx0 = (2.f * x + 1.f) / W - 1.f, gy0 = (2.f * y + 1.f) / H - 1.f;
+    const float gx = th[0] * gx0 + th[1] * gy0 + th[2];
+    const float gy = th[3] * gx0 + th[4] * gy0 + th[5];
+    const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    float gix = 0.f, giy = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* s = src + ((size_t)b * C + c) * H * W;
+      const float s00 = (vy0 && vx0) ? s[(size_t)y0 * W + x0] : 0.f;
+      const float s01 = (vy0 && vx1) ? s[(size_t)y0 * W + x1] : 0.f;
+      const float s10 = (vy1 && vx0) ? s[(size_t)y1 * W + x0] : 0.f;
+      const float s11 = (vy1 && vx1) ? s[(size_t)y1 * W + x1] : 0.f;
+      const float g = dout[((size_t)b * C + c) * H * W + p];
+      gix += g * ((s01 - s00) * wy0 + (s11 - s10) * wy1);
+      giy += g * ((s10 - s00) * wx0 + (s11 - s01) * wx1);
+    }
+    const float dgx = gix * (0.5f * W), dgy = giy * (0.5f * H);
+    v6[0] = dgx * gx0; v6[1] = dgx * gy0; v6[2] = dgx;
+    v6[3] = dgy * gx0; v6[4] = dgy * gy0; v6[5] = dgy;
+  }
+  __shared__ float red[4][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float a = v6[k];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 6 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void affine_grid_sample_bwd_theta_finish(const float* partial, float* dtheta, int Bn, int nblk) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= Bn * 6) return;
+  const int b = i / 6, k = i - b * 6;
+  float a = 0.f;
+  for (int j = 0; j < nblk; ++j) a += partial[((size_t)b * nblk + j) * 6 + k];
+  dtheta[i] = a;
+}
+
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n,
                             float step_size, float beta1, float beta2, float eps,
                             float bc2_sqrt) {
@@ -1120,6 +1231,28 @@ extern "C" int p2l_affine_grid_sample(const float* src, const float* theta, floa
   if (!src || !theta || !dst || Bn < 1) return P2L_EINVAL;
   hipLaunchKernelGGL(affine_grid_sample_kernel, dim3(cdiv((size_t)Bn * H * W, 256)), dim3(256),
                      0, ST(stream), src, theta, dst, Bn, C, H, W);
+  return p2l_check_launch();
+}
+
+extern "C" size_t p2l_affine_grid_sample_bwd_ws_bytes(int Bn, int H, int W) {
+  return (size_t)Bn * cdiv(H * W, 256) * 6 * sizeof(float);
+}
+extern "C" int p2l_affine_grid_sample_bwd(const float* src, const float* theta, const float* dout,
+                                          float* dsrc, float* dtheta, int Bn, int C, int H, int W,
+                                          void* workspace, size_t ws_bytes, void* stream) {
+  if (!theta || !dout || Bn < 1 || (!dsrc && !dtheta)) return P2L_EINVAL;
+  if (dsrc)
+    hipLaunchKernelGGL(affine_grid_sample_bwd_src_kernel, dim3(cdiv((size_t)Bn * H * W, 256)), dim3(256),
+                       0, ST(stream), dout, theta, dsrc, Bn, C, H, W);
+  if (dtheta) {
+    if (!src) return P2L_EINVAL;
+    const int nblk = cdiv(H * W, 256);
+    if (!workspace || ws_bytes < p2l_affine_grid_sample_bwd_ws_bytes(Bn, H, W)) return P2L_EWS;
+    hipLaunchKernelGGL(affine_grid_sample_bwd_theta_kernel, dim3(nblk, Bn), dim3(256), 0, ST(stream),
+                       src, theta, dout, (float*)workspace, C, H, W);
+    hipLaunchKernelGGL(affine_grid_sample_bwd_theta_finish, dim3(cdiv(Bn * 6, 64)), dim3(64), 0,
+                       ST(stream), (const float*)workspace, dtheta, Bn, nblk);
+  }
   return p2l_check_launch();
 }
 

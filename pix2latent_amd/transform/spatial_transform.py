@@ -2,7 +2,8 @@
 warp of generated images (reference pix2latent/transform/spatial_transform.py:10-108).
 
 On the ROCm device the warp is one fused affine-grid + bilinear grid-sample HIP kernel
-(`p2l_affine_grid_sample`); CPU tensors (host-side preprocessing, golden tests) use the
+(`p2l_affine_grid_sample`) with a native backward to the images and to theta
+(`p2l_affine_grid_sample_bwd`); CPU tensors (host-side preprocessing, golden tests) use the
 same two torch ops the reference calls.
 """
 import numpy as np
@@ -13,14 +14,13 @@ from .transform_utils import compute_pre_alignment
 from .base_transform import TransformTemplate
 
 
-def _warp(ims, theta):
-    """ims [B,C,H,W], theta [B,2,3] -> F.grid_sample(ims, F.affine_grid(theta, ims.size()))"""
-    theta = theta.type_as(ims)
-    assert theta.size(0) == ims.size(0), \
-        'one transformation per image expected but got {} for {} images'.format(
-            theta.size(0), ims.size(0))
-    needs_grad = torch.is_grad_enabled() and (ims.requires_grad or theta.requires_grad)
-    if ims.is_cuda and not needs_grad:
+class _WarpFn(torch.autograd.Function):
+    """F.grid_sample(ims, F.affine_grid(theta, ims.size())) on the device with its backward:
+    `p2l_affine_grid_sample` / `p2l_affine_grid_sample_bwd` (d ims in gather form, d theta by a
+    fixed-order reduction: no atomics, unlike ATen's grid_sampler backward)."""
+
+    @staticmethod
+    def forward(ctx, ims, theta):
         from .. import _native as N
         src = ims.contiguous().float()
         th = theta.contiguous().float().view(-1, 6)
@@ -28,9 +28,40 @@ def _warp(ims, theta):
         B, C, H, W = src.shape
         N.check(N.lib().p2l_affine_grid_sample(N.ptr(src), N.ptr(th), N.ptr(dst), B, C, H, W,
                                                N.stream()), 'p2l_affine_grid_sample')
+        ctx.save_for_backward(src, th)
+        ctx.theta_shape = theta.shape
         return dst
-    # CPU tensors, and differentiable uses on the device (invertibility_loss, gradient-based
-    # search of t): the two torch ops the reference calls, so autograd sees ims AND theta
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import _native as N
+        src, th = ctx.saved_tensors
+        B, C, H, W = src.shape
+        dout = dout.contiguous().float()
+        want_src, want_th = ctx.needs_input_grad
+        dsrc = torch.empty_like(src) if want_src else None
+        dth = torch.empty_like(th) if want_th else None
+        L = N.lib()
+        nbytes = L.p2l_affine_grid_sample_bwd_ws_bytes(B, H, W) if want_th else 0
+        ws = torch.empty(max(nbytes // 4, 1), device=src.device, dtype=torch.float32)
+        import ctypes as C_
+        N.check(L.p2l_affine_grid_sample_bwd(N.ptr(src), N.ptr(th), N.ptr(dout), N.ptr(dsrc), N.ptr(dth),
+                                             B, C, H, W, N.ptr(ws), C_.c_size_t(nbytes), N.stream()),
+                'p2l_affine_grid_sample_bwd')
+        return dsrc, (dth.view(ctx.theta_shape) if want_th else None)
+
+
+def _warp(ims, theta):
+    """ims [B,C,H,W], theta [B,2,3] -> F.grid_sample(ims, F.affine_grid(theta, ims.size()))"""
+    theta = theta.type_as(ims)
+    assert theta.size(0) == ims.size(0), \
+        'one transformation per image expected but got {} for {} images'.format(
+            theta.size(0), ims.size(0))
+    if ims.is_cuda:
+        # the native kernel, differentiable in ims and theta (invertibility_loss, gradient-based
+        # search of t): no ATen fallback on the device
+        return _WarpFn.apply(ims, theta)
+    # CPU tensors (host-side preprocessing, golden tests): the two torch ops the reference calls
     return F.grid_sample(ims, F.affine_grid(theta, list(ims.size()), align_corners=False),
                          align_corners=False)
 

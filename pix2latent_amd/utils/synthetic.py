@@ -90,6 +90,68 @@ def biggan_weights(seed=0, ch=CH, layers=LAYERS, attn_pos=ATTN_POS, z_dim=Z_DIM,
     return W
 
 
+def heavy_tailed(W, seed=7, frac=0.02, alpha=64.0, spike=1024.0):
+    """A heavy-tailed variant of a BigGAN-deep state dict (returns a new dict).
+
+    `biggan_weights` draws every tensor from a well-conditioned Gaussian: activations are near
+    Gaussian, max / typical ~ 5.  Trained generators are not like that: BN statistics span orders
+    of magnitude and a few channels carry activations 10^2 - 10^3 x the median.  The block-
+    floating-point arithmetic of the fp16 x 2 kernels (per-image power-of-two scales, maxima
+    handed over as BOUNDS) has to be shown on such data.  The network is
+    re-parametrised so that it computes (nearly) the same function -- the activations stay sane
+    through 50 layers -- while the tensors the kernels see become heavy-tailed; for every
+    conv_k -> bn_{k+1} -> ReLU -> conv_{k+1} chain inside a GenBlock (k = 0, 1, 2):
+
+      * RAW outliers: `frac` of conv_k's output channels x alpha (weight rows, bias), undone by
+        bn_{k+1}'s statistics (means x alpha, variances x alpha^2): the stored tensor has outlier
+        channels, the fused prologue's scales span alpha;
+      * small-variance channels: another `frac` / alpha (variances down to ~1e-3 x the usual);
+      * ACTIVATION outliers: another `frac` of bn_{k+1}'s channels get variance / alpha^2 and
+        offset x alpha -- the post-ReLU activation is alpha x larger -- undone by conv_{k+1}'s
+        input-channel weights / alpha; ONE channel per layer gets `spike` instead of alpha
+        ("a few 10^3 outlier activations per image").
+    """
+    g = torch.Generator().manual_seed(seed)
+    W = {k: v.clone() for k, v in W.items()}
+    blocks = sorted({k.rsplit('.bn_0.', 1)[0] for k in W if '.bn_0.running_means' in k})
+    for p in blocks:
+        for k in (0, 1, 2):
+            cw, cb = p + '.conv_%d.weight' % k, p + '.conv_%d.bias' % k
+            bn = p + '.bn_%d' % (k + 1)
+            nw = p + '.conv_%d.weight' % (k + 1)
+            C = W[cw].shape[0]
+            n = max(1, int(round(frac * C)))
+            perm = torch.randperm(C, generator=g)
+            raw_hi, raw_lo, act = perm[:n], perm[n:2 * n], perm[2 * n:3 * n]
+            for idx, a in ((raw_hi, alpha), (raw_lo, 1.0 / alpha)):
+                W[cw][idx] *= a
+                W[cb][idx] *= a
+                W[bn + '.running_means'][:, idx] *= a
+                W[bn + '.running_vars'][:, idx] *= a * a
+            a_act = torch.full((len(act),), alpha)
+            a_act[0] = spike
+            W[bn + '.running_vars'][:, act] /= (a_act * a_act)
+            W[bn + '.offset.weight'][act] *= a_act[:, None]
+            W[nw][:, act] /= a_act[None, :, None, None]
+    return W
+
+
+def heavy_tailed_vgg(Wv, seed=8, frac=0.02, alpha=32.0):
+    """heavy-tailed variant of the LPIPS-VGG16 weights: `frac` of every conv's output channels
+    x alpha (trained VGG features have such dominant channels), undone by the next conv's
+    input-channel weights where there is one (the LPIPS taps see the outlier channels)."""
+    g = torch.Generator().manual_seed(seed)
+    Wv = {k: v.clone() for k, v in Wv.items()}
+    for i in range(len(VGG_CONVS)):
+        C = Wv['vgg.conv%d.weight' % i].shape[0]
+        idx = torch.randperm(C, generator=g)[:max(1, int(round(frac * C)))]
+        Wv['vgg.conv%d.weight' % i][idx] *= alpha
+        Wv['vgg.conv%d.bias' % i][idx] *= alpha
+        if i + 1 < len(VGG_CONVS):
+            Wv['vgg.conv%d.weight' % (i + 1)][:, idx] /= alpha
+    return Wv
+
+
 def lpips_vgg_weights(seed=1):
     g = torch.Generator().manual_seed(seed)
     Wv = {}

@@ -34,7 +34,8 @@ def test_bench_single_gpu_line():
     assert rec['unit'] == 'evals/s' and rec['higher_is_better'] is True
     roof = rec['roofline']
     assert roof['bound'] == 'mfma' and 0 < roof['frac'] < 1 and roof['sampled_launches'] > 0
-    assert 0 < roof['frac_executed'] < 1 and roof['launches_per_step'] > 0
+    assert roof['launches_per_step'] > 0 and roof['algorithmic']['tflops'] > roof['algorithmic']['executed_fp32_equiv_tflops'] > 0
+    assert 'executed' in roof['frac_is']          # frac = what the matrix pipe executes / its dense peak
     assert roof['conv1x1']['bound'] == 'hbm' and 'telemetry' in rec
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     assert len(rec['config']['last_losses']) == 18

@@ -89,3 +89,20 @@ def test_make_gif_and_video_soft_dependencies(tmp_path):
     if importlib.util.find_spec('skvideo') is None:
         with pytest.raises(ImportError, match='skvideo'):
             video.make_video(str(tmp_path / 'h.mp4'), frames)
+
+
+@pytest.mark.parametrize('case', ['wide', 'tall', 'odd', 'upscale', 'square'])
+def test_read_matches_the_fixture(tmp_path, case):
+    """tests/golden/image_read.npz (tools/make_image_golden.py): the reference's torchvision
+    composition (pix2latent/utils/image.py:15-64) restated with PIL + numpy -- short-side bilinear
+    Resize -> CenterCrop -> [-1, 1], and the 'stylegan' pad-to-square -> Resize variant"""
+    import os
+    from pix2latent_amd.utils import image
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'image_read.npz'))
+    p = str(tmp_path / (case + '.png'))
+    Image.fromarray(G[case + '.input']).save(p)                  # (PNG: lossless)
+    size = int(G[case + '.size'])
+    for style, key in ((None, 'biggan'), ('biggan', 'biggan'), ('stylegan', 'stylegan'), ('stylegan2', 'stylegan')):
+        t = image.read(p, as_transformed_tensor=True, im_size=size, transform_style=style)
+        assert t.shape == (3, size, size)
+        assert np.array_equal(t.numpy(), G[case + '.' + key]), (case, style)

@@ -991,3 +991,69 @@ def test_thin_output_conv_and_dgrad(dev, O, B, H, Cin):
     di, _ = O.conv(nhwc(dy, dev), wt, B, H, H, Cin, 32, 9, wfmt=4, n_store=16, y_ld=16)
     torch.cuda.synchronize()
     assert relerr(nchw(di)[:, :3], img.grad) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 32, 32), (1, 2, 24, 40), (3, 1, 64, 48)])
+def test_affine_grid_sample_backward(dev, shape):
+    """p2l_affine_grid_sample_bwd: d src (gather-form adjoint) and d theta of the fused warp against
+    autograd through the two torch ops the reference calls (F.affine_grid + F.grid_sample,
+    /root/reference pix2latent/transform/spatial_transform.py:69-104) on the CPU in fp64 -- scale +
+    shift as SpatialTransform builds them, and general matrices (rotation / shear / out-of-range
+    shifts: zero padding on every side)."""
+    from pix2latent_amd.transform.spatial_transform import _warp, SpatialTransform
+    g = torch.Generator().manual_seed(17)
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W, generator=g)
+    probe = torch.randn(B, C, H, W, generator=g)
+    thetas = []
+    st = SpatialTransform()
+    t = torch.tensor([[1.3, 0.2, -0.1], [0.7, -0.4, 0.3], [1.0, 0.0, 0.0]])[:B]
+    thetas.append(st._theta(t[:, 0], t[:, 1:]))
+    thetas.append(torch.eye(2, 3).unsqueeze(0).repeat(B, 1, 1) + 0.35 * torch.randn(B, 2, 3, generator=g))
+    for theta in thetas:
+        xr = x.double().requires_grad_(True)
+        tr = theta.double().requires_grad_(True)
+        ref = F.grid_sample(xr, F.affine_grid(tr, [B, C, H, W], align_corners=False), align_corners=False)
+        (ref * probe.double()).sum().backward()
+        xd = x.to(dev).requires_grad_(True)
+        td = theta.to(dev).requires_grad_(True)
+        out = _warp(xd, td)
+        (out * probe.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        assert relerr(out.detach().cpu(), ref.detach()) < 1e-5
+        assert relerr(xd.grad.cpu(), xr.grad) < 1e-5
+        # d theta sums B*C*H*W products whose per-pixel sign changes at every cell border: compare
+        # against the fp64 value with an fp32-accumulation tolerance
+        assert relerr(td.grad.cpu(), tr.grad) < 2e-4, (td.grad.cpu(), tr.grad)
+        # only the image is differentiable / only theta
+        x2 = x.to(dev).requires_grad_(True)
+        _warp(x2, theta.to(dev)).mul(probe.to(dev)).sum().backward()
+        assert torch.equal(x2.grad, xd.grad)
+        t2 = theta.to(dev).requires_grad_(True)
+        _warp(x.to(dev), t2).mul(probe.to(dev)).sum().backward()
+        assert torch.equal(t2.grad, td.grad)
+
+
+def test_invertibility_loss_runs_native_on_the_device(dev):
+    """loss_functions.invertibility_loss (/root/reference pix2latent/loss_functions.py:30-38)
+    differentiates through transform + invert_transform: both warps and both backward passes are
+    the native kernels (no ATen grid_sampler in the graph)"""
+    import pix2latent_amd.loss_functions as LF
+    from pix2latent_amd.transform.spatial_transform import SpatialTransform, _WarpFn
+    g = torch.Generator().manual_seed(3)
+    ims = torch.randn(2, 3, 32, 32, generator=g)
+    t = torch.tensor([[1.2, 0.1, -0.2], [0.9, 0.0, 0.15]])
+    st = SpatialTransform()
+    ims_d = ims.to(dev).requires_grad_(True)
+    out = st.invert_transform(st.transform(ims_d, t.to(dev)), t.to(dev))
+    names = []
+    fn = out.grad_fn
+    while fn is not None and len(names) < 8:
+        names.append(type(fn).__name__)
+        fn = fn.next_functions[0][0] if fn.next_functions else None
+    assert names[0].startswith('_WarpFn') and not any('GridSampler' in n for n in names), names
+    out.sum().backward()
+    ims_c = ims.double().requires_grad_(True)
+    ref = st.invert_transform(st.transform(ims_c, t.double()), t.double())
+    ref.sum().backward()
+    assert relerr(out.detach().cpu(), ref.detach()) < 1e-5 and relerr(ims_d.grad.cpu(), ims_c.grad) < 1e-5

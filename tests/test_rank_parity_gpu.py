@@ -1,0 +1,92 @@
+"""north_star: "identical CMA rankings".  CMA-ES `tell` is rank based
+(/root/reference pix2latent/optimizer/base_cma_optimizer.py:120-141: the re-scored losses of the
+whole population go to `cma.tell`), so what must agree with the reference arithmetic is the ORDER
+of the population's losses.  Asserted here on the actual populations, not on 3 candidates:
+
+  * BigGAN-256, the bench problem (BASELINE configs[2]): the full pycma population of 18, asked by
+    the sampler, scored forward-only in ONE device pass of 18 and in the reference's chunks 9 + 9;
+  * StyleGAN2 64^2 (z in R^512): population 22 = 4 + floor(3 ln 512) (reference README.md:74), the
+    noise maps injected explicitly.
+
+Oracle: oracle/biggan_ref.py / stylegan2_ref.py + lpips_ref.py in fp32 on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same_order(native, oracle, what):
+    native, oracle = np.asarray(native, dtype=np.float64), np.asarray(oracle, dtype=np.float64)
+    gaps = np.diff(np.sort(oracle))
+    # (a tie in the oracle itself would make "the" order meaningless: the problems are seeded)
+    assert gaps.min() > 1e-5, '%s: oracle losses %g apart' % (what, gaps.min())
+    assert np.abs(native - oracle).max() < 1e-3, (what, np.abs(native - oracle).max())
+    assert np.array_equal(np.argsort(native), np.argsort(oracle)), \
+        '%s: ranking differs\nnative %s\noracle %s' % (what, native, oracle)
+
+
+@pytest.mark.timeout(1800)
+def test_full_population_18_ranks_like_the_oracle(dev):
+    import bench
+    from oracle import biggan_ref as R, lpips_ref as L
+    scored = {}
+    for ebs in (18, None):                       # one device pass | the reference's chunks of 9
+        opt, vm, (W, Wv, c_default, target, weight) = bench.build_problem(dev, exec_batch_size=ebs)
+        opt.setup_cma(vm)
+        variables = opt.cma_init(vm)             # the asked population (seeded sampler)
+        asked = torch.stack([t.detach().cpu() for t in variables.input.z.data])
+        _, losses, _ = opt.step(variables, optimize=False)     # the forward-only re-score `tell` gets
+        scored[ebs] = (asked, np.array(losses, dtype=np.float64))
+    assert torch.equal(scored[18][0], scored[None][0])
+    assert scored[18][0].shape == (18, 128)
+    # chunks of 9 vs one pass of 18: the 4^2 ... 16^2 layers pick their split-K factor from the grid
+    # size, i.e. the fp32 summation order of those layers follows the chunk -- same values to
+    # rounding, same order
+    assert np.abs(scored[18][1] - scored[None][1]).max() < 1e-5
+    assert np.array_equal(np.argsort(scored[18][1]), np.argsort(scored[None][1]))
+    z = scored[18][0].clamp(-2.0, 2.0)           # (the Clamp hook runs on a re-score too)
+    c = c_default.unsqueeze(0).repeat(18, 1)
+    ref = []
+    with torch.no_grad():
+        for i in range(0, 18, 6):
+            out = R.biggan_forward(W, z[i:i + 6], c[i:i + 6])
+            t = target.unsqueeze(0).repeat(out.shape[0], 1, 1, 1)
+            w = weight.unsqueeze(0).repeat(out.shape[0], 1, 1, 1)
+            ref.append(L.projection_loss(Wv, out, t, w))
+    ref = torch.cat(ref).numpy()
+    _assert_same_order(scored[18][1], ref, 'BigGAN-256 pop 18')
+
+
+@pytest.mark.timeout(900)
+def test_stylegan2_population_22_ranks_like_the_oracle(dev):
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    import pix2latent_amd.loss_functions as LF
+    from pix2latent_amd.optimizer.base_cma_optimizer import CMA
+    from oracle import stylegan2_ref as R, lpips_ref as L
+    SIZE, POP = 64, 22
+    W = S.stylegan2_weights(SIZE, 0)
+    Wv = S.lpips_vgg_weights(1)
+    model = StyleGAN2(model='cars', search='z', weights=W, size=SIZE, device=dev)
+    loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
+    es = CMA(mu=np.zeros(512), sigma=1.0, seed=4)
+    assert es.batch_size() == POP                # 4 + floor(3 ln 512)
+    z = torch.as_tensor(np.asarray(es.ask()), dtype=torch.float32).clamp(-2.0, 2.0)
+    g = torch.Generator().manual_seed(3)
+    noise1 = [torch.randn(1, 1, s[2], s[3], generator=g) for s in R.noise_shapes(SIZE)]
+    target = S.synthetic_target(SIZE, 1)
+    weight = torch.ones(3, SIZE, SIZE)
+    native = []
+    with torch.no_grad():
+        for lo, hi in ((0, 9), (9, 18), (18, 22)):            # chunks of max_batch_size = 9
+            n = hi - lo
+            out = model.forward_z(z[lo:hi].to(dev), noises=[t.repeat(n, 1, 1, 1).to(dev) for t in noise1])
+            native.append(loss_fn(out, target.unsqueeze(0).repeat(n, 1, 1, 1).to(dev),
+                                  weight.unsqueeze(0).repeat(n, 1, 1, 1).to(dev)).cpu())
+        out_r = R.forward_z(W, z, [t.repeat(POP, 1, 1, 1) for t in noise1], SIZE)
+        ref = L.projection_loss(Wv, out_r, target.unsqueeze(0).repeat(POP, 1, 1, 1),
+                                weight.unsqueeze(0).repeat(POP, 1, 1, 1))
+    _assert_same_order(torch.cat(native).numpy(), ref.numpy(), 'StyleGAN2-64 pop 22')
