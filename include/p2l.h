@@ -306,6 +306,16 @@ int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_
 int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I, int N_pad, int K_pad,
                                     int transpose_flip, int mode, float* w_packed,
                                     void* stream);
+/* Sub-pixel weights of a P2L_WFMT_BF16X3W model: the image above FOLLOWED by the fp16 x 2 image of
+ * the same 16 phase-tap slabs (4 bytes per weight + 4 tail floats; p2l_h2.hip): every 3x3 / sub-pixel
+ * launch of such a model that the Winograd kernel does not take runs in the fp16 x 2 arithmetic of
+ * section "fp16 x 2" above (3 MFMA products per fp32 product on per-image / per-layer power-of-two
+ * scaled operands) when the caller passes the workspace p2l_conv_workspace_bytes asks for; plain
+ * 3x3 buffers (p2l_pack_conv_weight_bf3w) carry their fp16 x 2 direct image behind the Winograd
+ * images.  p2l_packed_subpix_weight_floats: floats of a sub-pixel buffer of format wfmt. */
+size_t p2l_packed_subpix_weight_floats(int N_pad, int K_pad, int wfmt);
+int p2l_pack_conv_weight_subpix_h2(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                                   int transpose_flip, int mode, float* w_packed, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Batched GEMM fp32 (attention bmm's and their gradients).                  */

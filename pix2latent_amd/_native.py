@@ -186,9 +186,10 @@ def pack_conv_weight(src, taps, n_pad, k_pad, flip, wfmt, subpix_mode=None):
     if taps != 9:
         wfmt = WFMT_F32
     if subpix_mode is not None:
-        n = 16 * n_pad * k_pad
-        dst = torch.empty(n * 3 // 2 if wfmt != WFMT_F32 else n, device=src.device, dtype=torch.float32)
-        fn = L.p2l_pack_conv_weight_subpix_bf3 if wfmt != WFMT_F32 else L.p2l_pack_conv_weight_subpix
+        dst = torch.empty(L.p2l_packed_subpix_weight_floats(n_pad, k_pad, wfmt), device=src.device,
+                          dtype=torch.float32)
+        fn = {WFMT_F32: L.p2l_pack_conv_weight_subpix,
+              WFMT_BF16X3W: L.p2l_pack_conv_weight_subpix_h2}.get(wfmt, L.p2l_pack_conv_weight_subpix_bf3)
         check(fn(ptr(src), O, I, n_pad, k_pad, int(flip), int(subpix_mode), ptr(dst), stream()),
               'p2l_pack_conv_weight_subpix')
         return dst
@@ -216,7 +217,7 @@ EXPORTS = [
     'p2l_pack_conv_weight_pw', 'p2l_adam_step_dev',
     'p2l_attn_supported', 'p2l_attn_fwd_ws_bytes', 'p2l_attn_fwd', 'p2l_attn_bwd_dv_ws_bytes',
     'p2l_attn_bwd_dv', 'p2l_attn_bwd_qk_ws_bytes', 'p2l_attn_bwd_qk',
-    'p2l_pack_conv_weight_subpix_bf3', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
+    'p2l_pack_conv_weight_subpix_bf3', 'p2l_pack_conv_weight_subpix_h2', 'p2l_packed_subpix_weight_floats', 'p2l_gemm', 'p2l_gemm_ws_bytes', 'p2l_gemm_ws', 'p2l_linear_fwd', 'p2l_linear_bwd',
     'p2l_cbn_fold_fwd', 'p2l_cbn_fold_bwd', 'p2l_affine_relu_bwd_nblk',
     'p2l_affine_relu_bwd', 'p2l_softmax_fwd', 'p2l_softmax_bwd', 'p2l_maxpool2_bwd', 'p2l_maxpool2_bwd_amax', 'p2l_maxpool2_bwd_amax_slots',
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',
@@ -263,7 +264,7 @@ def lib():
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
                      'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes',
-                     'p2l_packed_weight_floats', 'p2l_attn_fwd_ws_bytes', 'p2l_affine_grid_sample_bwd_ws_bytes',
+                     'p2l_packed_weight_floats', 'p2l_packed_subpix_weight_floats', 'p2l_attn_fwd_ws_bytes', 'p2l_affine_grid_sample_bwd_ws_bytes',
                      'p2l_attn_bwd_dv_ws_bytes', 'p2l_attn_bwd_qk_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t
     return _lib

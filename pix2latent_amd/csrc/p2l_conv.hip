@@ -707,12 +707,13 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
     acc += __shfl_xor(acc, 32, 64);
     a[s] = acc;
   }
-  if (!(live && zp == 0)) return;
+  // the lanes that own an item (zp == 0) run the epilogue; every lane stays for the maxima
+  float mx = 0.f, mxp = 0.f;          // max |value stored to y| / |... to yp| of this lane's item
+  if (live && zp == 0) {
   if (k.arb_x == nullptr) {
     epilogue_quad<false>(k, a, (b * k.H + 2 * qy) * k.W + 2 * qx, b, 2 * qy, 2 * qx, n,
-                         k.bias ? k.bias[n] : 0.f);
-    return;
-  }
+                         k.bias ? k.bias[n] : 0.f, &mx, &mxp);
+  } else {
   // fused backward of relu(x*s+t) on the finished input gradient (same arithmetic as the
   // ARB branch of epilogue_vec, one channel per lane); the per-(sample, channel) sums are
   // written per QUAD (arb_nblk = quads per image) and reduced by p2l_arb_finish
@@ -749,6 +750,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
         }
       }
       dst[(size_t)pix * dld + n] = o;
+      if (pool_sum) mxp = fmaxf(mxp, fabsf(o)); else mx = fmaxf(mx, fabsf(o));
       sgx += g * xv;
       sg += g;
     }
@@ -756,6 +758,27 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const ConvK k) {
   const size_t po = ((size_t)b * k.arb_nblk + (size_t)qy * Wh + qx) * k.Cout + n;
   k.arb_partial[po] = sgx;
   k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + po] = sg;
+  }
+  }
+  // one partial maximum per BLOCK (64 items) for the launch that reads the tensor next (P2LAmax; the
+  // launcher sets the pointers only when a block's 64 items lie in one image)
+  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+    __shared__ float red[8];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64)); }
+    if (lane == 0) { red[wave] = mx; red[4 + wave] = mxp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const size_t first = (size_t)blockIdx.x * 64;                // first item of the block
+      const size_t per_image = (size_t)Hh * Wh * k.n_store;
+      if (first < total) {
+        const size_t bb = first / per_image;
+        const size_t slot = bb * k.amax_out_n + (first - bb * per_image) / 64;
+        if (k.amax_out != nullptr) k.amax_out[slot] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (k.amax_outp != nullptr) k.amax_outp[slot] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+      }
+    }
+  }
 }
 
 // Finish of a K-sliced Winograd launch (2 or 4 slices of [B,H,W,Cout] partial outputs): item =
@@ -950,6 +973,9 @@ int halo_pitch(int TW, bool bf3) {
   if (!bf3) return TW + 2;
   return TW == 16 ? 24 : (TW == 8 ? 12 : TW + 2);
 }
+// ... of the fp16 x 2 kernel's 64-byte rows (tools/h2_banks.py: 16- and 8-wide tiles are conflict
+// free at 24 rows per line, 2.0 LDS cycles per lane group at best for the 4-wide tiles of the 4^2 layers)
+int halo_pitch_h2(int TW) { return TW >= 8 ? 24 : (TW == 4 ? 8 : TW + 2); }
 
 // Winograd form (p2l_wino.hip).  Which launches take it is a function of the LAYER SHAPE only,
 // never of the batch: a candidate's result must not depend on how many others share its chunk
@@ -1002,6 +1028,17 @@ static int thin_shape(const P2LConv* d) {
 }
 // either bf16x3 pointwise kernel: no split-K
 static bool pw_any(const P2LConv* d) { return pw_shape(d) || thin_shape(d) >= 0; }
+
+// fp16 x 2 form of the direct 3x3 / sub-pixel kernel (p2l_h2.hip): every P2L_WFMT_BF16X3W launch that
+// the Winograd kernel does not take (sub-pixel up-convs, the 4^2 ... 16^2 layers in split-K slices,
+// H / W not multiples of 16) -- a function of the layer shape and the format; P2L_FORM_WINO_BF3
+// ("bf16 x 3 instead of fp16 x 2") keeps the bf16 x 3 kernel.  The launch also needs the 256 B per
+// image of workspace p2l_conv_workspace_bytes asks for.
+static bool direct_h2(const P2LConv* d) {
+  if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || (d->form & P2L_FORM_WINO_BF3)) return false;
+  if (d->ups == 1 || d->x_ld % 4 || d->Cin % 16 || d->Cout % 32) return false;
+  return !wino_shape(d);
+}
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
 // round.  All blocks of a launch do the same MFMA work and co-resident blocks
@@ -1100,7 +1137,13 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     }
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
-  if (d->ups > 2 || effective_splitk(d) > 1) return 0;
+  if (effective_splitk(d) > 1) {
+    // split-K launch of the direct kernels: the scalar finish kernel writes the tensor, one partial
+    // per block of 64 (quad, channel) items -- when a block never straddles two images.  (The
+    // hand-over thereby follows the LAYER, not the split-K choice a batch size brings with it.)
+    const int per_image = (d->H / 2) * (d->W / 2) * d->n_store;
+    return (per_image % 64 == 0) ? per_image / 64 : 0;
+  }
   ConvK k{};
   if (choose_tile(d, k) != P2L_OK || k.tb_log != 0 || k.partial) return 0;
   const int tm = thin_shape(d);
@@ -1112,7 +1155,7 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1) * 4;
 }
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
-  const size_t h2 = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  const size_t h2 = (wino_h2(d) || direct_h2(d)) ? (size_t)d->B * 64 * sizeof(float) : 0;
   if (d->splitk <= 1) return h2;
   return h2 + (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
 }
@@ -1203,7 +1246,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
   // fp16 x 2 Winograd: the partial maxima sit at the head of the workspace; a caller that gives
   // none gets the bf16 x 3 arithmetic
-  const size_t h2_bytes = wino_h2(d) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  const bool h2_direct = direct_h2(d);
+  const size_t h2_bytes = (wino_h2(d) || h2_direct) ? (size_t)d->B * 64 * sizeof(float) : 0;
   const bool use_h2 = h2_bytes && workspace &&
                       ws_bytes >= h2_bytes + (k.splitk > 1 ? (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float) : 0);
   if (use_h2) {
@@ -1375,6 +1419,25 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256) && k.tb_log == 0;
     const bool bf3 = bf3_3x3;
+    if (use_h2 && h2_direct) {
+      // fp16 x 2 form (p2l_h2.hip): its image follows the bf16 x 3 one
+      ConvK kh = k;
+      kh.hp = halo_pitch_h2(1 << k.tw_log);
+      kh.w = w + (size_t)16 * d->Cout * d->Cin * 3 / 2;
+      kh.w_tail = reinterpret_cast<const unsigned*>(kh.w + (size_t)16 * d->Cout * d->Cin);
+      if (kh.amax_in == nullptr) {
+        ConvK ka = kh;                      // the INPUT tensor: low-res (forward) / high-res frame (gradient)
+        ka.H = k.ibH; ka.W = k.ibW;
+        rc = p2l_amax_launch(ka, d->pro, st);
+        if (rc) return rc;
+      }
+      rc = p2l_h2_launch(kh, d->pro, 4, bn, small_sp, st);
+      if (prof_slot >= 0) {
+        g_prof.nprod[prof_slot] = 3;
+        (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
+      }
+      return rc;
+    }
     const int a_lds_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * k.hp;
     size_t lds_sp = (size_t)(a_lds_sp + 4 * bn) * (bf3 ? 24 : 20) * sizeof(float);
     const size_t lds_epi = (size_t)4 * 32 * (bn + 4) * sizeof(float);
@@ -1424,6 +1487,21 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     if (lds_epi > lds) lds = lds_epi;
   }
 
+  if (d->taps == 9 && use_h2 && h2_direct) {
+    ConvK kh = k;
+    kh.hp = halo_pitch_h2(TW);
+    kh.w = w + (size_t)9 * d->Cout * d->Cin * 3 / 2;
+    if (p2l_wino_weight_ok(d->Cout, d->Cin))
+      kh.w += p2l_wino_weight_floats(d->Cout, d->Cin) + p2l_wino_h2_weight_floats(d->Cout, d->Cin);
+    kh.w_tail = reinterpret_cast<const unsigned*>(kh.w + (size_t)9 * d->Cout * d->Cin);
+    if (kh.amax_in == nullptr) {
+      rc = p2l_amax_launch(kh, d->pro, st);
+      if (rc) return rc;
+    }
+    const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
+    rc = p2l_h2_launch(kh, d->pro, 9, bn, small, st);
+    if (prof_slot >= 0) g_prof.nprod[prof_slot] = 3;
+  } else
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
     if (bf3) {
@@ -1668,6 +1746,7 @@ extern "C" size_t p2l_packed_weight_floats(int taps, int N_pad, int K_pad, int w
   size_t n = direct * 3 / 2;
   if (wfmt == P2L_WFMT_BF16X3W && taps == 9 && p2l_wino_weight_ok(N_pad, K_pad))
     n += p2l_wino_weight_floats(N_pad, K_pad) + p2l_wino_h2_weight_floats(N_pad, K_pad);
+  if (wfmt == P2L_WFMT_BF16X3W && taps == 9) n += p2l_h2_weight_floats(N_pad, K_pad, 0);   // fp16 x 2 direct image
   if (wfmt == P2L_WFMT_BF16X3T && taps == 9) n += p2l_thin_weight_floats(N_pad, K_pad);
   return n;
 }
@@ -1703,9 +1782,31 @@ extern "C" int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int 
                                          void* stream) {
   int rc = p2l_pack_conv_weight_bf3(w_oihw, O, I, taps, N_pad, K_pad, transpose_flip, w_packed,
                                     stream);
-  if (rc || !p2l_wino_weight_ok(N_pad, K_pad)) return rc;
-  return p2l_wino_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip,
-                       w_packed + (size_t)taps * N_pad * K_pad * 3 / 2, (hipStream_t)stream);
+  if (rc) return rc;
+  float* next = w_packed + (size_t)taps * N_pad * K_pad * 3 / 2;
+  if (p2l_wino_weight_ok(N_pad, K_pad)) {
+    rc = p2l_wino_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip, next, (hipStream_t)stream);
+    if (rc) return rc;
+    next += p2l_wino_weight_floats(N_pad, K_pad) + p2l_wino_h2_weight_floats(N_pad, K_pad);
+  }
+  // the fp16 x 2 image of the direct kernel's weight tile (p2l_h2.hip) behind everything else
+  return p2l_h2_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip, -1, next, (hipStream_t)stream);
+}
+
+// sub-pixel weights of a P2L_WFMT_BF16X3W model: the bf16 x 3 image of p2l_pack_conv_weight_subpix_bf3
+// followed by the fp16 x 2 image of the same 16 phase-tap slabs
+extern "C" size_t p2l_packed_subpix_weight_floats(int N_pad, int K_pad, int wfmt) {
+  const size_t n = (size_t)16 * N_pad * K_pad;
+  if (wfmt == P2L_WFMT_F32) return n;
+  return n * 3 / 2 + (wfmt == P2L_WFMT_BF16X3W ? p2l_h2_weight_floats(N_pad, K_pad, 1) : 0);
+}
+extern "C" int p2l_pack_conv_weight_subpix_h2(const float* w_oihw, int O, int I, int N_pad, int K_pad,
+                                              int transpose_flip, int mode, float* w_packed,
+                                              void* stream) {
+  int rc = p2l_pack_conv_weight_subpix_bf3(w_oihw, O, I, N_pad, K_pad, transpose_flip, mode, w_packed, stream);
+  if (rc) return rc;
+  return p2l_h2_pack(w_oihw, O, I, N_pad, K_pad, transpose_flip, mode,
+                     w_packed + (size_t)16 * N_pad * K_pad * 3 / 2, (hipStream_t)stream);
 }
 
 extern "C" int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,

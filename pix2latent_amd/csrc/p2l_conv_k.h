@@ -168,7 +168,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 template <bool SIMPLE>
 __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], int pix0,
                                               int b, int oy0, int ox0, int n,
-                                              float bias_n) {
+                                              float bias_n, float* amax = nullptr,
+                                              float* amaxp = nullptr) {
   const int W = k.W;
   const int sub[4] = {0, 1, W, W + 1};
   if (SIMPLE) {
@@ -195,6 +196,7 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
     t = apply_act(t, k.act);
     if (k.mask) t = (k.mask[(size_t)(pix * (unsigned)k.mask_ld + (unsigned)n)] > 0.f) ? t : 0.f;
     if (k.y) k.y[(size_t)(pix * (unsigned)k.y_ld + (unsigned)n)] = t;
+    if (amax) *amax = fmaxf(*amax, fabsf(t));
     v[s] = t;
   }
   if (k.pool) {
@@ -205,6 +207,7 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
       p = (v[0] + v[1]) + (v[2] + v[3]);
     const unsigned pp = (unsigned)((b * (k.H >> 1) + (oy0 >> 1)) * (W >> 1) + (ox0 >> 1));
     k.yp[(size_t)(pp * (unsigned)k.yp_ld + (unsigned)n)] = p;
+    if (amaxp) *amaxp = fmaxf(*amaxp, fabsf(p));
   }
 }
 
@@ -441,3 +444,12 @@ int p2l_pw_pack_h2(const float* w_oihw, int O, int I, int N_pad, int K_pad, int 
 int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int transpose_flip,
                   float* dst, hipStream_t st);
 int p2l_wino_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
+// max |x| of every image (the fused prologue applied): 64 partial maxima each -> k.amax[B][64];
+// the extents of the INPUT tensor in k.H, k.W, k.Cin, k.x_ld (p2l_wino.hip)
+int p2l_amax_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);
+
+// fp16 x 2 form of the direct 3x3 / sub-pixel kernel (p2l_h2.hip)
+size_t p2l_h2_weight_floats(int N_pad, int K_pad, int subpix);
+int p2l_h2_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int flip, int mode, float* dst,
+                hipStream_t st);
+int p2l_h2_launch(const p2lconv::ConvK& k, int pro, int taps, int bn, bool small, hipStream_t st);

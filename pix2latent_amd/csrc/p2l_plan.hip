@@ -181,8 +181,12 @@ int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
   float *so = nullptr, *sop = nullptr;
   int ns = 0, set_o = -1, set_p = -1;
   if (R) {
-    if (c.d.ups == 0 && c.d.x_ld == c.d.Cin)
+    // (the input of a sub-pixel forward launch is the LOW-resolution tensor, that of its
+    //  input-gradient form the high-resolution one)
+    if ((c.d.ups == 0 || c.d.ups == 3) && c.d.x_ld == c.d.Cin)
       R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n);
+    else if (c.d.ups == 2 && !c.d.ext && c.d.x_ld == c.d.Cin)
+      R->get(c.x, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cin, &ex.amax.in, &ex.amax.in_n);
     R->drop(c.y); R->drop(c.yp);                       // this launch overwrites them
     ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
     if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.n_store == c.d.Cout) {
@@ -224,11 +228,11 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
     float* so = nullptr;
     int ns = 0, set_o = -1;
     if (R) {
-      if (c.d.ups == 0 && c.d.x_ld == c.d.Cin)
+      if ((c.d.ups == 0 || (c.d.ups == 3 && !c.d.ext)) && c.d.x_ld == c.d.Cin)
         R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &arb.amax.in, &arb.amax.in_n);
       R->drop(dx);
       ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
-      if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.ups == 0) {
+      if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && (c.d.ups == 0 || (c.d.ups == 3 && !c.d.ext))) {
         so = R->take(&set_o);
         if (pooled) arb.amax.outp = so; else arb.amax.out = so;
       }
@@ -567,7 +571,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c0.x = x; c0.w = g.w[0]; c0.bias = g.b[0]; c0.y = W + o.h1;
     c0.d.pro = P2L_PRO_AFFINE_RELU; c0.d.pro_bstride = CT;
     c0.ps = W + L.s + g.cbn_off[0]; c0.pt = W + L.t + g.cbn_off[0];
-    c0.want_amax = !g.up;                              // (an up block's conv_1 takes the sub-pixel, bf16 x 3 form)
+    c0.want_amax = true;                               // (conv_1: Winograd / sub-pixel / direct, all fp16 x 2)
     RET_IF(run_conv(c0, skws, L.skws_floats, st));
     // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
     ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
@@ -642,6 +646,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
     // ds/dt of the tail BN feed nothing (no conditioning): park them in `draw`.
     ArbArgs a{xlast, m->ch, m->tail_s, m->tail_t, 0, nullptr, 0, 0, 0, W + L.draw,
               W + L.draw + (size_t)B * m->ch, m->ch};
+    c.want_amax = true;                                  // (conv_3's input gradient of the last block reads ga)
     RET_IF(run_dgrad_arb(c, a, ga, gd, part, skws, L.skws_floats, st));
     part += L.tail_pf;
   }
@@ -748,10 +753,20 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
         RET_IF(p2l_gemm_ws(&q4, gb, W + L.att_theta, W + L.d_phi_p, skws, L.skws_floats * sizeof(float), st));
       }
       // max-pool backward for phi and g
-      RET_IF(p2l_maxpool2_bwd(W + L.att_phi, C / 8, W + L.d_phi_p, C / 8, nullptr, 0,
-                              W + L.d_phi, C / 8, B, H, H, C / 8, 0, st));
-      RET_IF(p2l_maxpool2_bwd(W + L.att_g, C / 2, W + L.d_g_p, C / 2, nullptr, 0,
-                              W + L.d_g, C / 2, B, H, H, C / 2, 0, st));
+      // (the max-pool backward leaves the maxima of what it writes for the 1x1 convs t2 / t3 below,
+      //  which take the fp16 x 2 form with them)
+      auto pool_bwd = [&](const float* y, const float* dyp, float* dy, int Cc) -> int {
+        float* so = nullptr;
+        int set_o = -1;
+        const int ns = p2l_maxpool2_bwd_amax_slots(H, H, Cc);
+        amax_drop(dy);
+        if (g_amax && ns > 0 && (size_t)ns * B <= g_amax->set_floats) so = g_amax->take(&set_o);
+        RET_IF(p2l_maxpool2_bwd_amax(y, Cc, dyp, Cc, nullptr, 0, dy, Cc, B, H, H, Cc, 0, so, st));
+        if (so) g_amax->put(dy, B, H, H, Cc, so, ns, set_o);
+        return P2L_OK;
+      };
+      RET_IF(pool_bwd(W + L.att_phi, W + L.d_phi_p, W + L.d_phi, C / 8));
+      RET_IF(pool_bwd(W + L.att_g, W + L.d_g_p, W + L.d_g, C / 2));
       // dx = dy + theta^T-grad + phi-grad + g-grad (chained residual, in place)
       ConvCall t1 = mk_conv(B, H, H, C / 8, C, 1);
       t1.x = W + L.d_theta; t1.w = m->att_wt[0]; t1.y = ga; t1.res = ga; t1.d.res_ld = C;
@@ -761,8 +776,8 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
       RET_IF(run_conv(t2, skws, L.skws_floats, st));
       ConvCall t3 = mk_conv(B, H, H, C / 2, C, 1);
       t3.x = W + L.d_g; t3.w = m->att_wt[2]; t3.y = ga; t3.res = ga; t3.d.res_ld = C;
+      t3.want_amax = true;                               // (ga feeds the next block's conv_3 input gradient)
       RET_IF(run_conv(t3, skws, L.skws_floats, st));
-      amax_clear();
     }
   }
   // ga = d gen_z output [B, 16*16*ch]; conditioning gradients

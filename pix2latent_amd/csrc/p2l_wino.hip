@@ -1099,6 +1099,13 @@ int p2l_wino_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int t
   return p2l_check_launch();
 }
 
+int p2l_amax_launch(const ConvK& k, int pro, hipStream_t st) {
+  if (pro == P2L_PRO_NONE) hipLaunchKernelGGL(wino_amax_kernel<P2L_PRO_NONE>, dim3(64, k.B), dim3(256), 0, st, k);
+  else if (pro == P2L_PRO_AFFINE_RELU) hipLaunchKernelGGL(wino_amax_kernel<P2L_PRO_AFFINE_RELU>, dim3(64, k.B), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(wino_amax_kernel<P2L_PRO_AFFINE>, dim3(64, k.B), dim3(256), 0, st, k);
+  return p2l_check_launch();
+}
+
 // k arrives with the 8x16-pixel tiling (tiles_x = W/16, tiles_y = H/8, n_mtiles, n_ntiles =
 // Cout/64).  16x16-pixel blocks whenever H and W allow it (measured in the bench step at 18, 9,
 // 5, 3, 2 candidates per GPU: tools/policy_probe.py), the 8x16-pixel kernel otherwise or on

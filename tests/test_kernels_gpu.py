@@ -1007,7 +1007,9 @@ def test_affine_grid_sample_backward(dev, shape):
     probe = torch.randn(B, C, H, W, generator=g)
     thetas = []
     st = SpatialTransform()
-    t = torch.tensor([[1.3, 0.2, -0.1], [0.7, -0.4, 0.3], [1.0, 0.0, 0.0]])[:B]
+    # (no identity: there every sample sits exactly ON a pixel centre, the kink of the bilinear kernel,
+    #  and which one-sided derivative d theta gets is decided by the last bit of ix)
+    t = torch.tensor([[1.3, 0.2, -0.1], [0.7, -0.4, 0.3], [1.07, 0.03, -0.05]])[:B]
     thetas.append(st._theta(t[:, 0], t[:, 1:]))
     thetas.append(torch.eye(2, 3).unsqueeze(0).repeat(B, 1, 1) + 0.35 * torch.randn(B, 2, 3, generator=g))
     for theta in thetas:
@@ -1057,3 +1059,143 @@ def test_invertibility_loss_runs_native_on_the_device(dev):
     ref = st.invert_transform(st.transform(ims_c, t.double()), t.double())
     ref.sum().backward()
     assert relerr(out.detach().cpu(), ref.detach()) < 1e-5 and relerr(ims_d.grad.cpu(), ims_c.grad) < 1e-5
+
+
+def _mfma_products(N, fn):
+    """run fn() under the launch profiler -> 16-bit MFMA products per fp32 product of its 3x3 launches
+    (6 = bf16 x 3, 3 = fp16 x 2)"""
+    lib = N.lib()
+    N.check(lib.p2l_prof_begin(64), 'p2l_prof_begin')
+    lib.p2l_prof_step(0, 1)
+    out = fn()
+    torch.cuda.synchronize()
+    arr = [(C.c_double * 2)() for _ in range(5)]
+    cnt = (C.c_int32 * 2)()
+    N.check(lib.p2l_prof_end4(arr[0], arr[1], cnt, arr[2], arr[3], arr[4]), 'p2l_prof_end4')
+    assert cnt[0] >= 1
+    return out, arr[4][0] / arr[3][0]
+
+
+H2_DIRECT_CASES = [
+    # (the Winograd kernel takes none of these: H not a multiple of 16 / sub-pixel / small grids in split-K slices)
+    dict(B=2, H=24, Cin=64, Cout=64, pro='affine_relu', bias=True, splitk=1),      # partial tiles (never split)
+    dict(B=3, H=8, Cin=256, Cout=64, bias=True, res='same', alpha=0.5),            # two images per tile, split-K
+    dict(B=5, H=4, Cin=128, Cout=128, pro='affine', act='relu'),                    # eight images per tile
+    dict(B=2, H=48, Cin=32, Cout=32, act='relu', pool='max'),                       # BN = 32
+    dict(B=2, H=40, Cin=48, Cout=96, act='relu', splitk=1),                         # partial tiles
+    dict(B=2, H=16, Cin=512, Cout=64, splitk=1),                                    # forced unsplit, one image per tile
+]
+
+
+@pytest.mark.parametrize('case', H2_DIRECT_CASES, ids=lambda c: '-'.join('%s%s' % kv for kv in c.items()))
+def test_direct_kernel_fp16x2(dev, O, case):
+    """conv_h2_kernel (csrc/p2l_h2.hip): the direct 3x3 kernel in the fp16 x 2 arithmetic -- default for
+    every P2L_WFMT_BF16X3W launch the Winograd kernel does not take -- against torch in fp64 at the
+    tolerance of the fp32-grade kernels, next to the bf16 x 3 form of the same launch
+    (P2L_FORM_WINO_BF3); the launch profiler confirms which arithmetic ran."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(21)
+    B, H, Cin, Cout = case['B'], case['H'], case['Cin'], case['Cout']
+    x = torch.randn(B, Cin, H, H, generator=g)
+    x[0] *= 1e-6                                        # images of very different magnitude in one launch
+    if B > 2:
+        x[2] *= 3e4
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = 0.1 * torch.randn(Cout, generator=g) if case.get('bias') else None
+    kw = dict(wfmt=2)
+    a = x.double()
+    if case.get('pro'):
+        s = 0.5 + torch.rand(B, Cin, generator=g)
+        t = 0.3 * torch.randn(B, Cin, generator=g) * x.abs().amax(dim=(1, 2, 3)).view(B, 1)
+        a = a * s.double().view(B, Cin, 1, 1) + t.double().view(B, Cin, 1, 1)
+        if case['pro'] == 'affine_relu':
+            a = F.relu(a)
+        kw.update(pro=N.PRO_AFFINE_RELU if case['pro'] == 'affine_relu' else N.PRO_AFFINE,
+                  pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin)
+    alpha = case.get('alpha', 1.0)
+    ref = alpha * F.conv2d(a, w.double(), None, padding=1)
+    if bias is not None:
+        ref = ref + bias.double().view(1, Cout, 1, 1)
+        kw['bias'] = bias.to(dev)
+    if case.get('res'):
+        r = torch.randn(B, Cout, H, H, generator=g) * ref.abs().amax(dim=(1, 2, 3)).view(B, 1, 1, 1).float()
+        ref = ref + r.double()
+        kw['res'] = nhwc(r, dev)
+    if case.get('act') == 'relu':
+        ref = F.relu(ref)
+        kw['act'] = N.ACT_RELU
+    if case.get('pool') == 'max':
+        kw['pool'] = N.POOL_MAX
+    if 'splitk' in case:
+        kw['splitk'] = case['splitk']
+    kw['alpha'] = alpha
+    wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
+    xs = nhwc(x, dev)
+    O.DEFAULT_FORM = N.FORM_NO_WINO
+    (y, yp), mm = _mfma_products(N, lambda: O.conv(xs, wp, B, H, H, Cin, Cout, 9, **kw))
+    assert abs(mm - 3.0) < 1e-6, 'expected the fp16 x 2 kernel, got %g products' % mm
+    O.DEFAULT_FORM = N.FORM_NO_WINO | N.FORM_WINO_BF3
+    (y3, _), mm3 = _mfma_products(N, lambda: O.conv(xs, wp, B, H, H, Cin, Cout, 9, **kw))
+    assert abs(mm3 - 6.0) < 1e-6
+    y, y3 = nchw(y).double(), nchw(y3).double()
+    for b in range(B):
+        sc = ref[b].abs().max().item()
+        assert (y[b] - ref[b]).abs().max().item() < 2e-5 * sc, (b, (y[b] - ref[b]).abs().max().item() / sc)
+        assert (y3[b] - y[b]).abs().max().item() < 2e-5 * sc
+    if yp is not None:
+        assert relerr(nchw(yp), F.max_pool2d(ref, 2)) < 2e-5
+    # a candidate's bits do not depend on who shares its launch (same split-K request)
+    kw1 = dict(kw)
+    for key in ('pro_s', 'pro_t', 'res'):
+        if key in kw1:
+            kw1[key] = kw1[key][1:2].contiguous()
+    if 'splitk' not in kw1:
+        d = N.P2LConv()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.wfmt, d.x_ld = B, H, H, Cin, Cout, 9, 2, Cin
+        d.n_store = d.y_ld = Cout
+        d.form = N.FORM_NO_WINO
+        kw1['splitk'] = N.lib().p2l_conv_suggest_splitk(C.byref(d))
+    O.DEFAULT_FORM = N.FORM_NO_WINO
+    ya, _ = O.conv(xs, wp, B, H, H, Cin, Cout, 9, **dict(kw, splitk=kw1['splitk']))
+    y1, _ = O.conv(xs[1:2].contiguous(), wp, 1, H, H, Cin, Cout, 9, **kw1)
+    assert torch.equal(y1[0], ya[1]), 'result depends on the batch composition'
+
+
+def test_direct_kernel_fp16x2_subpixel_and_maxima(dev, O):
+    """the sub-pixel forms (nearest-x2 up-conv forward, its input gradient) in the fp16 x 2 arithmetic,
+    and the maxima a split-K launch now leaves through its finish kernel (P2LAmax): exact per-image
+    maxima, and a consumer that takes them gives the bits of the consumer that ran its own pass."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(23)
+    B, H, Cin, Cout = 2, 32, 64, 64
+    x = torch.randn(B, Cin, H // 2, H // 2, generator=g)
+    x[1] *= 1e3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode='nearest'), w.double(), None, padding=1)
+    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin, wfmt=2)
+    O.DEFAULT_FORM = N.FORM_AUTO
+    (y, _), mm = _mfma_products(N, lambda: O.conv(nhwc(x, dev), wsp, B, H, H, Cin, Cout, 9, wfmt=2, ups=2))
+    assert abs(mm - 3.0) < 1e-6
+    for b in range(B):
+        assert (nchw(y)[b].double() - ref[b]).abs().max().item() < 2e-5 * ref[b].abs().max().item()
+    # input-gradient form: dx[low res] of the same conv for a gradient dy at high resolution
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), w.double(), None, padding=1).backward(dy.double())
+    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True, wfmt=2)
+    (dx, _), mm = _mfma_products(N, lambda: O.conv(nhwc(dy, dev), wtsp, B, H, H, Cout, Cin, 9, wfmt=2, ups=3))
+    assert abs(mm - 3.0) < 1e-6
+    assert relerr(nchw(dx), xr.grad) < 2e-5
+    # split-K launch -> finish kernel -> maxima
+    Hs, Ci, Co = 8, 256, 128
+    xs = torch.randn(3, Ci, Hs, Hs, generator=g)
+    xs[2] *= 1e-4
+    ws = torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)
+    wps = O.pack_conv_weight(ws.to(dev), 9, Co, Ci, wfmt=2)
+    ys, _, (am, _) = O.conv(nhwc(xs, dev), wps, 3, Hs, Hs, Ci, Co, 9, wfmt=2, act=N.ACT_RELU, want_amax=True)
+    assert am is not None and torch.equal(am.amax(dim=1), ys.abs().amax(dim=(1, 2, 3)))
+    w2 = torch.randn(Co, Co, 3, 3, generator=g) / math.sqrt(9 * Co)
+    wp2 = O.pack_conv_weight(w2.to(dev), 9, Co, Co, wfmt=2)
+    z0, _ = O.conv(ys, wp2, 3, Hs, Hs, Co, Co, 9, wfmt=2)
+    z1, _ = O.conv(ys, wp2, 3, Hs, Hs, Co, Co, 9, wfmt=2, amax_in=am)
+    assert torch.equal(z0, z1)

@@ -33,7 +33,7 @@ def sg(request, dev):
     z = torch.randn(B, 512, generator=g)
     noises = [torch.randn(B, 1, s[2], s[3], generator=g) for s in R.noise_shapes(SIZE)]
     probe = torch.randn(B, 3, SIZE, SIZE, generator=g) / SIZE
-    return dict(W=W, model=model, z=z, noises=noises, probe=probe, B=B, R=R)
+    return dict(W=W, model=model, z=z, noises=noises, probe=probe, B=B, R=R, strict=(request.param == 'narrow'))
 
 
 FLOOR_X, SLACK = 3.0, 2e-4
@@ -46,6 +46,32 @@ def d64(W):
 def rel(a, b):
     a, b = a.detach().cpu().double().flatten(), b.detach().cpu().double().flatten()
     return ((a - b).norm() / b.norm()).item()
+
+
+def rel_rows(a, b):
+    """per-candidate relative L2 distance"""
+    a = a.detach().cpu().double().reshape(a.shape[0], -1)
+    b = b.detach().cpu().double().reshape(b.shape[0], -1)
+    return (a - b).norm(dim=1) / b.norm(dim=1)
+
+
+def grad_close(got, ref32, ref64, what, strict):
+    """The gradient of this network is piecewise: every leaky-ReLU unit whose pre-activation two
+    arithmetics put on different sides of zero moves a candidate's gradient by a STEP.  Measured per
+    candidate (tools/sg2_ab.py, three seeds x {exact fp32, bf16 x 3, fp16 x 2} kernels): the distance
+    from the fp64 oracle is either ~2e-6 -- the arithmetic alone, the same for all three native
+    arithmetics and for the fp32 CPU oracle -- or one of a few values between 2e-4 and 4e-3 that
+    whichever arithmetics take the same flip SHARE (1.81e-3 for one candidate in all three).  The
+    wide network flips in most candidates, the narrow one hardly ever.  So, per candidate:
+      * none beyond 1e-2, the typical one within FLOOR_X x the fp32 oracle's typical distance plus
+        one flip (2e-3);
+      * narrow network (strict): the typical candidate within FLOOR_X x the fp32 oracle's typical
+        distance + 2e-5 -- arithmetic level, no flip allowance."""
+    dist, floor = rel_rows(got, ref64), rel_rows(ref32, ref64)
+    assert dist.max().item() < 1e-2, (what, dist, floor)
+    assert dist.median().item() < FLOOR_X * floor.median().item() + 2e-3, (what, dist, floor)
+    if strict:
+        assert dist.median().item() < FLOOR_X * floor.median().item() + 2e-5, (what, dist, floor)
 
 
 def test_mapping(sg, dev):
@@ -74,8 +100,7 @@ def test_gradient_to_z(sg, dev):
     zd = sg['z'].to(dev).requires_grad_(True)
     out = sg['model'].forward_z(zd, noises=[n.to(dev) for n in sg['noises']])
     (out * sg['probe'].to(dev)).sum().backward()
-    floor = rel(zr.grad, z64.grad)
-    assert rel(zd.grad, z64.grad) < FLOOR_X * floor + SLACK, (rel(zd.grad, z64.grad), floor)
+    grad_close(zd.grad, zr.grad, z64.grad, 'dz', sg['strict'])
 
 
 def test_forward_w_and_noise_gradients(sg, dev):
@@ -97,9 +122,8 @@ def test_forward_w_and_noise_gradients(sg, dev):
     (out * sg['probe'].to(dev)).sum().backward()
     w64, n64 = wplus.double().requires_grad_(True), flat.double().requires_grad_(True)
     (R.forward_w(d64(sg['W']), w64, n64, SIZE) * sg['probe'].double()).sum().backward()
-    fw, fn = rel(wr.grad, w64.grad), rel(nr.grad, n64.grad)
-    assert rel(wd.grad, w64.grad) < FLOOR_X * fw + SLACK, (rel(wd.grad, w64.grad), fw)
-    assert rel(nd.grad, n64.grad) < FLOOR_X * fn + SLACK, (rel(nd.grad, n64.grad), fn)
+    grad_close(wd.grad, wr.grad, w64.grad, 'dw+', sg['strict'])
+    grad_close(nd.grad, nr.grad, n64.grad, 'dnoise', sg['strict'])
     assert hasattr(model, 'latent_mean') and hasattr(model, 'latent_std')
 
 
