@@ -997,6 +997,9 @@ static int wino_split(const P2LConv* d) {
 static bool wino_shape(const P2LConv* d) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || (d->form & P2L_FORM_NO_WINO)) return false;
   if (d->H % 8 || d->W % 16 || d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin)) return false;
+#ifdef P2L_AB_DIRECT64                                  // (A/B build: 64-input-channel layers on the direct kernel)
+  if (d->Cin <= P2L_AB_DIRECT64 && !(d->form & P2L_FORM_WINO_ANY)) return false;
+#endif
   const int per_image = (d->H / 8) * (d->W / 16) * (d->Cout / 64);
   if ((d->form & P2L_FORM_WINO_ANY) || per_image >= 64) return true;
   // small-grid layers: in the K-sliced form only, i.e. when the caller passes the slice count

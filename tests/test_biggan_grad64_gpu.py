@@ -24,7 +24,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-def _oracle(W, Wv, z, c, target, weight, dtype):
+def _oracle(W, Wv, z, c, target, weight, dtype, tape=None):
     from oracle import biggan_ref as R, lpips_ref as L
     cast = (lambda t: t.to(dtype))
     Wd = {k: cast(v) if torch.is_floating_point(v) else v for k, v in W.items()}
@@ -32,8 +32,8 @@ def _oracle(W, Wv, z, c, target, weight, dtype):
     zr = cast(z).clone().requires_grad_(True)
     cr = cast(c).clone().requires_grad_(True)
     taps = {}
-    out = R.generator_forward(Wd, torch.cat((zr, cr), dim=1), cbn_taps=taps)
-    loss = L.projection_loss(Wvd, out, cast(target), cast(weight))
+    out = R.generator_forward(Wd, torch.cat((zr, cr), dim=1), cbn_taps=taps, tape=tape)
+    loss = L.projection_loss(Wvd, out, cast(target), cast(weight), tape=tape)
     loss.mean().backward()                      # closure.py:58
     return dict(loss=loss.detach(), out=out.detach(), dz=zr.grad, dc=cr.grad,
                 cbn={k: (w.grad.flatten(1), b.grad.flatten(1)) for k, (w, b) in taps.items()})
@@ -71,6 +71,13 @@ def runs(dev):
                cbn=hip_cbn)
     o32 = _oracle(W, Wv, z, c, target, weight, torch.float32)
     o64 = _oracle(W, Wv, z, c, target, weight, torch.float64)
+    # the same two oracles with the DISCRETE decisions of the native run replayed (ReLU signs,
+    # max-pool winners, L1 signs: oracle/replay.py, oracle/masks.py): arithmetic alone
+    from oracle.masks import DecisionTape
+    from oracle.replay import native_decisions
+    items = native_decisions(model, loss_fn, W, B, dev, out, target.to(dev), None)
+    o32['replayed'] = _oracle(W, Wv, z, c, target, weight, torch.float32, DecisionTape(replay=items))
+    o64['replayed'] = _oracle(W, Wv, z, c, target, weight, torch.float64, DecisionTape(replay=items))
     return hip, o32, o64, model._bn_prefixes
 
 
@@ -92,22 +99,29 @@ def test_latent_gradients_within_3x_of_the_oracles_own_fp32_noise(runs, which):
 
 def test_per_layer_cbn_gradients(runs):
     """gains and biases of the 48 conditional-BN layers, output side first (the order the
-    backward pass produces them in)"""
+    backward pass produces them in).
+
+    Round 4: with the native run's decisions REPLAYED in both oracles.  Free-running, one ReLU of
+    a 16^2 layer that two arithmetics put on different sides of zero shifts EVERY gradient upstream
+    of it by the same ~7e-3 (measured when the 4^2 ... 16^2 convs moved to the fp16 x 2 kernel: all
+    of layers 4 ... 0 moved together, with and without handed-over maxima), which says nothing about
+    the gradient path.  With the decisions equal a wrong path still shows as an error of order one,
+    and the arithmetic has to sit at the fp32 oracle's own level, layer by layer."""
     hip, o32, o64, prefixes = runs
-    assert len(prefixes) == 48 and set(prefixes) == set(o64['cbn'].keys())
+    r32, r64 = o32['replayed'], o64['replayed']
+    assert len(prefixes) == 48 and set(prefixes) == set(r64['cbn'].keys())
     report = []
     for p in reversed(prefixes):
         for k, name in ((0, 'gain'), (1, 'bias')):
-            floor = rel(o32['cbn'][p][k], o64['cbn'][p][k])
-            got = rel(hip['cbn'][p][k], o64['cbn'][p][k])
+            floor = rel(r32['cbn'][p][k], r64['cbn'][p][k])
+            got = rel(hip['cbn'][p][k], r64['cbn'][p][k])
             report.append((p, name, got, floor))
-    # the fp32 noise of one layer's gradient is a handful of discrete events (which ReLU /
-    # max-pool masks flip), so a layer's own fp32-oracle distance fluctuates around the typical
-    # level: judge every layer against the larger of its own floor and the median one.  (A wrong
-    # gradient path is not a factor-3 effect: it shows up as a relative error of order one.)
     typical = float(np.median([r[3] for r in report]))
-    bad = [r for r in report if not r[2] < FLOOR_X * max(r[3], typical) + SLACK]
+    bad = [r for r in report if not r[2] < 1.5 * max(r[3], typical) + 2e-5]
     worst = max(report, key=lambda r: r[2] / (max(r[3], typical) + 1e-12))
-    print('typical fp32-oracle distance %.3g' % typical)
+    print('decisions replayed: typical fp32-oracle distance %.3g' % typical)
     print('worst layer: %s %s native %.3g oracle-fp32 %.3g' % worst)
     assert not bad, 'first failing (from the output side): %s %s native %.3g vs floor %.3g' % bad[0]
+    # free-running, coarse: no layer off by more than a few flips
+    free = max(rel(hip['cbn'][p][k], o64['cbn'][p][k]) for p in prefixes for k in (0, 1))
+    assert free < 3e-2, free
