@@ -997,9 +997,12 @@ static int wino_split(const P2LConv* d) {
 static bool wino_shape(const P2LConv* d) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || d->ups != 0 || (d->form & P2L_FORM_NO_WINO)) return false;
   if (d->H % 8 || d->W % 16 || d->x_ld % 4 || !p2l_wino_weight_ok(d->Cout, d->Cin)) return false;
-#ifdef P2L_AB_DIRECT64                                  // (A/B build: 64-input-channel layers on the direct kernel)
-  if (d->Cin <= P2L_AB_DIRECT64 && !(d->form & P2L_FORM_WINO_ANY)) return false;
-#endif
+  // 64 input channels = 4 chunks per block: the 16x16 kernel's prologue + epilogue (16.5 k cycles, one
+  // block per CU) are more than its loop (14 k), and the direct fp16 x 2 kernel -- three blocks per CU
+  // that overlap each other's epilogues -- is as fast per launch (tools/bench_h2.py: 256^2 0.387 vs
+  // 0.393 ms, 128^2 0.093 vs 0.100) and +0.7 ... 1.7 % in the step at 18 / 9 candidates, neutral
+  // below (same-box A/B, round 4); 128-channel layers stay (1.22x for Winograd)
+  if (d->Cin <= 64 && !(d->form & P2L_FORM_WINO_ANY)) return false;
   const int per_image = (d->H / 8) * (d->W / 16) * (d->Cout / 64);
   if ((d->form & P2L_FORM_WINO_ANY) || per_image >= 64) return true;
   // small-grid layers: in the K-sliced form only, i.e. when the caller passes the slice count
@@ -1041,6 +1044,17 @@ static bool direct_h2(const P2LConv* d) {
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || (d->form & P2L_FORM_WINO_BF3)) return false;
   if (d->ups == 1 || d->x_ld % 4 || d->Cin % 16 || d->Cout % 32) return false;
   return !wino_shape(d);
+}
+
+// ... and of the 1x1 kernel's small-grid form (p2l_pw.hip, pw_h2_kernel<.., SM>): the 4^2 ... 16^2
+// layers of P2L_WFMT_PW weights that the full-tile pointwise kernels do not take (multi-image tiles,
+// split-K slices).  Shape and format only.
+static bool pw_small_h2(const P2LConv* d) {
+  if (d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0 || pw_shape(d)) return false;
+  if (d->form & (P2L_FORM_NO_PW | P2L_FORM_WINO_BF3)) return false;
+  if (d->Cin % 32 || d->Cout % 64 || d->x_ld % 4) return false;
+  ConvK k{};
+  return choose_tile(d, k) == P2L_OK && !k.partial;
 }
 
 // Output-channel tile: 64 unless the grid then leaves CUs idle in its last
@@ -1158,7 +1172,7 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1) * 4;
 }
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
-  const size_t h2 = (wino_h2(d) || direct_h2(d)) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  const size_t h2 = (wino_h2(d) || direct_h2(d) || pw_small_h2(d)) ? (size_t)d->B * 64 * sizeof(float) : 0;
   if (d->splitk <= 1) return h2;
   return h2 + (size_t)d->splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
 }
@@ -1249,8 +1263,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   k.splitk = cdiv(k.nchunks, k.chunks_per_split);
   // fp16 x 2 Winograd: the partial maxima sit at the head of the workspace; a caller that gives
   // none gets the bf16 x 3 arithmetic
-  const bool h2_direct = direct_h2(d);
-  const size_t h2_bytes = (wino_h2(d) || h2_direct) ? (size_t)d->B * 64 * sizeof(float) : 0;
+  const bool h2_direct = direct_h2(d), h2_pw_small = pw_small_h2(d);
+  const size_t h2_bytes = (wino_h2(d) || h2_direct || h2_pw_small) ? (size_t)d->B * 64 * sizeof(float) : 0;
   const bool use_h2 = h2_bytes && workspace &&
                       ws_bytes >= h2_bytes + (k.splitk > 1 ? (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float) : 0);
   if (use_h2) {
@@ -1517,6 +1531,19 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
                              : launch_conv<9, 64, 16, 5>(k, d->pro, d->ups, lds, st);
     else          rc = small ? launch_conv<9, 32, 16, 3>(k, d->pro, d->ups, lds, st)
                              : launch_conv<9, 32, 16, 5>(k, d->pro, d->ups, lds, st);
+  } else if (d->taps == 1 && use_h2 && h2_pw_small) {
+    // 1x1 layers of 4^2 ... 16^2 in the fp16 x 2 arithmetic (multi-image tiles, split-K in
+    // blockIdx.y; the slices meet in conv_splitk_finish below)
+    ConvK kp = k;
+    kp.w = w + (size_t)d->Cout * d->Cin + (size_t)d->Cout * d->Cin * 3 / 2;
+    kp.w_tail = reinterpret_cast<const unsigned*>(kp.w + (size_t)d->Cout * d->Cin);
+    kp.n_ntiles = d->Cout / 64;
+    if (kp.amax_in == nullptr) {
+      rc = p2l_amax_launch(kp, d->pro, st);
+      if (rc) return rc;
+    }
+    rc = p2l_pw_launch(kp, d->pro, st);
+    if (prof_slot >= 0) g_prof.nprod[prof_slot] = 3;
   } else if (kc == 32) {
     if (bn == 64) rc = launch_conv<1, 64, 32, 4>(k, d->pro, 0, lds, st);
     else          rc = launch_conv<1, 32, 32, 4>(k, d->pro, 0, lds, st);

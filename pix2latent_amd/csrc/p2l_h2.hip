@@ -94,19 +94,25 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   {
     float sw, inv_w;
     h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
-    for (int t = 0; t < TB; ++t) {
+    // one image per tile: the whole block reduces; several: one WAVE per image (shuffles only)
+    const int step = (TB == 1) ? 256 : 64, me = (TB == 1) ? tid : lane;
+    for (int t = (TB == 1) ? 0 : wave; t < TB; t += 4) {
       const int b = b0 + t;
       float a = 0.f, ms = 0.f, mtt = 0.f;
       if (b < k.B) {
         if (k.amax_in != nullptr) {
-          for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+          for (int i = me; i < k.amax_in_n; i += step) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
           if (PRO != P2L_PRO_NONE) {
-            const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
-            const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
-            for (int c = tid; c < k.Cin; c += 256) { ms = fmaxf(ms, fabsf(ps[c])); mtt = fmaxf(mtt, fabsf(pt[c])); }
+            const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
+            const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
+            for (int c = me; c < (k.Cin >> 2); c += step) {
+              const f32x4 s4 = ps[c], t4 = pt[c];
+              ms = fmaxf(fmaxf(ms, fmaxf(fabsf(s4.x), fabsf(s4.y))), fmaxf(fabsf(s4.z), fabsf(s4.w)));
+              mtt = fmaxf(fmaxf(mtt, fmaxf(fabsf(t4.x), fabsf(t4.y))), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+            }
           }
-        } else if (tid < 64) {
-          a = k.amax[b * 64 + tid];
+        } else if (me < 64) {
+          a = k.amax[b * 64 + me];
         }
       }
 #pragma unroll
@@ -114,17 +120,20 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         a = fmaxf(a, __shfl_xor(a, o, 64));
         if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mtt = fmaxf(mtt, __shfl_xor(mtt, o, 64)); }
       }
-      if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mtt; }
-      __syncthreads();
-      a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
-      ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
-      mtt = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
+      if (TB == 1) {
+        if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mtt; }
+        __syncthreads();
+        a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
+        ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
+        mtt = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
+      }
       if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mtt) * 1.001f;
       float xs, inv_x;
       h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
-      if (tid == 0) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
-      __syncthreads();                                 // (scratch reused by the next image / the tile)
+      if ((TB == 1) ? (tid == 0) : (lane == 0)) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
+      if (TB == 1) break;
     }
+    __syncthreads();                                   // (scales visible; the scratch becomes the tile)
   }
 
   // ---- per-thread staging descriptors (fixed across chunks) --------------

@@ -202,12 +202,20 @@ __device__ __forceinline__ void pw_store_split_h2(float* As, int row, int q4, co
   *reinterpret_cast<h16x4*>(rb + h2_chunk(2 + (q4 >> 1), row) * 16) = m;
 }
 
-template <int PRO>
-__global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
+// SM = the small-grid form (4^2 ... 16^2 layers: 16 ... 256 pixels per image, 512 ... 2048 channels;
+// on the exact-fp32 MFMA until round 4, at 1/16 of the matrix rate and 3-9 x their floor): a 128-pixel
+// tile spans several images, each with its OWN power of two (input rows scaled while they are staged,
+// accumulator rows un-scaled at the end); blockIdx.y is a split-K slice of the stages whose un-scaled
+// partial outputs go to k.ws for the deterministic finish kernel of the direct path (p2l_conv.hip);
+// the maxima come from the producer (P2LAmax) or from the 64 partials per image of the pass in front.
+template <int PRO, bool SM = false>
+__global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {   // (SM: per-item prologue operands, 130-160 VGPR)
   constexpr int KS = 32, VPP = KS / 4;
+  constexpr int A_ITERS = 128 * VPP / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + PWH_A_FLOATS;
+  float* scl = smem + PWH_LDS_BYTES / sizeof(float);     // SM: [TB] x {x scale, output un-scale}
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -217,44 +225,82 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
   const int tiles_per_image = k.tiles_x * k.tiles_y;
-  const int b0 = mt / tiles_per_image;                   // one image per tile (launcher)
-  const int tile_in_image = mt - b0 * tiles_per_image;
+  const int bt = mt / tiles_per_image;
+  const int b0 = SM ? (bt << k.tb_log) : bt;             // (!SM: one image per tile, launcher)
+  const int tile_in_image = mt - bt * tiles_per_image;
   const int ty = tile_in_image / k.tiles_x, tx = tile_in_image - ty * k.tiles_x;
   const int n0 = nt * 64;
   const int y0 = ty << k.th_log, x0 = tx << k.tw_log;
 
-  // ---- the image's power of two from the handed-over maxima (bound for a fused prologue) ----
-  float x_scale, out_scale;
+  // ---- the images' powers of two (bound max|s| max|x| + max|t| for a fused prologue on handed-over maxima) ----
+  float x_scale = 1.f, out_scale = 1.f;
   {
-    float a = 0.f, ms = 0.f, mt_ = 0.f;
-    for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b0 * k.amax_in_n + i]);
-    if (PRO != P2L_PRO_NONE) {
-      const float* ps = k.pro_s + (size_t)b0 * k.pro_bstride;
-      const float* pt = k.pro_t + (size_t)b0 * k.pro_bstride;
-      for (int c = tid; c < k.Cin; c += 256) { ms = fmaxf(ms, fabsf(ps[c])); mt_ = fmaxf(mt_, fabsf(pt[c])); }
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      a = fmaxf(a, __shfl_xor(a, o, 64));
-      if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
-    }
-    if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mt_; }
-    __syncthreads();
-    a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
-    ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
-    mt_ = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
-    __syncthreads();                                     // (the first stage is staged there next)
-    if (PRO != P2L_PRO_NONE) a = (ms * a + mt_) * 1.001f;
-    float inv_x, sw, inv_w;
-    h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
+    float sw, inv_w;
     h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
-    out_scale = inv_x * inv_w;
+    if (!SM) {
+      float a = 0.f, ms = 0.f, mt_ = 0.f;
+      for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b0 * k.amax_in_n + i]);
+      if (PRO != P2L_PRO_NONE) {
+        const float* ps = k.pro_s + (size_t)b0 * k.pro_bstride;
+        const float* pt = k.pro_t + (size_t)b0 * k.pro_bstride;
+        for (int c = tid; c < k.Cin; c += 256) { ms = fmaxf(ms, fabsf(ps[c])); mt_ = fmaxf(mt_, fabsf(pt[c])); }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
+      }
+      if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mt_; }
+      __syncthreads();
+      a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
+      ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
+      mt_ = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
+      __syncthreads();                                   // (the first stage is staged there next)
+      if (PRO != P2L_PRO_NONE) a = (ms * a + mt_) * 1.001f;
+      float inv_x;
+      h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
+      out_scale = inv_x * inv_w;
+    } else {
+      // one WAVE per image (images w, w + 4 of the tile): shuffles only, one barrier for the tile
+      const int TBn = 1 << k.tb_log;
+      for (int t = wave; t < TBn; t += 4) {
+        const int b = b0 + t;
+        float a = 0.f, ms = 0.f, mt_ = 0.f;
+        if (b < k.B) {
+          if (k.amax_in != nullptr) {
+            for (int i = lane; i < k.amax_in_n; i += 64) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+            if (PRO != P2L_PRO_NONE) {
+              const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
+              const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
+              for (int c = lane; c < (k.Cin >> 2); c += 64) {
+                const f32x4 s4 = ps[c], t4 = pt[c];
+                ms = fmaxf(fmaxf(ms, fmaxf(fabsf(s4.x), fabsf(s4.y))), fmaxf(fabsf(s4.z), fabsf(s4.w)));
+                mt_ = fmaxf(fmaxf(mt_, fmaxf(fabsf(t4.x), fabsf(t4.y))), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+              }
+            }
+          } else {
+            a = k.amax[b * 64 + lane];                   // (the prologue was applied by the pass)
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          a = fmaxf(a, __shfl_xor(a, o, 64));
+          if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
+        }
+        if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mt_) * 1.001f;
+        float xs, inv_x;
+        h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
+        if (lane == 0) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
+      }
+      __syncthreads();
+    }
   }
 
   // ---- A staging: 128 pixels x 8 float4 per stage = 4 items per thread ----------------------
-  constexpr int A_ITERS = 128 * VPP / 256;
   const int av = tid & (VPP - 1);
-  int a_goff[A_ITERS];
+  int a_goff[A_ITERS], a_soff[SM ? A_ITERS : 1];
+  float a_xs[SM ? A_ITERS : 1];
+  unsigned a_valid = 0;
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
     const int p = (tid + 256 * it) / VPP;
@@ -262,7 +308,18 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
     const int qx = Q & ((TW >> 1) - 1);
     const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
     const int iy = y0 + 2 * qy + (s >> 1), ix = x0 + 2 * qx + (s & 1);
-    a_goff[it] = ((b0 * k.H + iy) * k.W + ix) * k.x_ld + av * 4;
+    if (SM) {
+      const int tb = Q >> (k.tw_log + k.th_log - 2);
+      const int b = b0 + tb;
+      a_goff[it] = 0; a_soff[it] = 0; a_xs[it] = scl[2 * tb];
+      if (b < k.B) {                                     // (the grid is a whole number of tiles per image)
+        a_goff[it] = ((b * k.H + iy) * k.W + ix) * k.x_ld + av * 4;
+        a_soff[it] = b * k.pro_bstride + av * 4;
+        a_valid |= 1u << it;
+      }
+    } else {
+      a_goff[it] = ((b0 * k.H + iy) * k.W + ix) * k.x_ld + av * 4;
+    }
   }
   const int s_off = b0 * k.pro_bstride + av * 4;
   // ---- B staging: [sub][64 rows][4 x 16 B] = 512 items per stage, 2 per thread; the packed image
@@ -277,14 +334,19 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
   }
   const int b_stage = PWH_SUB * (k.Cout >> 5) * 32 * 16;   // floats per stage of the image
 
-  f32x4 xr[A_ITERS], wr[B_ITERS], sr, tr;
+  f32x4 xr[A_ITERS], wr[B_ITERS], sr[SM ? A_ITERS : 1], tr[SM ? A_ITERS : 1];
   auto load_regs = [&](int st) {
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it)
+    for (int it = 0; it < A_ITERS; ++it) {
       xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + st * KS);
-    if (PRO != P2L_PRO_NONE) {
-      sr = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + st * KS);
-      tr = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + st * KS);
+      if (SM && PRO != P2L_PRO_NONE) {
+        sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + a_soff[it] + st * KS);
+        tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + a_soff[it] + st * KS);
+      }
+    }
+    if (!SM && PRO != P2L_PRO_NONE) {
+      sr[0] = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + st * KS);
+      tr[0] = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + st * KS);
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it)
@@ -295,14 +357,15 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
     for (int it = 0; it < A_ITERS; ++it) {
       f32x4 v = xr[it];
       if (PRO != P2L_PRO_NONE) {
-        v = v * sr + tr;
+        v = v * sr[SM ? it : 0] + tr[SM ? it : 0];
         if (PRO == P2L_PRO_AFFINE_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
           v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
       }
+      if (SM && !((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       const int p = (tid + 256 * it) / VPP;
-      pw_store_split_h2(As + (av >> 2) * (128 * 16), p, av & 3, v * x_scale);
+      pw_store_split_h2(As + (av >> 2) * (128 * 16), p, av & 3, v * (SM ? a_xs[it] : x_scale));
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it)
@@ -318,12 +381,15 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
   const int a_row = wave * 32 + l31;
   const int a_h = h2_chunk(lhi, a_row) * 4, a_m = h2_chunk(2 + lhi, a_row) * 4;
   const int b_h = h2_chunk(lhi, l31) * 4, b_m = h2_chunk(2 + lhi, l31) * 4;
+  // SM: blockIdx.y = split-K slice of the stages (k.chunks_per_split stages each)
   const int nstages = k.Cin / KS;
-  load_regs(0);
+  const int st_lo = SM ? (int)blockIdx.y * k.chunks_per_split : 0;
+  const int st_hi = SM ? min(nstages, st_lo + k.chunks_per_split) : nstages;
+  load_regs(st_lo);
   write_lds();
   __syncthreads();
-  for (int st = 0; st < nstages; ++st) {
-    const bool more = st + 1 < nstages;
+  for (int st = st_lo; st < st_hi; ++st) {
+    const bool more = st + 1 < st_hi;
     if (more) load_regs(st + 1);
 #pragma unroll
     for (int sub = 0; sub < PWH_SUB; ++sub) {
@@ -346,10 +412,46 @@ __global__ __launch_bounds__(256, 4) void pw_h2_kernel(const ConvK k) {
     if (more) write_lds();
     __syncthreads();
   }
+  if (!SM) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] *= out_scale;  // (exact: a power of two)
+      for (int r = 0; r < 16; ++r) acc[j][r] *= out_scale;  // (exact: a power of two)
+    epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
+    return;
+  }
+  // small-grid form: registers 4g .. 4g+3 of a lane are quad Q = wave*8 + 2g + lhi (one image each)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int Q = wave * 8 + 2 * g + lhi;
+    const float os = scl[2 * (Q >> (k.tw_log + k.th_log - 2)) + 1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[j][4 * g + s] *= os;
+  }
+  if (k.splitk > 1) {
+    const size_t mtot = (size_t)k.B * k.H * k.W;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int Q = wave * 8 + 2 * g + lhi;
+      const int qx = Q & ((TW >> 1) - 1);
+      const int qy = (Q >> (k.tw_log - 1)) & ((TH >> 1) - 1);
+      const int b = b0 + (Q >> (k.tw_log + k.th_log - 2));
+      if (b >= k.B) continue;
+      const size_t pix0 = ((size_t)b * k.H + y0 + 2 * qy) * k.W + x0 + 2 * qx;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* wp = k.ws + ((size_t)blockIdx.y * mtot + pix0) * k.Cout + n0 + j * 32 + l31;
+        wp[0] = acc[j][g * 4 + 0];
+        wp[k.Cout] = acc[j][g * 4 + 1];
+        wp[(size_t)k.W * k.Cout] = acc[j][g * 4 + 2];
+        wp[(size_t)(k.W + 1) * k.Cout] = acc[j][g * 4 + 3];
+      }
+    }
+    return;
+  }
+  __syncthreads();                                       // (scl read by every wave before the dumps start)
   epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
 }
 
@@ -420,20 +522,29 @@ int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL((pw_bf3_kernel<PRO, 32>), grid, block, PwCfg<32>::LDS_BYTES, st, k);  \
   } while (0)
-#define P2L_PWH(PRO)                                                                         \
+#define P2L_PWH(PRO, SMV)                                                                    \
   do {                                                                                       \
     static std::atomic<bool> attr_set{false};                                                \
     if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)pw_h2_kernel<PRO>,                              \
+      (void)hipFuncSetAttribute((const void*)pw_h2_kernel<PRO, SMV>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
-    hipLaunchKernelGGL(pw_h2_kernel<PRO>, grid, block, PWH_LDS_BYTES, st, k);                \
+    hipLaunchKernelGGL((pw_h2_kernel<PRO, SMV>), gridh, block, PWH_LDS_BYTES + 128, st, k);  \
   } while (0)
-  if (k.amax_in != nullptr) {                          // fp16 x 2 (conv_launch_impl decides)
-    if (pro == P2L_PRO_NONE) P2L_PWH(P2L_PRO_NONE);
-    else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWH(P2L_PRO_AFFINE_RELU);
-    else P2L_PWH(P2L_PRO_AFFINE);
+  if (k.amax_in != nullptr || k.amax != nullptr) {     // fp16 x 2 (conv_launch_impl decides)
+    // k.amax set: the small-grid form (multi-image tiles, split-K slices in blockIdx.y)
+    const bool sm = k.amax != nullptr;
+    dim3 gridh(k.n_mtiles * k.n_ntiles, sm ? k.splitk : 1);
+    if (sm) {
+      if (pro == P2L_PRO_NONE) P2L_PWH(P2L_PRO_NONE, true);
+      else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWH(P2L_PRO_AFFINE_RELU, true);
+      else P2L_PWH(P2L_PRO_AFFINE, true);
+      return p2l_check_launch();
+    }
+    if (pro == P2L_PRO_NONE) P2L_PWH(P2L_PRO_NONE, false);
+    else if (pro == P2L_PRO_AFFINE_RELU) P2L_PWH(P2L_PRO_AFFINE_RELU, false);
+    else P2L_PWH(P2L_PRO_AFFINE, false);
     return p2l_check_launch();
   }
 #undef P2L_PWH

@@ -89,12 +89,25 @@ def test_forward_against_fp64(runs):
 
 
 @pytest.mark.parametrize('which', ['dz', 'dc'])
-def test_latent_gradients_within_3x_of_the_oracles_own_fp32_noise(runs, which):
+def test_latent_gradients_at_the_fp32_oracles_level(runs, which):
+    """with the native decisions replayed: arithmetic alone, per candidate, at the fp32 CPU oracle's own
+    distance from fp64 (the rule of tests/test_fixed_mask_grad_gpu.py); free-running -- where one flipped
+    ReLU of a 16^2 layer is a step of several 1e-3 in every upstream gradient, whichever arithmetic takes
+    it -- only coarsely (round 3 asserted 3x the fp32 oracle's free-running distance there and flipped
+    between pass and fail with every kernel that changed a rounding)."""
     hip, o32, o64, _ = runs
-    floor = rel(o32[which], o64[which])
-    got = rel(hip[which], o64[which])
-    print('%s: native vs fp64 %.3g, oracle fp32 vs fp64 %.3g' % (which, got, floor))
-    assert got < FLOOR_X * floor + SLACK, (which, got, floor)
+    r32, r64 = o32['replayed'], o64['replayed']
+
+    def rows(a, b):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return (a - b).norm(dim=1) / b.norm(dim=1)
+    got, floor = rows(hip[which], r64[which]), rows(r32[which], r64[which])
+    free = rows(hip[which], o64[which])
+    print('%s per candidate: native vs fp64 (decisions replayed) %s, fp32 oracle %s; free-running %s'
+          % (which, ['%.2e' % v for v in got.tolist()], ['%.2e' % v for v in floor.tolist()],
+             ['%.2e' % v for v in free.tolist()]))
+    assert (got <= 1.5 * floor + 2e-5).all(), (which, got, floor)
+    assert free.max().item() < 1e-2, (which, free)
 
 
 def test_per_layer_cbn_gradients(runs):

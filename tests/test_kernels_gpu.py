@@ -1199,3 +1199,93 @@ def test_direct_kernel_fp16x2_subpixel_and_maxima(dev, O):
     z0, _ = O.conv(ys, wp2, 3, Hs, Hs, Co, Co, 9, wfmt=2)
     z1, _ = O.conv(ys, wp2, 3, Hs, Hs, Co, Co, 9, wfmt=2, amax_in=am)
     assert torch.equal(z0, z1)
+
+
+PW_SMALL_CASES = [
+    dict(B=3, H=8, Cin=512, Cout=128, pro='affine_relu', bias=True),                 # two images per tile
+    dict(B=5, H=4, Cin=256, Cout=64, bias=True, res='same', alpha=0.5),              # eight images per tile
+    dict(B=2, H=16, Cin=128, Cout=256, act='relu', pro='affine'),                    # one image per tile (2 tiles)
+    dict(B=3, H=8, Cin=1024, Cout=64, splitk=4),
+]
+
+
+@pytest.mark.parametrize('case', PW_SMALL_CASES, ids=lambda c: '-'.join('%s%s' % kv for kv in c.items()))
+def test_pointwise_small_grid_fp16x2(dev, O, case):
+    """pw_h2_kernel<.., SM> (csrc/p2l_pw.hip): the 1x1 convs of the 4^2 ... 16^2 layers in the fp16 x 2
+    arithmetic -- tiles that span several images, each on its own power of two, split-K slices summed by
+    the deterministic finish kernel -- against torch in fp64 and against the exact-fp32 MFMA kernel
+    (P2L_FORM_NO_PW), with and without handed-over maxima; a candidate's bits do not depend on the batch."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(31)
+    B, H, Cin, Cout = case['B'], case['H'], case['Cin'], case['Cout']
+    x = torch.randn(B, Cin, H, H, generator=g)
+    x[0] *= 1e-5
+    x[B - 1] *= 2e3
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    kw = dict(wfmt=3)
+    a = x.double()
+    if case.get('pro'):
+        s = 0.5 + torch.rand(B, Cin, generator=g)
+        t = 0.3 * torch.randn(B, Cin, generator=g) * x.abs().amax(dim=(1, 2, 3)).view(B, 1)
+        a = a * s.double().view(B, Cin, 1, 1) + t.double().view(B, Cin, 1, 1)
+        if case['pro'] == 'affine_relu':
+            a = F.relu(a)
+        kw.update(pro=N.PRO_AFFINE_RELU if case['pro'] == 'affine_relu' else N.PRO_AFFINE,
+                  pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin)
+    alpha = case.get('alpha', 1.0)
+    ref = alpha * F.conv2d(a, w.double())
+    if case.get('bias'):
+        bias = 0.1 * torch.randn(Cout, generator=g)
+        ref = ref + bias.double().view(1, Cout, 1, 1)
+        kw['bias'] = bias.to(dev)
+    if case.get('res'):
+        r = torch.randn(B, Cout, H, H, generator=g) * ref.abs().amax(dim=(1, 2, 3)).view(B, 1, 1, 1).float()
+        ref = ref + r.double()
+        kw['res'] = nhwc(r, dev)
+    if case.get('act') == 'relu':
+        ref = F.relu(ref)
+        kw['act'] = N.ACT_RELU
+    kw['alpha'] = alpha
+    if 'splitk' in case:
+        kw['splitk'] = case['splitk']
+    wp = O.pack_conv_weight(w.to(dev), 1, Cout, Cin, wfmt=3)
+    xs = nhwc(x, dev)
+
+    def products(fn):
+        lib = N.lib()
+        N.check(lib.p2l_prof_begin(64), 'p2l_prof_begin')
+        lib.p2l_prof_step(0, 1)
+        out = fn()
+        torch.cuda.synchronize()
+        arr = [(C.c_double * 2)() for _ in range(5)]
+        cnt = (C.c_int32 * 2)()
+        N.check(lib.p2l_prof_end4(arr[0], arr[1], cnt, arr[2], arr[3], arr[4]), 'p2l_prof_end4')
+        return out, arr[4][1] / arr[3][1]
+
+    O.DEFAULT_FORM = N.FORM_AUTO
+    (y, _), mm = products(lambda: O.conv(xs, wp, B, H, H, Cin, Cout, 1, **kw))
+    assert abs(mm - 3.0) < 1e-6, 'expected the fp16 x 2 small-grid kernel, got %g products' % mm
+    O.DEFAULT_FORM = N.FORM_NO_PW
+    (y32, _), mm32 = products(lambda: O.conv(xs, wp, B, H, H, Cin, Cout, 1, **kw))
+    assert abs(mm32 - 16.0) < 1e-6
+    O.DEFAULT_FORM = N.FORM_AUTO
+    am = x.abs().amax(dim=(1, 2, 3)).view(B, 1).contiguous().to(dev)      # maxima handed over
+    yh, _ = O.conv(xs, wp, B, H, H, Cin, Cout, 1, amax_in=am, **kw)
+    y, y32, yh = nchw(y).double(), nchw(y32).double(), nchw(yh).double()
+    for b in range(B):
+        sc = ref[b].abs().max().item()
+        assert (y[b] - ref[b]).abs().max().item() < 2e-5 * sc, (b, (y[b] - ref[b]).abs().max().item() / sc)
+        assert (yh[b] - ref[b]).abs().max().item() < 2e-5 * sc
+        assert (y32[b] - y[b]).abs().max().item() < 2e-5 * sc
+    # batch composition (same split-K request)
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.wfmt, d.x_ld = B, H, H, Cin, Cout, 1, 3, Cin
+    d.n_store = d.y_ld = Cout
+    sk = kw.get('splitk', N.lib().p2l_conv_suggest_splitk(C.byref(d)))
+    kw1 = dict(kw, splitk=sk)
+    for key in ('pro_s', 'pro_t', 'res'):
+        if key in kw1:
+            kw1[key] = kw1[key][1:2].contiguous()
+    ya, _ = O.conv(xs, wp, B, H, H, Cin, Cout, 1, **dict(kw, splitk=sk))
+    y1, _ = O.conv(xs[1:2].contiguous(), wp, 1, H, H, Cin, Cout, 1, **kw1)
+    assert torch.equal(y1[0], ya[1]), 'result depends on the batch composition'
