@@ -87,55 +87,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   const int c_begin = z * k.chunks_per_split;
   const int c_end = min(k.nchunks, c_begin + k.chunks_per_split);
 
-  // ---- the images' powers of two ------------------------------------------------------------
-  // max |x| of image b: the partial maxima the producer of the tensor left (P2LAmax; a fused
-  // prologue x*s+t is then bounded by max|s| max|x| + max|t|), or the 64 partials of the pass in
-  // front of this launch (the prologue applied there)
-  {
-    float sw, inv_w;
-    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
-    // one image per tile: the whole block reduces; several: one WAVE per image (shuffles only)
-    const int step = (TB == 1) ? 256 : 64, me = (TB == 1) ? tid : lane;
-    for (int t = (TB == 1) ? 0 : wave; t < TB; t += 4) {
-      const int b = b0 + t;
-      float a = 0.f, ms = 0.f, mtt = 0.f;
-      if (b < k.B) {
-        if (k.amax_in != nullptr) {
-          for (int i = me; i < k.amax_in_n; i += step) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
-          if (PRO != P2L_PRO_NONE) {
-            const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
-            const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
-            for (int c = me; c < (k.Cin >> 2); c += step) {
-              const f32x4 s4 = ps[c], t4 = pt[c];
-              ms = fmaxf(fmaxf(ms, fmaxf(fabsf(s4.x), fabsf(s4.y))), fmaxf(fabsf(s4.z), fabsf(s4.w)));
-              mtt = fmaxf(fmaxf(mtt, fmaxf(fabsf(t4.x), fabsf(t4.y))), fmaxf(fabsf(t4.z), fabsf(t4.w)));
-            }
-          }
-        } else if (me < 64) {
-          a = k.amax[b * 64 + me];
-        }
-      }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        a = fmaxf(a, __shfl_xor(a, o, 64));
-        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mtt = fmaxf(mtt, __shfl_xor(mtt, o, 64)); }
-      }
-      if (TB == 1) {
-        if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mtt; }
-        __syncthreads();
-        a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
-        ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
-        mtt = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
-      }
-      if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mtt) * 1.001f;
-      float xs, inv_x;
-      h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
-      if ((TB == 1) ? (tid == 0) : (lane == 0)) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
-      if (TB == 1) break;
-    }
-    __syncthreads();                                   // (scales visible; the scratch becomes the tile)
-  }
-
   // ---- per-thread staging descriptors (fixed across chunks) --------------
   // item j = tid + 256 it: pixel j >> 2, channel quarter tid & 3.  Loads are issued unconditionally
   // from a clamped (always valid) address and zeroed at LDS-write time.
@@ -143,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   int a_goff[A_ITERS];   // float offset of the source pixel's chunk-0 vector
   int a_soff[A_ITERS];   // float offset into pro_s / pro_t
   int a_row[A_ITERS];    // LDS row, -1 = no item
-  float a_xs[S_ITERS];   // the item's image scale
+  float a_xs[S_ITERS];   // the item's image scale (read once the scales exist, below)
+  int a_tb[S_ITERS];     // ... and which image of the tile the item belongs to
   unsigned a_valid = 0;  // bit it: source pixel exists (else zero padding)
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
@@ -151,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     a_goff[it] = 0;
     a_soff[it] = 0;
     a_row[it] = -1;
-    if (it < S_ITERS) a_xs[it] = scl[0];
+    if (it < S_ITERS) { a_xs[it] = 1.f; a_tb[it] = 0; }
     if (p < a_rows) {
       const int tb = p / (HH_ * HW_);
       const int rem = p - tb * (HH_ * HW_);
@@ -159,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
       a_row[it] = (tb * HH_ + hy) * HP + hx;
       const int b = b0 + tb;
-      if (!S_UNI) a_xs[it] = scl[2 * tb];
+      if (!S_UNI) a_tb[it] = tb;
       if (b < k.B && iy >= 0 && iy < k.iH && ix >= 0 && ix < k.iW) {
         int pix;
         if (sp_bwd)            // phase plane (0,0) of the high-res gradient buffer
@@ -286,6 +238,64 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     dma_b(c_begin, H0c{});
     dma_b(c_begin, H1c{});
     load_a(c_begin);
+  }
+  // (the scales are only needed when the first tile is WRITTEN: the first weight tile and patch are
+  //  in flight while the maxima are reduced)
+  // max |x| of image b: the partial maxima the producer of the tensor left (P2LAmax; a fused
+  // prologue x*s+t is then bounded by max|s| max|x| + max|t|), or the 64 partials of the pass in
+  // front of this launch (the prologue applied there)
+  {
+    float sw, inv_w;
+    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
+    // one image per tile: the whole block reduces; several: one WAVE per image (shuffles only)
+    const int step = (TB == 1) ? 256 : 64, me = (TB == 1) ? tid : lane;
+    for (int t = (TB == 1) ? 0 : wave; t < TB; t += 4) {
+      const int b = b0 + t;
+      float a = 0.f, ms = 0.f, mtt = 0.f;
+      if (b < k.B) {
+        if (k.amax_in != nullptr) {
+          for (int i = me; i < k.amax_in_n; i += step) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+          if (PRO != P2L_PRO_NONE) {
+            const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
+            const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
+            for (int c = me; c < (k.Cin >> 2); c += step) {
+              const f32x4 s4 = ps[c], t4 = pt[c];
+              ms = fmaxf(fmaxf(ms, fmaxf(fabsf(s4.x), fabsf(s4.y))), fmaxf(fabsf(s4.z), fabsf(s4.w)));
+              mtt = fmaxf(fmaxf(mtt, fmaxf(fabsf(t4.x), fabsf(t4.y))), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+            }
+          }
+        } else if (me < 64) {
+          a = k.amax[b * 64 + me];
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mtt = fmaxf(mtt, __shfl_xor(mtt, o, 64)); }
+      }
+      if (TB == 1) {
+        if (lane == 0) { smem[wave * 4] = a; smem[wave * 4 + 1] = ms; smem[wave * 4 + 2] = mtt; }
+        __syncthreads();
+        a = fmaxf(fmaxf(smem[0], smem[4]), fmaxf(smem[8], smem[12]));
+        ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
+        mtt = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
+      }
+      if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mtt) * 1.001f;
+      float xs, inv_x;
+      h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
+      if ((TB == 1) ? (tid == 0) : (lane == 0)) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
+      if (TB == 1) break;
+    }
+    __syncthreads();                                   // (scales visible; the scratch becomes the tile)
+  }
+
+  if (S_UNI) {
+    a_xs[0] = scl[0];
+  } else {
+#pragma unroll
+    for (int it = 0; it < S_ITERS; ++it) a_xs[it] = scl[2 * a_tb[it]];
+  }
+  if (c_begin < c_end) {
     write_a();
     __builtin_amdgcn_sched_barrier(0);
     if (c_begin + 1 < c_end) load_a(c_begin + 1);

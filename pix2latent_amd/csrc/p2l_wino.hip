@@ -386,43 +386,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   const int c_lo = z * k.chunks_per_split;
   const int nchunks = min(k.chunks_per_split, k.nchunks - c_lo);
 
-  // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
-  float x_scale = 1.f, out_scale = 1.f;
-  if (H2) {
-    float a;
-    if (k.amax_in != nullptr) {
-      // maxima handed over by the launch that wrote x (P2LAmax): its per-block partials of this
-      // image; a fused prologue x*s+t (ReLU or not) is bounded by max|s| max|x| + max|t|
-      a = 0.f;
-      for (int i = tid; i < k.amax_in_n; i += W16_THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
-      float ms = 0.f, mt = 0.f;
-      if (PRO != P2L_PRO_NONE) {
-        const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
-        const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
-        for (int c = tid; c < k.Cin; c += W16_THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
-      }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        a = fmaxf(a, __shfl_xor(a, o, 64));
-        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt = fmaxf(mt, __shfl_xor(mt, o, 64)); }
-      }
-      if (lane == 0) { raw[wave * 4 + 0] = a; raw[wave * 4 + 1] = ms; raw[wave * 4 + 2] = mt; }
-      __syncthreads();
-      a = 0.f; ms = 0.f; mt = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
-      __syncthreads();                                   // (the patch is staged there next)
-      if (PRO != P2L_PRO_NONE) a = (ms * a + mt) * 1.001f;
-    } else {
-      a = k.amax[b * 64 + lane];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
-    }
-    float inv_x, sw, inv_w;
-    h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
-    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
-    out_scale = inv_x * inv_w;
-  }
+  float x_scale = 1.f, out_scale = 1.f;   // fp16 x 2: the image's power of two and its inverse (set below, H2)
 
   // ---- staging: 324 pixels x 4 channel quads over 512 threads ---------------------------
   constexpr int A_ITERS = 3;
@@ -756,6 +720,45 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   P2L_TR(0, 63);                                       // (lab) block phases: start | loop | epilogue | pass 1 | end
   load_raw(0);
   load_b(0, 0, 0);
+  // (round 4: the scale is only needed when the patch is WRITTEN, so the first patch and weight
+  //  requests are in flight while the partial maxima are reduced: ~1 k cycles of every block)
+  // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
+  if (H2) {
+    float a;
+    if (k.amax_in != nullptr) {
+      // maxima handed over by the launch that wrote x (P2LAmax): its per-block partials of this
+      // image; a fused prologue x*s+t (ReLU or not) is bounded by max|s| max|x| + max|t|
+      a = 0.f;
+      for (int i = tid; i < k.amax_in_n; i += W16_THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+      float ms = 0.f, mt = 0.f;
+      if (PRO != P2L_PRO_NONE) {
+        const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
+        const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
+        for (int c = tid; c < k.Cin; c += W16_THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a = fmaxf(a, __shfl_xor(a, o, 64));
+        if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt = fmaxf(mt, __shfl_xor(mt, o, 64)); }
+      }
+      if (lane == 0) { raw[wave * 4 + 0] = a; raw[wave * 4 + 1] = ms; raw[wave * 4 + 2] = mt; }
+      __syncthreads();
+      a = 0.f; ms = 0.f; mt = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
+      __syncthreads();                                   // (the patch is staged there next)
+      if (PRO != P2L_PRO_NONE) a = (ms * a + mt) * 1.001f;
+    } else {
+      a = k.amax[b * 64 + lane];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) a = fmaxf(a, __shfl_xor(a, o, 64));
+    }
+    float inv_x, sw, inv_w;
+    h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
+    h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
+    out_scale = inv_x * inv_w;
+  }
+
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) write_raw1(it);
   __syncthreads();
