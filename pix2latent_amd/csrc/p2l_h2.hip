@@ -339,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         // half 1 of THIS chunk (DMA'd at the end of the previous one, the youngest VMEM op) must
         // have landed in every wave, and every wave must be done reading half 0 before it is
         // refilled
-        P2L_WAIT(0, 0);
+        // (the activation loads of chunk c+1 were issued AFTER that DMA and stay in flight: with
+        //  three MFMAs per unit half a chunk is ~770 cycles, less than a global round trip)
+        if (more) P2L_WAIT(NA_LD, 0); else P2L_WAIT(0, 0);
         __builtin_amdgcn_s_barrier();
         if (more) dma_b(c + 1, H0c{});
         if (j == 0) lda(tap, af[tap & 1]);
@@ -364,12 +366,12 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       write_a();
       __builtin_amdgcn_sched_barrier(0);
       const bool more2 = (c + 2 < c_end);
+      dma_b(c + 1, H1c{});                // (BEFORE the activation loads: the mid-chunk wait for it
+      __builtin_amdgcn_sched_barrier(0);  //  then leaves those loads in flight)
       if (more2) load_a(c + 2);
       __builtin_amdgcn_sched_barrier(0);
-      dma_b(c + 1, H1c{});
-      __builtin_amdgcn_sched_barrier(0);
-      // A tile written (lgkmcnt 0) and half 0 of c+1 landed; the ops issued after it - the
-      // activation loads of c+2 (if any) and the half-1 DMAs - may still be in flight
+      // A tile written (lgkmcnt 0) and half 0 of c+1 landed; the ops issued after it - the half-1
+      // DMAs and the activation loads of c+2 (if any) - may still be in flight
       if (more2) P2L_WAIT(NA_LD + NH1_MIN, 0); else P2L_WAIT(NH1_MIN, 0);
     } else {
       P2L_WAIT(63, 0);

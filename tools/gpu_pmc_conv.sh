@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC view of the 3x3 kernels (direct bf16x3 and Winograd) on the bench layers:
+# PMC view of the 3x3 kernels (direct bf16x3 / fp16x2, Winograd 16x16 bf16x3 / fp16x2, sub-pixel fp16x2) on the bench layers:
 # rocprofv3 --pmc over tools/conv_probe.py, one line per dispatch
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -15,8 +15,9 @@ rows = list(csv.DictReader(open(f)))
 by = collections.OrderedDict()
 for r in rows:
     n = r['Kernel_Name']
-    if 'conv_mfma' not in n and 'wino' not in n: continue
-    key = (int(r['Dispatch_Id']), ('amax' if 'wino_amax' in n else 'wino16-f16x2' if ('wino16s' in n and 'true' in n) else 'wino16' if 'wino16s' in n else 'wino8' if 'wino_conv' in n else 'direct'), r['Grid_Size'])
+    if 'conv_mfma' not in n and 'wino' not in n and 'conv_h2' not in n: continue
+    if 'pack' in n or 'wmax' in n: continue
+    key = (int(r['Dispatch_Id']), ('amax' if 'wino_amax' in n else 'wino16-f16x2' if ('wino16s' in n and 'true' in n) else 'wino16-bf16x3' if 'wino16s' in n else 'wino8' if 'wino_conv' in n else 'subpix-f16x2' if 'conv_h2_kernel<4' in n else 'direct-f16x2' if 'conv_h2' in n else 'direct-bf16x3'), r['Grid_Size'])
     by.setdefault(key, {})[r['Counter_Name']] = float(r['Counter_Value'])
 print('disp kind grid  mfma_busy parked issue_stall issuing valu_share lds_busy lds_conf clk(GUI cycles)')
 for k, v in sorted(by.items()):
