@@ -32,7 +32,19 @@ using namespace p2lconv;
 
 namespace {
 
-__device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3); }
+// (A/B builds, tools/ab_build.sh p2l_h2 -DP2L_H2_ABL=n: timing ablations of the main loop -- results are
+//  wrong when set: 1 no split / LDS write of the activation tile, 2 no activation loads, 4 no weight DMA,
+//  8 no MFMAs, 16 no barriers; all after the first chunk)
+#ifndef P2L_H2_ABL
+#define P2L_H2_ABL 0
+#endif
+
+// position of logical 16-byte chunk c (0, 1 = h; 2, 3 = m) inside 64-byte LDS row `row`.  Bits 2-3 of the
+// row make the 16 rows of a ds_read_b128 lane group hit 16 different bank windows; bit 1 swaps the h / m
+// halves of rows 2, 3 (mod 4) so that the 16 lanes of a ds_write_b64 (4 consecutive rows x 4 channel
+// quarters of ONE piece) cover all 32 banks instead of 16 twice (PMC: 6.4 % of LDS cycles were conflicts,
+// all of them these writes)
+__device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1); }
 
 // s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
 #define P2L_WAIT(VM, LGKM) __builtin_amdgcn_s_waitcnt(((VM) & 15) | (7 << 4) | ((LGKM) << 8) | (((VM) >> 4) << 14))
@@ -342,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         // (the activation loads of chunk c+1 were issued AFTER that DMA and stay in flight: with
         //  three MFMAs per unit half a chunk is ~770 cycles, less than a global round trip)
         if (more) P2L_WAIT(NA_LD, 0); else P2L_WAIT(0, 0);
-        __builtin_amdgcn_s_barrier();
-        if (more) dma_b(c + 1, H0c{});
+        if (!(P2L_H2_ABL & 16)) __builtin_amdgcn_s_barrier();
+        if (more && !(P2L_H2_ABL & 4)) dma_b(c + 1, H0c{});
         if (j == 0) lda(tap, af[tap & 1]);
         ldb(u, bq[u & 1]);
       }
@@ -355,20 +367,22 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       __builtin_amdgcn_sched_barrier(0);
       const h16x8 (&a)[2] = af[tap & 1];
       const h16x8 (&b)[2] = bq[u & 1];
+      if (!(P2L_H2_ABL & 8)) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[j], 0, 0, 0);   // smallest terms first
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[j], 0, 0, 0);
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[j], 0, 0, 0);
+      } else { acc[j][0] += (float)a[0][0] * (float)b[0][0]; }
       __builtin_amdgcn_sched_barrier(0);
     }
     P2L_WAIT(63, 0);                      // my LDS reads are done
-    __builtin_amdgcn_s_barrier();         // everybody is done with half 1 and the A tile
+    if (!(P2L_H2_ABL & 16)) __builtin_amdgcn_s_barrier();         // everybody is done with half 1 and the A tile
     if (more) {
-      write_a();
+      if (!(P2L_H2_ABL & 1)) write_a();
       __builtin_amdgcn_sched_barrier(0);
       const bool more2 = (c + 2 < c_end);
-      dma_b(c + 1, H1c{});                // (BEFORE the activation loads: the mid-chunk wait for it
+      if (!(P2L_H2_ABL & 4)) dma_b(c + 1, H1c{});                // (BEFORE the activation loads: the mid-chunk wait for it
       __builtin_amdgcn_sched_barrier(0);  //  then leaves those loads in flight)
-      if (more2) load_a(c + 2);
+      if (more2 && !(P2L_H2_ABL & 2)) load_a(c + 2);
       __builtin_amdgcn_sched_barrier(0);
       // A tile written (lgkmcnt 0) and half 0 of c+1 landed; the ops issued after it - the half-1
       // DMAs and the activation loads of c+2 (if any) - may still be in flight
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     } else {
       P2L_WAIT(63, 0);
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(P2L_H2_ABL & 16)) __builtin_amdgcn_s_barrier();
   }
 
   // ---- un-scale: accumulator row r of a lane belongs to pixel wave*32 + (r&3) + 8(r>>2) + 4 lhi ----

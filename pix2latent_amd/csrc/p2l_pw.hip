@@ -193,13 +193,18 @@ constexpr int PWH_EPI_FLOATS = 4 * 32 * (64 + 4);         // the vector epilogue
 constexpr size_t PWH_LDS_BYTES =
     (size_t)(PWH_A_FLOATS + PWH_B_FLOATS > PWH_EPI_FLOATS ? PWH_A_FLOATS + PWH_B_FLOATS : PWH_EPI_FLOATS) * sizeof(float);
 __device__ __forceinline__ int h2_chunk(int c, int row) { return c ^ ((row >> 2) & 3); }
-__device__ __forceinline__ void pw_store_split_h2(float* As, int row, int q4, const f32x4 x) {
+// activation rows: the h / m halves of the ODD 16-channel sub-chunk are swapped on top of that (`sub`),
+// so that the 16 lanes of a staging ds_write_b64 -- 2 pixels x 2 sub-chunks x 4 quarters of one piece --
+// cover all 32 banks instead of 16 of them twice (a lane group of the fragment READS sees one sub-chunk:
+// a constant term there)
+__device__ __forceinline__ int h2_chunk_a(int c, int row, int sub) { return h2_chunk(c, row) ^ ((sub & 1) << 1); }
+__device__ __forceinline__ void pw_store_split_h2(float* As, int row, int q4, int sub, const f32x4 x) {
   const h16x4 h = __builtin_convertvector(x, h16x4);
   const f32x4 w = __builtin_convertvector(h, f32x4);
   const h16x4 m = __builtin_convertvector(x - w, h16x4);
   char* rb = reinterpret_cast<char*>(As) + row * 64 + (q4 & 1) * 8;
-  *reinterpret_cast<h16x4*>(rb + h2_chunk(q4 >> 1, row) * 16) = h;
-  *reinterpret_cast<h16x4*>(rb + h2_chunk(2 + (q4 >> 1), row) * 16) = m;
+  *reinterpret_cast<h16x4*>(rb + h2_chunk_a(q4 >> 1, row, sub) * 16) = h;
+  *reinterpret_cast<h16x4*>(rb + h2_chunk_a(2 + (q4 >> 1), row, sub) * 16) = m;
 }
 
 // SM = the small-grid form (4^2 ... 16^2 layers: 16 ... 256 pixels per image, 512 ... 2048 channels;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
       }
       if (SM && !((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
       const int p = (tid + 256 * it) / VPP;
-      pw_store_split_h2(As + (av >> 2) * (128 * 16), p, av & 3, v * (SM ? a_xs[it] : x_scale));
+      pw_store_split_h2(As + (av >> 2) * (128 * 16), p, av & 3, av >> 2, v * (SM ? a_xs[it] : x_scale));
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it)
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int a_row = wave * 32 + l31;
-  const int a_h = h2_chunk(lhi, a_row) * 4, a_m = h2_chunk(2 + lhi, a_row) * 4;
+  const int a_h = h2_chunk(lhi, a_row) * 4, a_m = h2_chunk(2 + lhi, a_row) * 4;     // (even sub-chunks; odd: swapped)
   const int b_h = h2_chunk(lhi, l31) * 4, b_m = h2_chunk(2 + lhi, l31) * 4;
   // SM: blockIdx.y = split-K slice of the stages (k.chunks_per_split stages each)
   const int nstages = k.Cin / KS;
@@ -394,8 +399,8 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
 #pragma unroll
     for (int sub = 0; sub < PWH_SUB; ++sub) {
       const float* ar = As + (sub * 128 + a_row) * 16;
-      const h16x8 ah = *reinterpret_cast<const h16x8*>(ar + a_h);
-      const h16x8 am = *reinterpret_cast<const h16x8*>(ar + a_m);
+      const h16x8 ah = *reinterpret_cast<const h16x8*>(ar + ((sub & 1) ? a_m : a_h));
+      const h16x8 am = *reinterpret_cast<const h16x8*>(ar + ((sub & 1) ? a_h : a_m));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float* br = Bs + (sub * 64 + j * 32 + l31) * 16;

@@ -1,6 +1,8 @@
 """LDS bank conflicts of the A-fragment reads of conv_h2_kernel (csrc/p2l_h2.hip) by patch-line pitch.
 
-Rows are 64 B = 4 x 16-byte chunks, physical chunk = logical ^ ((row >> 2) & 3).  A ds_read_b128 is
+Rows are 64 B = 4 x 16-byte chunks, physical chunk = logical ^ ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1)
+(the last term makes the ds_write_b64 of the staging conflict free; it is constant over a read lane group's
+rows with equal row & 3, so the read analysis is unchanged).  A ds_read_b128 is
 served in four lane groups of 16 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32,
 /opt/skills/guides/MI355X_MICROARCH.md, LDS); a group takes one LDS cycle when its 16 addresses hit
 16 different 16-byte bank windows.  The MFMA M index -> pixel map is the 2x2-quad order of the conv
@@ -32,7 +34,7 @@ def cycles(rows, chunk):
         windows = {}
         for l in g:
             r = rows[l]
-            w = ((r * 64 + ((chunk ^ ((r >> 2) & 3)) * 16)) // 16) % 16     # 16-byte window of 64 banks x 4 B
+            w = ((r * 64 + ((chunk ^ ((r >> 2) & 3) ^ (((r >> 1) & 1) << 1)) * 16)) // 16) % 16     # 16-byte window of 64 banks x 4 B
             windows.setdefault(w, set()).add(r)
         tot += max(len(v) for v in windows.values())
     return tot / len(GROUPS)
