@@ -10,7 +10,7 @@ import sys
 
 # every kernel a 3x3 launch of the bench step can be: direct (TAPS=9), sub-pixel (TAPS=4), Winograd
 # (8x16 and 16x16 blocks), three-channel image convs
-KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'wino_conv_kernel', 'wino16s_conv_kernel',
+KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'conv_h2_kernel', 'wino_conv_kernel', 'wino16s_conv_kernel',
            'conv_thinin_kernel', 'conv_thinout_kernel')
 
 
@@ -36,7 +36,7 @@ def per_launch(path, counter):
 nf, f = per_launch(sys.argv[1], 'FETCH_SIZE')
 nw, w = per_launch(sys.argv[2], 'WRITE_SIZE')
 out = {
-    'kernel': '3x3 conv launches: conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
+    'kernel': '3x3 conv launches: conv_h2_kernel<TAPS=9|4,...> / conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
               'wino16s_conv_kernel + conv_thinin/thinout_kernel; the bytes of wino_amax_kernel (max-|x| pass of '
               'the fp16 x 2 Winograd launches) and conv_splitk_finish* are included, per conv launch',
     'commit': sys.argv[4] if len(sys.argv) > 4 else None,
@@ -47,6 +47,8 @@ out = {
     'fetch_bytes_per_launch': round(f * 1024 * 2),
     'write_bytes_per_launch': round(w * 1024),
     'hbm_bytes_per_launch': round(f * 1024 * 2 + w * 1024),
+    'fetch_launches_note': 'FETCH and WRITE are reported separately so that their ratios to the algorithmic '
+                           'read / write bytes can be formed (bench.py roofline.traffic_*)',
     'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over '
               '`bench.py --steps 2 --warmup 1`; KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read '
               'under-count); WRITE_SIZE uncalibrated',
