@@ -259,7 +259,7 @@ def extra_configs(dev, n_steps=3):
             if m[0] > 0:
                 tf = f[0] / (m[0] * 1e-3) / 1e12
                 out[name]['dominant_kernel'] = {
-                    'family': '3x3 / sub-pixel convs (wino16s_conv_kernel + conv_mfma_kernel<4>)',
+                    'family': '3x3 / sub-pixel convs (wino16s_conv_kernel + conv_h2_kernel<9|4>)',
                     'time_share_of_step': round(4 * m[0] * 1e-3 / el, 3),
                     'achieved_tflops_algorithmic': round(tf, 1),
                     'frac_of_bf16x3_ceiling': round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 3),
@@ -438,7 +438,8 @@ def main():
     abytes = (C.c_double * 2)()
     xflops = (C.c_double * 2)()
     mflops = (C.c_double * 2)()
-    N.check(lib.p2l_prof_end4(flops, ms, cnt, abytes, xflops, mflops), 'p2l_prof_end4')
+    wbytes = (C.c_double * 2)()
+    N.check(lib.p2l_prof_end5(flops, ms, cnt, abytes, xflops, mflops, wbytes), 'p2l_prof_end5')
     last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()
@@ -469,7 +470,7 @@ def main():
         # PMC counters cannot be read from inside the timed process: `traffic` is the
         # committed result of the separate rocprofv3 --pmc passes over this same command
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_rw = None, None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
         for name in ('round4_traffic.json', 'round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
             tpath = os.path.join(prof_dir, name)
@@ -477,6 +478,14 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic = tj.get('hbm_bytes_per_launch')
+                if tj.get('fetch_bytes_per_launch') and cnt[0] > 0:
+                    a_wr = wbytes[0] / cnt[0]
+                    a_rd = abytes[0] / cnt[0] - a_wr
+                    traffic_rw = {'fetch_bytes_per_launch': tj['fetch_bytes_per_launch'],
+                                  'write_bytes_per_launch': tj['write_bytes_per_launch'],
+                                  'algo_read_bytes_per_launch': round(a_rd), 'algo_write_bytes_per_launch': round(a_wr),
+                                  'fetch_over_algorithmic': round(tj['fetch_bytes_per_launch'] / a_rd, 3) if a_rd > 0 else None,
+                                  'write_over_algorithmic': round(tj['write_bytes_per_launch'] / a_wr, 3) if a_wr > 0 else None}
                 traffic_src = {'file': 'profiles/' + name, 'commit': tj.get('commit'),
                                'box': tj.get('box'), 'command': tj.get('command'),
                                'note': 'separate rocprofv3 --pmc passes over this bench command '
@@ -495,9 +504,10 @@ def main():
             'vs_baseline': None,
             'dtype': ('f32 (fp32 tensors everywhere; convolutions >= 32x32 and the self-attention multiply on '
                       'the 16-bit MFMA pipe with fp32-grade operand splits and fp32 accumulate: the 16x16 '
-                      'Winograd 3x3 kernel and the 1x1 kernel on power-of-two scaled operands in 2 fp16 pieces, '
-                      '3 products; the other kernels on 3 bf16 pieces, 6 products; small layers, dense layers, reductions '
-                      'and elementwise work exact fp32)'
+                      'Winograd, direct and sub-pixel 3x3 kernels and the 1x1 kernels (4x4 layers included) on '
+                      'power-of-two scaled operands in 2 fp16 pieces, 3 products; the fused attention, the 3-channel '
+                      'image convs and the launches without handed-over maxima on 3 bf16 pieces, 6 products; dense '
+                      'layers, reductions and elementwise work exact fp32)'
                       if bf3 else 'f32'),
             'data': 'synthetic',
             'config': {
@@ -508,7 +518,7 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
-                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel; 1x1 kernel where the maxima are handed over) + bf16x3 (every other >= 32x32 kernel)' if bf3 else 'f32',
+                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel >= 128 channels; direct / sub-pixel kernel for 64-channel, up-sampling and small layers; 1x1 kernels) + bf16x3 (3-channel image convs, attention)' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
@@ -526,7 +536,7 @@ def main():
                            '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
                            'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product; per-image maxima handed '
                            'over by the launch that wrote the input, wino_amax_kernel where none did), '
-                           'conv_mfma_kernel<TAPS=9|4,BF3> (direct | sub-pixel) and '
+                           'conv_h2_kernel<TAPS=9|4> (direct | sub-pixel, the same fp16 x 2 arithmetic) and '
                            'conv_thinin/thinout_kernel (3-channel image convs) in the bf16 x 3 arithmetic (6 x '
                            'v_mfma_f32_32x32x16_bf16 per product on 3-way split fp32 operands)'
                            if bf3 else
@@ -561,6 +571,7 @@ def main():
                 'traffic': traffic,
                 'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                 'traffic_source': traffic_src,
+                'traffic_read_write': traffic_rw,
                 'algo_bytes_per_launch': round(abytes[0] / max(cnt[0], 1)),
                 'sampled_launches': int(cnt[0]),
                 'launches_per_step': round(cnt[0] * period / args.steps, 1),
@@ -580,7 +591,7 @@ def main():
                             'peak_tb_per_s': HBM_PEAK_TBS,
                             'measured_stream_tb_per_s': {'write': 4.5, 'read': 6.5, 'copy': 5.0},
                             'frac': round(abytes[1] / (ms[1] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if ms[1] > 0 else None,
-                            'per_layer_table': 'profiles/round3_conv1x1_roofline.txt'},
+                            'per_layer_table': 'profiles/round4_conv1x1_roofline.txt'},
             },
             'telemetry': telemetry.summary(),
         }

@@ -118,10 +118,18 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
  * the fields.  Consumer: `in` = the partial maxima of the tensor it reads as x ([B][in_n], the RAW
  * tensor: a fused prologue x*s+t is bounded by max|s| max|x| + max|t| inside the kernel); NULL =
  * the launch reduces max|x| itself.  The caller guarantees that nothing else wrote the tensor in
- * between.  All NULL / 0 = not used. */
+ * between.  All NULL / 0 = not used.
+ * The bound of a fused prologue is loose when large |s| and large |x| sit in different channels
+ * (trained networks: two orders of magnitude), and every factor of two of it is a bit of the
+ * fp16 x 2 operand's range.  A producer that is told the affine its reader will fuse (`next_s`,
+ * `next_t`: [B][next_bstride] per-channel vectors, bstride 0 = shared by the images) therefore
+ * records the maxima of |y*next_s + next_t| in `out` instead (never in `outp`); the reader is then
+ * given them with `in_applied` = 1 and takes max|x*s+t| from them as it stands. */
 typedef struct P2LAmax {
   float* out; float* outp;
   const float* in; int32_t in_n;
+  const float* next_s; const float* next_t; int32_t next_bstride;
+  int32_t in_applied;
 } P2LAmax;
 typedef struct P2LArb {
   const float* x; int32_t x_ld;              /* pre-activation input of the forward conv */
@@ -175,6 +183,10 @@ int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[
  * fraction of the time the matrix pipe is busy */
 int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
                   double exec_flops[2], double mfma_flops[2]);
+/* same, plus the WRITTEN share of `bytes` (outputs y / yp), so that the PMC read (FETCH_SIZE) and
+ * write (WRITE_SIZE) traffic can each be set against its own algorithmic count */
+int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                  double exec_flops[2], double mfma_flops[2], double write_bytes[2]);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
  * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;

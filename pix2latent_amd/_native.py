@@ -27,7 +27,9 @@ class P2LConv(C.Structure):
 
 
 class P2LAmax(C.Structure):
-    _fields_ = [('out', C.c_void_p), ('outp', C.c_void_p), ('in_', C.c_void_p), ('in_n', C.c_int32)]
+    _fields_ = [('out', C.c_void_p), ('outp', C.c_void_p), ('in_', C.c_void_p), ('in_n', C.c_int32),
+                ('next_s', C.c_void_p), ('next_t', C.c_void_p), ('next_bstride', C.c_int32),
+                ('in_applied', C.c_int32)]
 
 
 class P2LArb(C.Structure):
@@ -227,7 +229,7 @@ EXPORTS = [
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_affine_grid_sample_bwd', 'p2l_affine_grid_sample_bwd_ws_bytes', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_ws_lookup', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_end4', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_end4', 'p2l_prof_end5', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
     'p2l_sg2_pixelnorm_fwd', 'p2l_sg2_pixelnorm_bwd', 'p2l_sg2_bias_lrelu_fwd', 'p2l_sg2_lrelu_bwd',
     'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
     'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',

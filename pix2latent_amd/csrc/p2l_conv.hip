@@ -63,7 +63,8 @@ struct ConvProf {
   std::vector<double> flops;    // algorithmic (direct convolution on the real channels)
   std::vector<double> xflops;   // executed on the matrix pipe (padded channels, 4 phase-taps)
   std::vector<int> nprod;       // 16-bit MFMA products per fp32 product: 6 bf16x3 | 3 fp16x2 | 16 = fp32 MFMA
-  std::vector<double> bytes;
+  std::vector<double> bytes;    // algorithmic bytes: every operand once + the packed weights
+  std::vector<double> wbytes;   // ... of which written (y, yp)
   std::vector<int> kind;
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
   std::string dump_path;                    // p2l_prof_dump
@@ -1041,6 +1042,9 @@ static bool pw_any(const P2LConv* d) { return pw_shape(d) || thin_shape(d) >= 0;
 // ("bf16 x 3 instead of fp16 x 2") keeps the bf16 x 3 kernel.  The launch also needs the 256 B per
 // image of workspace p2l_conv_workspace_bytes asks for.
 static bool direct_h2(const P2LConv* d) {
+#ifdef P2L_AB_NO_DIRECT_H2      // A/B builds (tools/ab_build.sh): bisecting an arithmetic difference by kernel family
+  return false;
+#endif
   if (d->wfmt != P2L_WFMT_BF16X3W || d->taps != 9 || (d->form & P2L_FORM_WINO_BF3)) return false;
   if (d->ups == 1 || d->x_ld % 4 || d->Cin % 16 || d->Cout % 32) return false;
   return !wino_shape(d);
@@ -1050,6 +1054,9 @@ static bool direct_h2(const P2LConv* d) {
 // layers of P2L_WFMT_PW weights that the full-tile pointwise kernels do not take (multi-image tiles,
 // split-K slices).  Shape and format only.
 static bool pw_small_h2(const P2LConv* d) {
+#ifdef P2L_AB_NO_PWSMALL_H2
+  return false;
+#endif
   if (d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0 || pw_shape(d)) return false;
   if (d->form & (P2L_FORM_NO_PW | P2L_FORM_WINO_BF3)) return false;
   if (d->Cin % 32 || d->Cout % 64 || d->x_ld % 4) return false;
@@ -1275,12 +1282,18 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     const P2LAmax* am = ex ? &ex->amax : (arb ? &arb->amax : nullptr);
     // consumers: the fp16 x 2 Winograd launch (instead of its own max-|x| pass) and the pointwise
     // kernel (which takes the fp16 x 2 form only with handed-over maxima)
-    if (am && am->in && am->in_n > 0 && (use_h2 || (pw_shape(d) && !(d->form & P2L_FORM_WINO_BF3)))) {
+    // (maxima recorded with a prologue applied say nothing about the raw tensor: not usable without one)
+    if (am && am->in && am->in_n > 0 && !(am->in_applied && d->pro == P2L_PRO_NONE) &&
+        (use_h2 || (pw_shape(d) && !(d->form & P2L_FORM_WINO_BF3)))) {
       k.amax_in = am->in; k.amax_in_n = am->in_n;
+      k.amax_in_applied = am->in_applied ? 1 : 0;
     }
     int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
     if (thin_shape(d) >= 0 && ex && (ex->oscale || ex->noise)) nslots = 0;   // (generic kernel then)
     if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
+    if (nslots > 0 && am->out && am->next_s && am->next_t && !arb) {
+      k.amax_ps = am->next_s; k.amax_pt = am->next_t; k.amax_pbstride = am->next_bstride;
+    }
   }
   if (k.splitk > 1) {
     const size_t need = (use_h2 ? h2_bytes : 0) + (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
@@ -1325,6 +1338,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       if (mask) by += opx * d->n_store;
       if (arb) by += opx * d->n_store * (arb->skip ? 2.0 : 1.0);
       g_prof.bytes[prof_slot] = 4.0 * by;
+      g_prof.wbytes[prof_slot] = 4.0 * ((y ? opx * d->n_store : 0.0) + (yp ? opx / 4 * d->n_store : 0.0));
     }
     (void)hipEventRecord(g_prof.ev[2 * prof_slot], st);
   }
@@ -1680,6 +1694,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
   g_prof.xflops.assign(max_launches, 0.0);
   g_prof.nprod.assign(max_launches, 6);
   g_prof.bytes.assign(max_launches, 0.0);
+  g_prof.wbytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
   g_prof.shape.assign(max_launches, {});
   g_prof.n = 0;
@@ -1718,6 +1733,12 @@ extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], do
 
 extern "C" int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
                              double exec_flops[2], double mfma_flops[2]) {
+  return p2l_prof_end5(flops, ms, count, bytes, exec_flops, mfma_flops, nullptr);
+}
+
+extern "C" int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], double bytes[2],
+                             double exec_flops[2], double mfma_flops[2], double write_bytes[2]) {
+  if (write_bytes) write_bytes[0] = write_bytes[1] = 0.0;
   if (exec_flops) exec_flops[0] = exec_flops[1] = 0.0;
   if (mfma_flops) mfma_flops[0] = mfma_flops[1] = 0.0;
   std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -1737,6 +1758,7 @@ extern "C" int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], do
     if (exec_flops) exec_flops[k] += g_prof.xflops[i];
     if (mfma_flops) mfma_flops[k] += g_prof.xflops[i] * g_prof.nprod[i];
     if (bytes) bytes[k] += g_prof.bytes[i];
+    if (write_bytes) write_bytes[k] += g_prof.wbytes[i];
     ms[k] += t;
     count[k] += 1;
     if (dump) {

@@ -56,6 +56,10 @@ struct ConvK {
   // per block [B][amax_out_n]
   const float* amax_in; int amax_in_n;
   float* amax_out; float* amax_outp; int amax_out_n;
+  // the affine the reader of y will fuse (P2LAmax.next_s / next_t): amax_out then holds the maxima of
+  // |y*s + t|; amax_in_applied: amax_in was recorded that way with THIS launch's prologue
+  const float* amax_ps; const float* amax_pt; int amax_pbstride;
+  int amax_in_applied;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -196,7 +200,8 @@ __device__ __forceinline__ void epilogue_quad(const ConvK& k, const float a[4], 
     t = apply_act(t, k.act);
     if (k.mask) t = (k.mask[(size_t)(pix * (unsigned)k.mask_ld + (unsigned)n)] > 0.f) ? t : 0.f;
     if (k.y) k.y[(size_t)(pix * (unsigned)k.y_ld + (unsigned)n)] = t;
-    if (amax) *amax = fmaxf(*amax, fabsf(t));
+    if (amax) *amax = fmaxf(*amax, fabsf(k.amax_ps ? t * k.amax_ps[(size_t)b * k.amax_pbstride + n] +
+                                                     k.amax_pt[(size_t)b * k.amax_pbstride + n] : t));
     v[s] = t;
   }
   if (k.pool) {
@@ -253,6 +258,8 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
     if (k.bias) bias4 = ld4(k.bias, (unsigned)n);
     f32x4 osc = {1.f, 1.f, 1.f, 1.f};
     if (k.oscale) osc = ld4(k.oscale, (unsigned)(b * k.oscale_bstride + n));
+    f32x4 ns4 = {1.f, 1.f, 1.f, 1.f}, nt4 = {0, 0, 0, 0};     // the reader's prologue (maxima only)
+    if (k.amax_ps) { ns4 = ld4(k.amax_ps, (unsigned)(b * k.amax_pbstride + n)); nt4 = ld4(k.amax_pt, (unsigned)(b * k.amax_pbstride + n)); }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (!ok[s]) continue;
@@ -267,7 +274,7 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
         t.z = m.z > 0.f ? t.z : 0.f; t.w = m.w > 0.f ? t.w : 0.f;
       }
       if (k.y) st4(k.y, pix * (unsigned)k.y_ld + (unsigned)n, t);
-      if (k.amax_out) S.amax = absmax4(S.amax, t);
+      if (k.amax_out) S.amax = absmax4(S.amax, k.amax_ps ? t * ns4 + nt4 : t);
       v[s] = t;
     }
     if (k.pool) {

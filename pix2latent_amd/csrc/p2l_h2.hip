@@ -34,7 +34,7 @@ namespace {
 
 // (A/B builds, tools/ab_build.sh p2l_h2 -DP2L_H2_ABL=n: timing ablations of the main loop -- results are
 //  wrong when set: 1 no split / LDS write of the activation tile, 2 no activation loads, 4 no weight DMA,
-//  8 no MFMAs, 16 no barriers; all after the first chunk)
+//  8 no MFMAs, 16 no barriers; all after the first chunk; 32 no epilogue)
 #ifndef P2L_H2_ABL
 #define P2L_H2_ABL 0
 #endif
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       if (b < k.B) {
         if (k.amax_in != nullptr) {
           for (int i = me; i < k.amax_in_n; i += step) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
-          if (PRO != P2L_PRO_NONE) {
+          if (PRO != P2L_PRO_NONE && !k.amax_in_applied) {   // (applied: the maxima ARE those of x*s+t)
             const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
             const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
             for (int c = me; c < (k.Cin >> 2); c += step) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
         mtt = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
       }
-      if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mtt) * 1.001f;
+      if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (k.amax_in_applied ? a : ms * a + mtt) * 1.001f;
       float xs, inv_x;
       h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
       if ((TB == 1) ? (tid == 0) : (lane == 0)) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     }
   } else {
     __syncthreads();                      // (scl read above by every wave before the dumps start)
+    if (!(P2L_H2_ABL & 32) || acc[0][0] == 12345.678f)
     epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image,
                      sp_fwd ? 1 : 0, ph_y, ph_x);
   }

@@ -62,6 +62,9 @@ struct ConvCall {
   const float* ps = nullptr; const float* pt = nullptr; const float* res = nullptr;
   const float* mask = nullptr; float* y = nullptr; float* yp = nullptr;
   bool want_amax = false;   // the next reader of y / yp is a 3x3 conv: leave its maxima (P2LAmax)
+  // ... and the affine that reader fuses in front of its ReLU, when the plan knows it: the maxima of y
+  // are then recorded as max|y*s + t| (P2LAmax.next_s) and the reader needs no bound
+  const float* next_ps = nullptr; const float* next_pt = nullptr; int next_bstride = 0;
 };
 // weight format of the 3x3 convs of the model whose plan is running on this thread
 // (set at every extern "C" entry from the model struct's wfmt)
@@ -94,7 +97,8 @@ size_t conv_ws_floats(ConvCall& c) {
 struct AmaxReg {
   static constexpr int NSETS = 6, NENT = 8;
   float* ring = nullptr; size_t set_floats = 0; int next = 0;
-  struct Ent { const float* t = nullptr; int B = 0, H = 0, W = 0, C = 0; const float* slots = nullptr; int n = 0, set = -1; };
+  struct Ent { const float* t = nullptr; int B = 0, H = 0, W = 0, C = 0; const float* slots = nullptr; int n = 0, set = -1;
+               const float* ps = nullptr; int pbs = 0; };   // ps: recorded as max|t*ps + pt| (the reader's prologue)
   Ent e[NENT];
   float* take(int* set) {
     *set = next % NSETS; ++next;
@@ -102,15 +106,25 @@ struct AmaxReg {
     return ring + (size_t)*set * set_floats;
   }
   void drop(const float* t) { if (t) for (Ent& x : e) if (x.t == t) x = Ent(); }
-  void put(const float* t, int B, int H, int W, int C, const float* slots, int n, int set) {
+  void put(const float* t, int B, int H, int W, int C, const float* slots, int n, int set,
+           const float* ps = nullptr, int pbs = 0) {
     drop(t);
     Ent* f = &e[0];
     for (Ent& x : e) if (!x.t) { f = &x; break; }
     f->t = t; f->B = B; f->H = H; f->W = W; f->C = C; f->slots = slots; f->n = n; f->set = set;
+    f->ps = ps; f->pbs = pbs;
   }
-  bool get(const float* t, int B, int H, int W, int C, const float** slots, int32_t* n) const {
+  // ps / pbs = the prologue vector the READER fuses (NULL: none).  Maxima recorded with an affine
+  // applied serve that reader only (*applied = 1); raw maxima serve every reader (bound in the kernel).
+  bool get(const float* t, int B, int H, int W, int C, const float** slots, int32_t* n,
+           const float* ps = nullptr, int pbs = 0, int32_t* applied = nullptr) const {
     for (const Ent& x : e)
-      if (x.t == t && t && x.B == B && x.H == H && x.W == W && x.C == C) { *slots = x.slots; *n = x.n; return true; }
+      if (x.t == t && t && x.B == B && x.H == H && x.W == W && x.C == C) {
+        if (x.ps && (x.ps != ps || x.pbs != pbs || !applied)) return false;
+        *slots = x.slots; *n = x.n;
+        if (applied) *applied = x.ps ? 1 : 0;
+        return true;
+      }
     return false;
   }
 };
@@ -170,6 +184,20 @@ extern "C" int p2l_selftest_amaxreg(void) {
   live = 0;
   for (const auto& e : R.e) live += e.t != nullptr;
   if (live > AmaxReg::NSETS) return 9;                                            // never more live entries than sets
+  // maxima recorded with the reader's affine applied (P2LAmax.next_s) serve that reader only
+  float s1v[1], s2v[1];
+  int32_t applied = -1;
+  float* s4 = R.take(&set);
+  R.put(t1, 2, 8, 8, 64, s4, 3, set, s1v, 64);
+  if (!R.get(t1, 2, 8, 8, 64, &slots, &n, s1v, 64, &applied) || applied != 1 || slots != s4) return 10;
+  if (R.get(t1, 2, 8, 8, 64, &slots, &n, s2v, 64, &applied)) return 11;            // another prologue
+  if (R.get(t1, 2, 8, 8, 64, &slots, &n, s1v, 0, &applied)) return 12;             // another image stride
+  if (R.get(t1, 2, 8, 8, 64, &slots, &n, nullptr, 0, &applied)) return 13;         // a reader without prologue
+  if (R.get(t1, 2, 8, 8, 64, &slots, &n)) return 14;                               // a reader that cannot say
+  float* s5 = R.take(&set);
+  R.put(t1, 2, 8, 8, 64, s5, 3, set);                                              // raw maxima: every reader
+  applied = -1;
+  if (!R.get(t1, 2, 8, 8, 64, &slots, &n, s2v, 64, &applied) || applied != 0) return 15;
   return 0;
 }
 namespace {
@@ -183,22 +211,24 @@ int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
   if (R) {
     // (the input of a sub-pixel forward launch is the LOW-resolution tensor, that of its
     //  input-gradient form the high-resolution one)
+    const float* rps = c.d.pro != P2L_PRO_NONE ? c.ps : nullptr;
     if ((c.d.ups == 0 || c.d.ups == 3) && c.d.x_ld == c.d.Cin)
-      R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n);
+      R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied);
     else if (c.d.ups == 2 && !c.d.ext && c.d.x_ld == c.d.Cin)
-      R->get(c.x, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cin, &ex.amax.in, &ex.amax.in_n);
+      R->get(c.x, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied);
     R->drop(c.y); R->drop(c.yp);                       // this launch overwrites them
     ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
     if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.n_store == c.d.Cout) {
       if (c.y && c.d.y_ld == c.d.Cout) so = R->take(&set_o);
       if (c.yp && c.d.yp_ld == c.d.Cout) sop = R->take(&set_p);
       ex.amax.out = so; ex.amax.outp = sop;
+      if (so && c.next_ps && c.next_pt) { ex.amax.next_s = c.next_ps; ex.amax.next_t = c.next_pt; ex.amax.next_bstride = c.next_bstride; }
     }
   }
   const int rc = p2l_conv_fwd_ex(&c.d, &ex, c.x, c.w, c.bias, c.ps, c.pt, c.res, c.mask, c.y, c.yp, skws,
                                  skws_floats * sizeof(float), st);
   if (rc == P2L_OK && R) {
-    if (so) R->put(c.y, c.d.B, c.d.H, c.d.W, c.d.Cout, so, ns, set_o);
+    if (so) R->put(c.y, c.d.B, c.d.H, c.d.W, c.d.Cout, so, ns, set_o, ex.amax.next_s, ex.amax.next_bstride);
     if (sop) R->put(c.yp, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cout, sop, ns, set_p);
   }
   return rc;
@@ -558,7 +588,8 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
       ConvCall oc = mk_conv(B, H, H, C / 2, C, 1);
       oc.x = W + L.att_ag; oc.w = m->att_w[3]; oc.y = W + L.att_y;
       oc.d.alpha = m->gamma; oc.res = x; oc.d.res_ld = C;
-      oc.want_amax = true;
+      oc.want_amax = true;                             // (read by this block's conv_0 through cbn_0)
+      oc.next_ps = W + L.s + m->blocks[i].cbn_off[0]; oc.next_pt = W + L.t + m->blocks[i].cbn_off[0]; oc.next_bstride = CT;
       RET_IF(run_conv(oc, skws, L.skws_floats, st));
       x = W + L.att_y;
     }
@@ -572,6 +603,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c0.d.pro = P2L_PRO_AFFINE_RELU; c0.d.pro_bstride = CT;
     c0.ps = W + L.s + g.cbn_off[0]; c0.pt = W + L.t + g.cbn_off[0];
     c0.want_amax = true;                               // (conv_1: Winograd / sub-pixel / direct, all fp16 x 2)
+    c0.next_ps = W + L.s + g.cbn_off[1]; c0.next_pt = W + L.t + g.cbn_off[1]; c0.next_bstride = CT;
     RET_IF(run_conv(c0, skws, L.skws_floats, st));
     // conv_1 : relu(cbn_1) -> (nearest x2) -> 3x3
     ConvCall c1 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
@@ -581,12 +613,14 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c1.d.pro = P2L_PRO_AFFINE_RELU; c1.d.pro_bstride = CT;
     c1.ps = W + L.s + g.cbn_off[1]; c1.pt = W + L.t + g.cbn_off[1];
     c1.want_amax = true;
+    c1.next_ps = W + L.s + g.cbn_off[2]; c1.next_pt = W + L.t + g.cbn_off[2]; c1.next_bstride = CT;
     RET_IF(run_conv(c1, skws, L.skws_floats, st));
     ConvCall c2 = mk_conv(B, o.Ho, o.Ho, mid, mid, 9);
     c2.x = W + o.h2; c2.w = g.w[2]; c2.bias = g.b[2]; c2.y = W + o.h3;
     c2.d.pro = P2L_PRO_AFFINE_RELU; c2.d.pro_bstride = CT;
     c2.ps = W + L.s + g.cbn_off[2]; c2.pt = W + L.t + g.cbn_off[2];
     c2.want_amax = true;                               // (conv_3 is a pointwise conv: fp16 x 2 with the maxima)
+    c2.next_ps = W + L.s + g.cbn_off[3]; c2.next_pt = W + L.t + g.cbn_off[3]; c2.next_bstride = CT;
     RET_IF(run_conv(c2, skws, L.skws_floats, st));
     // conv_3 : 1x1 mid -> cout, + shortcut (channel-truncated, nearest x2)
     ConvCall c3 = mk_conv(B, o.Ho, o.Ho, mid, g.cout, 1);
@@ -594,7 +628,11 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
     c3.d.pro = P2L_PRO_AFFINE_RELU; c3.d.pro_bstride = CT;
     c3.ps = W + L.s + g.cbn_off[3]; c3.pt = W + L.t + g.cbn_off[3];
     c3.res = x; c3.d.res_ld = g.cin; c3.d.res_ups = g.up;
-    c3.want_amax = true;                               // (the next block's conv_0)
+    c3.want_amax = true;                               // (the next block's conv_0; the attention convs read it raw)
+    if (i + 1 < m->n_blocks && i + 1 != m->attn_before) {
+      c3.next_ps = W + L.s + m->blocks[i + 1].cbn_off[0]; c3.next_pt = W + L.t + m->blocks[i + 1].cbn_off[0];
+      c3.next_bstride = CT;
+    }
     RET_IF(run_conv(c3, skws, L.skws_floats, st));
     x = W + o.y;
     Cx = g.cout;

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
     if (!SM) {
       float a = 0.f, ms = 0.f, mt_ = 0.f;
       for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b0 * k.amax_in_n + i]);
-      if (PRO != P2L_PRO_NONE) {
+      const bool bound = PRO != P2L_PRO_NONE && !k.amax_in_applied;   // (applied: the maxima ARE those of x*s+t)
+      if (bound) {
         const float* ps = k.pro_s + (size_t)b0 * k.pro_bstride;
         const float* pt = k.pro_t + (size_t)b0 * k.pro_bstride;
         for (int c = tid; c < k.Cin; c += 256) { ms = fmaxf(ms, fabsf(ps[c])); mt_ = fmaxf(mt_, fabsf(pt[c])); }
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
       ms = fmaxf(fmaxf(smem[1], smem[5]), fmaxf(smem[9], smem[13]));
       mt_ = fmaxf(fmaxf(smem[2], smem[6]), fmaxf(smem[10], smem[14]));
       __syncthreads();                                   // (the first stage is staged there next)
-      if (PRO != P2L_PRO_NONE) a = (ms * a + mt_) * 1.001f;
+      if (PRO != P2L_PRO_NONE) a = (bound ? ms * a + mt_ : a) * 1.001f;
       float inv_x;
       h2_scales(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, a)), x_scale, inv_x);
       out_scale = inv_x * inv_w;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
         if (b < k.B) {
           if (k.amax_in != nullptr) {
             for (int i = lane; i < k.amax_in_n; i += 64) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
-            if (PRO != P2L_PRO_NONE) {
+            if (PRO != P2L_PRO_NONE && !k.amax_in_applied) {
               const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
               const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
               for (int c = lane; c < (k.Cin >> 2); c += 64) {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
           a = fmaxf(a, __shfl_xor(a, o, 64));
           if (PRO != P2L_PRO_NONE) { ms = fmaxf(ms, __shfl_xor(ms, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
         }
-        if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (ms * a + mt_) * 1.001f;
+        if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (k.amax_in_applied ? a : ms * a + mt_) * 1.001f;
         float xs, inv_x;
         h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
         if (lane == 0) { scl[2 * t] = xs; scl[2 * t + 1] = inv_x * inv_w; }

@@ -731,7 +731,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       a = 0.f;
       for (int i = tid; i < k.amax_in_n; i += W16_THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
       float ms = 0.f, mt = 0.f;
-      if (PRO != P2L_PRO_NONE) {
+      const bool bound = PRO != P2L_PRO_NONE && !k.amax_in_applied;   // (applied: the maxima ARE those of x*s+t)
+      if (bound) {
         const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
         const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
         for (int c = tid; c < k.Cin; c += W16_THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
 #pragma unroll
       for (int w = 0; w < 8; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
       __syncthreads();                                   // (the patch is staged there next)
-      if (PRO != P2L_PRO_NONE) a = (ms * a + mt) * 1.001f;
+      if (PRO != P2L_PRO_NONE) a = (bound ? ms * a + mt : a) * 1.001f;
     } else {
       a = k.amax[b * 64 + lane];
 #pragma unroll

@@ -41,10 +41,12 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
          pro_t=None, pro_bstride=0, ups=False, alpha=1.0, act=N.ACT_NONE, pool=N.POOL_NONE,
          res=None, res_ups=False, mask=None, n_store=None, y_ld=None, want_y=True,
          splitk=None, x_ld=None, ext=0, oscale=None, noise=None, noise_w=0.0, wfmt=N.WFMT_F32,
-         form=None, amax_in=None, want_amax=False):
+         form=None, amax_in=None, want_amax=False, amax_next=None, amax_applied=False):
     """amax_in: [B, n] partial maxima of |x| from the launch that wrote x (P2LAmax.in);
     want_amax: also return (amax_y, amax_yp) partial maxima of the outputs, or None when this launch
-    writes none (p2l_conv_amax_slots == 0)"""
+    writes none (p2l_conv_amax_slots == 0); amax_next = (s, t, bstride): the affine the reader of y
+    will fuse -- the maxima of y are recorded as max|y*s + t| (P2LAmax.next_s); amax_applied: amax_in
+    was recorded that way with THIS launch's pro_s / pro_t (P2LAmax.in_applied)"""
     d = N.P2LConv()
     d.wfmt = wfmt
     d.form = DEFAULT_FORM if form is None else form
@@ -78,6 +80,9 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
     am_y = am_yp = None
     if amax_in is not None:
         ex.amax.in_, ex.amax.in_n = amax_in.data_ptr(), amax_in.shape[-1]
+        ex.amax.in_applied = int(amax_applied)
+    if amax_next is not None:
+        ex.amax.next_s, ex.amax.next_t, ex.amax.next_bstride = amax_next[0].data_ptr(), amax_next[1].data_ptr(), int(amax_next[2])
     if want_amax:
         ns = _lib().p2l_conv_amax_slots(C.byref(d))
         if ns > 0:
