@@ -302,7 +302,7 @@ def extra_configs(dev, n_steps=3):
         run('stylegan2_cars_512_n32', FixedNoise(), vm, 32, 512,
             'BASELINE config 4 inner step: 32 samples (reference chunks 9,9,9,5 define the '
             'gradient scale; executed in one device pass), z-space, rows 64:-64 loss mask',
-            profile='profiles/round3_sg2_512_kernel_stats.csv, round3_sg2_512_layers.txt',
+            profile='profiles/round4_sg2_512_kernel_stats.csv, round4_sg2_512_layers.txt',
             exec_batch_size='all')
         del gen, fixed
         torch.cuda.empty_cache()
@@ -320,7 +320,7 @@ def extra_configs(dev, n_steps=3):
         run('stylegan2_ffhq_1024_shard3_wplus', gen, vm, 3, 1024,
             'BASELINE config 5, one rank\'s shard: 3 candidates, W+ latents [18,512] and the '
             '2.8M-element noise vector both optimised',
-            profile='profiles/round3_sg2_1024_kernel_stats.csv, round3_sg2_1024_layers.txt')
+            profile='profiles/round4_sg2_1024_kernel_stats.csv, round4_sg2_1024_layers.txt')
     return out
 
 

@@ -2,7 +2,7 @@
 
 usage: python tools/step_kernels.py <kernel_trace.csv> [marker-substring]
 The steps are delimited by the launches of a kernel that runs once per step (default: the forward
-attention core); the segment with the most launches between two markers is a full step (forward +
+attention core); the long segments between two markers are full steps (forward +
 loss + backward + Adam; the forward-only re-score passes of bench.py are shorter).  The trace's
 timestamps of back-to-back dependent launches abut (a launch's start is stamped while its
 predecessor drains), so idle time between kernels cannot be read from it: span == sum of durations."""
@@ -12,7 +12,11 @@ rows = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Nam
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
 segs = [(b - a, a, b) for a, b in zip(marks, marks[1:])]
 if not segs: sys.exit('fewer than 2 marker launches')
-_, a, b = max(segs)
+# (the first step also runs the one-off target preparation: take the LAST segment of the most common
+#  launch count among the long ones)
+big = [x for x in segs if x[0] >= 0.6 * max(segs)[0]]
+mode = collections.Counter(x[0] for x in big).most_common(1)[0][0]
+_, a, b = [x for x in big if x[0] == mode][-1]
 seg = rows[a:b]
 span = rows[b][0] - seg[0][0]
 busy = sum(e - s for s, e, _ in seg)
