@@ -206,8 +206,9 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
                              W + L.y[l], nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
     } else {
       d.ups = 2; d.ext = 1;
+      // (the workspace holds the per-image maxima of the fp16 x 2 form: without it the launch is bf16 x 3)
       RET_IF(p2l_conv_fwd(&d, x, c.w, nullptr, W + L.s[l], W + L.zeros, nullptr, nullptr,
-                          W + L.ubuf, nullptr, nullptr, 0, st));
+                          W + L.ubuf, nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
       RET_IF(p2l_sg2_blur_fwd(W + L.ubuf, W + L.d[l], nz, c.noise_w, c.act_b, W + L.y[l], B, c.res,
                               c.res, c.cout, st));
     }
