@@ -213,6 +213,12 @@ __device__ __forceinline__ void pw_store_split_h2(float* As, int row, int q4, in
 // accumulator rows un-scaled at the end); blockIdx.y is a split-K slice of the stages whose un-scaled
 // partial outputs go to k.ws for the deterministic finish kernel of the direct path (p2l_conv.hip);
 // the maxima come from the producer (P2LAmax) or from the 64 partials per image of the pass in front.
+// (A/B builds, tools/ab_build.sh p2l_pw -DP2L_PW_ABL=n: timing ablations of the stage loop -- results are
+//  wrong when set: 1 no split / LDS writes (activations and weights; the loads then go too), 2 no global
+//  loads of the stages, 8 no MFMAs, 16 no barriers; all after the first stage; 32 no epilogue)
+#ifndef P2L_PW_ABL
+#define P2L_PW_ABL 0
+#endif
 template <int PRO, bool SM = false>
 __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {   // (SM: per-item prologue operands, 130-160 VGPR)
   constexpr int KS = 32, VPP = KS / 4;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
   __syncthreads();
   for (int st = st_lo; st < st_hi; ++st) {
     const bool more = st + 1 < st_hi;
-    if (more) load_regs(st + 1);
+    if (more && !(P2L_PW_ABL & 2)) load_regs(st + 1);
 #pragma unroll
     for (int sub = 0; sub < PWH_SUB; ++sub) {
       const float* ar = As + (sub * 128 + a_row) * 16;
@@ -408,21 +414,24 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
         const h16x8 bh = *reinterpret_cast<const h16x8*>(br + b_h);
         const h16x8 bm = *reinterpret_cast<const h16x8*>(br + b_m);
         f32x16 t = acc[j];                               // smallest terms first
+        if (!(P2L_PW_ABL & 8)) {
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, t, 0, 0, 0);
+        } else { t[0] += (float)am[0] * (float)bh[0] + (float)ah[1] * (float)bm[1]; }
         acc[j] = t;
       }
     }
-    __syncthreads();
-    if (more) write_lds();
-    __syncthreads();
+    if (!(P2L_PW_ABL & 16)) __syncthreads();
+    if (more && !(P2L_PW_ABL & 1)) write_lds();
+    if (!(P2L_PW_ABL & 16)) __syncthreads();
   }
   if (!SM) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] *= out_scale;  // (exact: a power of two)
+    if (!(P2L_PW_ABL & 32) || acc[0][0] == 12345.678f)
     epilogue_vec<2>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image, 0, 0, 0);
     return;
   }
