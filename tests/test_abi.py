@@ -53,7 +53,7 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
     if shutil.which('gcc') is None:
         pytest.skip('no gcc')
     members = {
-        'P2LAmax': ['out', 'outp', 'in', 'in_n'],
+        'P2LAmax': ['out', 'outp', 'in', 'in_n', 'next_s', 'next_t', 'next_bstride', 'in_applied'],
         'P2LConvExtra': ['oscale', 'oscale_bstride', 'noise', 'noise_w', 'amax'],
         'P2LArb': ['x', 'x_ld', 's', 't', 'st_bstride', 'skip', 'skip_ld', 'skip_C', 'skip_ups', 'ds', 'dt',
                    'dsdt_bstride', 'partial', 'nomask', 'amax'],
