@@ -120,7 +120,7 @@ int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
  * the launch reduces max|x| itself.  The caller guarantees that nothing else wrote the tensor in
  * between.  All NULL / 0 = not used.
  * The bound of a fused prologue is loose when large |s| and large |x| sit in different channels
- * (trained networks: two orders of magnitude), and every factor of two of it is a bit of the
+ * (heavy-tailed synthetic weights: x 50 - 160 on every CBN layer), and every factor of two of it is a bit of the
  * fp16 x 2 operand's range.  A producer that is told the affine its reader will fuse (`next_s`,
  * `next_t`: [B][next_bstride] per-channel vectors, bstride 0 = shared by the images) therefore
  * records the maxima of |y*next_s + next_t| in `out` instead (never in `outp`); the reader is then

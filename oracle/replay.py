@@ -38,7 +38,14 @@ def native_decisions(model, loss_fn, W, B, dev, out, target, diag=None):
                 c = x.shape[-1]
                 off = d.blocks[bi].cbn_off[k]
                 sv, tv = s_all[:, off:off + c].view(B, 1, 1, c), t_all[:, off:off + c].view(B, 1, 1, c)
-                pre = torch.addcmul(tv, x, sv)
+                # the kernels evaluate x*s + t as ONE fused multiply-add (hipcc contracts it in every
+                # prologue and in the activation-backward epilogues): its sign is the sign of the exact
+                # value.  An unfused fp32 evaluation differs for the one-in-10^7 pre-activation whose
+                # product rounds across -t (heavy-tailed weights, seed 7: one element of 37.7 M at the
+                # input of block 10, latent gradient 8.5e-5 off when that decision is replayed wrongly)
+                pre = torch.addcmul(tv.double(), x.double(), sv.double())
+                if diag is not None:
+                    pre = torch.addcmul(tv, x, sv)
                 if diag is not None:
                     pre_b = (x * sv) + tv
                     pre_c = x.double() * sv.double() + tv.double()
@@ -46,14 +53,25 @@ def native_decisions(model, loss_fn, W, B, dev, out, target, diag=None):
                     diag.append(('%s.bn_%d' % (p, k), [int(v) for v in ((pre > 0) != (pre_b > 0)).flatten(1).sum(1)],
                                  [int(v) for v in ((pre > 0) != (pre_c > 0)).flatten(1).sum(1)],
                                  [int(v) for v in amb.flatten(1).sum(1)]))
+                    pre = pre_c
                 items.append(('%s.bn_%d' % (p, k), 'relu', _nchw(pre > 0).cpu()))
             bi += 1
         prev = model.saved_activation(0, i)
     # tail: unconditional BN folded as the plan folds it
-    mean, var = R._bn_stats(W['generator.bn.running_means'], W['generator.bn.running_vars'], 1.0)
-    s = (W['generator.bn.weight'] / torch.sqrt(var + R.BN_EPS)).to(dev)
-    t = (W['generator.bn.bias'] - mean * W['generator.bn.weight'] / torch.sqrt(var + R.BN_EPS)).to(dev)
-    items.append(('generator.bn', 'relu', _nchw(torch.addcmul(t, prev, s) > 0).cpu()))
+    # (the NATIVE fold, to the bit: t = b - m * s with the rounded s -- the algebraically equal
+    #  b - m * w / sqrt(v + eps) is an ulp away, and 8.4 M pre-activations per image put one or two of
+    #  them inside that ulp of zero: a decision the oracle would then replay differently from the run)
+    s, t = getattr(model, '_tail_s', None), getattr(model, '_tail_t', None)
+    if s is None or t is None:
+        mean, var = R._bn_stats(W['generator.bn.running_means'], W['generator.bn.running_vars'], 1.0)
+        s = (W['generator.bn.weight'] / torch.sqrt(var + R.BN_EPS))
+        t = (W['generator.bn.bias'] - mean * s).to(dev)
+        s = s.to(dev)
+    tail_pre = torch.addcmul(t.double(), prev.double(), s.double())
+    if diag is not None:
+        amb = tail_pre.double().abs() < 4e-7 * ((prev.double() * s.double()).abs() + t.double().abs())
+        diag.append(('generator.bn', [0] * B, [0] * B, [int(v) for v in amb.flatten(1).sum(1)]))
+    items.append(('generator.bn', 'relu', _nchw(tail_pre > 0).cpu()))
     # L1 term: sign of (out - target) of the pixels the native loss saw
     items.append(('l1', 'sign', torch.sign(out.detach() - target).cpu()))
     # VGG of the generated image

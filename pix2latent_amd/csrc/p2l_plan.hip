@@ -69,12 +69,16 @@ struct ConvCall {
 // weight format of the 3x3 convs of the model whose plan is running on this thread
 // (set at every extern "C" entry from the model struct's wfmt)
 thread_local int g_plan_wfmt = P2L_WFMT_F32;
+// P2LConv.form bits every conv of the running plan gets (A/B builds: -DP2L_AB_BWD_BF3 / _BG / _PL keep the
+// backward passes -- both / generator / loss network -- in the bf16 x 3 arithmetic)
+thread_local int g_plan_form = 0;
 
 ConvCall mk_conv(int B, int H, int W, int Cin, int Cout, int taps) {
   ConvCall c;
   c.d.wfmt = (taps == 9) ? (g_plan_wfmt & 0xF)
                          : ((g_plan_wfmt & P2L_WFMT_FLAG_PW) ? P2L_WFMT_PW : P2L_WFMT_F32);
   c.d.ext = 0;
+  c.d.form = g_plan_form;
   c.d.B = B; c.d.H = H; c.d.W = W; c.d.Cin = Cin; c.d.Cout = Cout; c.d.taps = taps;
   c.d.ups = 0; c.d.x_ld = Cin; c.d.pro = P2L_PRO_NONE; c.d.pro_bstride = 0;
   c.d.alpha = 1.f; c.d.act = P2L_ACT_NONE; c.d.pool = P2L_POOL_NONE;
@@ -222,7 +226,9 @@ int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
       if (c.y && c.d.y_ld == c.d.Cout) so = R->take(&set_o);
       if (c.yp && c.d.yp_ld == c.d.Cout) sop = R->take(&set_p);
       ex.amax.out = so; ex.amax.outp = sop;
+#ifndef P2L_AB_NO_NEXT_AFFINE                          // (A/B build: raw maxima + the reader's bound, as until round 4)
       if (so && c.next_ps && c.next_pt) { ex.amax.next_s = c.next_ps; ex.amax.next_t = c.next_pt; ex.amax.next_bstride = c.next_bstride; }
+#endif
     }
   }
   const int rc = p2l_conv_fwd_ex(&c.d, &ex, c.x, c.w, c.bias, c.ps, c.pt, c.res, c.mask, c.y, c.yp, skws,
@@ -653,6 +659,9 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
                               const float* img16, float* dimg16, float* dz, float* dc,
                               void* st) {
   g_plan_wfmt = m ? m->wfmt : P2L_WFMT_F32;
+#if defined(P2L_AB_BWD_BF3) || defined(P2L_AB_BWD_BF3_BG)
+  struct FormScope { FormScope() { g_plan_form = P2L_FORM_WINO_BF3; } ~FormScope() { g_plan_form = 0; } } form_scope;
+#endif
   BGLayout L;
   RET_IF(bg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !img16 || !dimg16 || !dz || !dc)
@@ -1042,6 +1051,9 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
                                 float beta, int use_lpips, const float* gloss, int B, int H,
                                 int W, void* ws, size_t ws_bytes, float* dimg16, void* st) {
   g_plan_wfmt = v ? v->wfmt : P2L_WFMT_F32;
+#if defined(P2L_AB_BWD_BF3) || defined(P2L_AB_BWD_BF3_PL)
+  struct FormScope { FormScope() { g_plan_form = P2L_FORM_WINO_BF3; } ~FormScope() { g_plan_form = 0; } } form_scope;
+#endif
   PLLayout L;
   RET_IF(pl_layout(B, H, W, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !cache || !img16 || !gloss || !dimg16)

@@ -152,9 +152,10 @@ def test_maxima_with_the_readers_affine_applied(dev, H):
     below the scaled maximum before an operand's low piece goes subnormal.  A producer that knows the
     reader's affine records max|y*s + t| itself: exactly that maximum (to the rounding of one FMA),
     from every kernel family that writes maxima, and every fp16 x 2 reader is fp32-grade on EVERY
-    output (relative to that output's own sum |x||w|).  At this single layer the bound still is too
-    (2^10 of slack inside 2^18); where it showed is the model above: 13 blocks x 4 bounded layers,
-    candidate 1 of 2, latent gradient 8.0e-5 off with the bounds, 1.5e-5 with the applied maxima."""
+    output (relative to that output's own sum |x||w|).  With the bound they still are (2^10 of slack
+    inside 2^18, here and in the model above alike: tools/heavytail_ab.py with -DP2L_AB_NO_NEXT_AFFINE);
+    the applied maxima are margin for statistics this repo has not seen, and two reductions less in
+    every reader's prologue."""
     import math
     import torch.nn.functional as F
     from pix2latent_amd import _native as N, ops as O
