@@ -28,8 +28,10 @@ def _inner_tail(model, n):
     return worst
 
 
+# seeds: the two draws on which the replayed oracle once took a decision the run had not (CHANGELOG, round 4)
 @pytest.mark.timeout(2400)
-def test_heavy_tailed_weights_both_arithmetics(dev, monkeypatch):
+@pytest.mark.parametrize('seed', [2, 7])
+def test_heavy_tailed_weights_both_arithmetics(dev, monkeypatch, seed):
     from pix2latent_amd import _native as N
     from pix2latent_amd.utils import synthetic as S
     from pix2latent_amd.model.biggan import BigGAN
@@ -40,7 +42,7 @@ def test_heavy_tailed_weights_both_arithmetics(dev, monkeypatch):
     W = S.heavy_tailed(S.biggan_weights(0))
     Wv = S.heavy_tailed_vgg(S.lpips_vgg_weights(1))
     n = 2
-    g = torch.Generator().manual_seed(2)
+    g = torch.Generator().manual_seed(seed)
     z = torch.fmod(torch.randn(n, 128, generator=g), 2.0)
     c = (0.05 * torch.randn(1, 128, generator=g)).repeat(n, 1)
     target = S.synthetic_target(256, 1).unsqueeze(0).repeat(n, 1, 1, 1)
