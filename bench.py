@@ -505,7 +505,7 @@ def main():
             'dtype': ('f32 (fp32 tensors everywhere; convolutions >= 32x32 and the self-attention multiply on '
                       'the 16-bit MFMA pipe with fp32-grade operand splits and fp32 accumulate: the 16x16 '
                       'Winograd, direct and sub-pixel 3x3 kernels and the 1x1 kernels (4x4 layers included) on '
-                      'power-of-two scaled operands in 2 fp16 pieces, 3 products; the fused attention, the 3-channel '
+                      'power-of-two scaled operands in 2 fp16 pieces, 3 products, the fused attention too; the 3-channel '
                       'image convs and the launches without handed-over maxima on 3 bf16 pieces, 6 products; dense '
                       'layers, reductions and elementwise work exact fp32)'
                       if bf3 else 'f32'),
@@ -518,7 +518,7 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
-                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel >= 128 channels; direct / sub-pixel kernel for 64-channel, up-sampling and small layers; 1x1 kernels) + bf16x3 (3-channel image convs, attention)' if bf3 else 'f32',
+                'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel >= 128 channels; direct / sub-pixel kernel for 64-channel, up-sampling and small layers; 1x1 kernels; fused attention) + bf16x3 (3-channel image convs)' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
