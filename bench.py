@@ -203,15 +203,20 @@ class _GpuTelemetry(object):
 # the other configurations BASELINE.json / north_star name, measured AFTER the timed region
 # and reported under config.extra (same JSON line)
 # ---------------------------------------------------------------------------------------
-def _time_steps(fn, n_warm, n):
+def _time_steps(fn, n_warm, n, reps=3):
+    """seconds per step: the MEDIAN of `reps` timings of n steps each (three steps alone caught a
+    30 ms host stall once in a dozen runs: 430 instead of 940 evals/s for the 8-sample configuration)"""
     for i in range(n_warm):
         fn(i == 0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn(False)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    per = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn(False)
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / n)
+    return sorted(per)[len(per) // 2]
 
 
 def extra_configs(dev, n_steps=3):
