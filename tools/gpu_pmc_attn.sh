@@ -17,7 +17,7 @@ for d in ('pmc_attn', 'pmc_attn2'):
     for r in rows:
         n = r['Kernel_Name']
         if 'attn_' not in n: continue
-        key = n.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+        key = n.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
         a = by.setdefault(key, collections.defaultdict(float))
         a[r['Counter_Name']] += float(r['Counter_Value']); a['_n' + r['Counter_Name']] += 1
     for k, v in by.items():
