@@ -833,71 +833,6 @@ __global__ __launch_bounds__(256) void conv_splitk_finish4(const ConvK k) {
   }
 }
 
-// The split-K finish of the direct / pointwise kernels with 16-byte accesses (round 4; the scalar kernel
-// above moves 64-byte segments: 2 TB/s on tensors of a few MB).  Item = one 2x2 quad x FOUR consecutive
-// channels; wave = 16 items x 4 z-parts, lane z sums slabs z, z+4, ... and the four partial sums meet in
-// the SAME fixed order ((z0 + z1) + (z2 + z3)): bit-identical sums.  The epilogue is the shared item
-// (epi_item), the maxima one partial per block of 64 items.
-__global__ __launch_bounds__(256) void conv_splitk_finish_v4(const ConvK k) {
-  const int Hh = k.H >> 1, Wh = k.W >> 1, C4 = k.n_store >> 2;
-  const size_t total = (size_t)k.B * Hh * Wh * C4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int zp = lane >> 4;
-  const size_t idx = ((size_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
-  const bool live = idx < total;
-  const size_t id2 = live ? idx : 0;
-  const int n = (int)(id2 % C4) * 4;
-  size_t q = id2 / C4;
-  const int qx = (int)(q % Wh);
-  q /= Wh;
-  const int qy = (int)(q % Hh);
-  const int b = (int)(q / Hh);
-  const size_t mtot = (size_t)k.B * k.H * k.W;
-  f32x4 v[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const size_t pix = ((size_t)b * k.H + 2 * qy + (s >> 1)) * k.W + 2 * qx + (s & 1);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int zz = zp; zz < k.splitk; zz += 4)
-      acc += *reinterpret_cast<const f32x4*>(k.ws + ((size_t)zz * mtot + pix) * k.Cout + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = acc[e];
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
-      acc[e] = t;
-    }
-    v[s] = acc * k.alpha;
-  }
-  EpiSums S;
-  if (live && zp == 0) {
-    epi_item(k, v, b, 2 * qy, 2 * qx, n, 0, 0, 0, S);
-    if (k.arb_x != nullptr) {
-      const size_t po = ((size_t)b * k.arb_nblk + (size_t)qy * Wh + qx) * k.Cout + n;
-      *reinterpret_cast<f32x4*>(k.arb_partial + po) = S.sgx;
-      *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + po) = S.sg;
-    }
-  }
-  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
-    __shared__ float red[8];
-    float mx = S.amax, mxp = S.amaxp;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64)); }
-    if (lane == 0) { red[wave] = mx; red[4 + wave] = mxp; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const size_t first = (size_t)blockIdx.x * 64;                // first item of the block
-      const size_t per_image = (size_t)Hh * Wh * C4;
-      if (first < total) {
-        const size_t bb = first / per_image;
-        const size_t slot = bb * k.amax_out_n + (first - bb * per_image) / 64;
-        if (k.amax_out != nullptr) k.amax_out[slot] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        if (k.amax_outp != nullptr) k.amax_outp[slot] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-      }
-    }
-  }
-}
-
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
 // its input-gradient conv O->I (K=O, N=I, taps mirrored).
 // bf16x3 packed element: row (idx / 16) holds [x1 k0-15 | x2 k0-15 | x3 k0-15] (96 bytes)
@@ -1214,12 +1149,6 @@ static bool wino_h2(const P2LConv* d) {
 // 128 pixels x 32 / 64 channels); every WAVE of a block writes its own partial.  Split-K launches (finish kernel), the 8x16 Winograd kernel, the
 // three-channel image kernels and tiles that span images write none.
 static int effective_splitk(const P2LConv* d);
-// the 16-byte finish kernel of a split-K launch: every pitch it touches a multiple of four floats
-// (descriptor only: p2l_conv_amax_slots and the launch must agree)
-static bool finish_v4_ok(const P2LConv* d) {
-  return d->n_store % 4 == 0 && d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->yp_ld % 4 == 0 &&
-         d->res_ld % 4 == 0 && d->mask_ld % 4 == 0;
-}
 extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   if (!d) return 0;
   if (wino_shape(d)) {
@@ -1233,11 +1162,10 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
   if (effective_splitk(d) > 1) {
-    // split-K launch of the direct kernels: a finish kernel writes the tensor, one partial per block of
-    // 64 items -- (quad, 4 channels) for the 16-byte kernel, (quad, channel) for the scalar one -- when
-    // a block never straddles two images.  (The hand-over thereby follows the LAYER, not the split-K
-    // choice a batch size brings with it.)
-    const int per_image = (d->H / 2) * (d->W / 2) * (finish_v4_ok(d) ? d->n_store / 4 : d->n_store);
+    // split-K launch of the direct kernels: the scalar finish kernel writes the tensor, one partial
+    // per block of 64 (quad, channel) items -- when a block never straddles two images.  (The
+    // hand-over thereby follows the LAYER, not the split-K choice a batch size brings with it.)
+    const int per_image = (d->H / 2) * (d->W / 2) * d->n_store;
     return (per_image % 64 == 0) ? per_image / 64 : 0;
   }
   ConvK k{};
@@ -1639,15 +1567,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   if (rc) return rc;
   if (k.splitk > 1) {
-    const bool arb_al = !arb || (k.arb_x_ld % 4 == 0 && (!k.arb_skip || k.arb_skip_ld % 4 == 0));
-    if (finish_v4_ok(d) && !arb_al) return P2L_EINVAL;   // (the maxima slots were sized for the 16-byte kernel)
-    if (finish_v4_ok(d)) {
-      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * (k.n_store >> 2);
-      hipLaunchKernelGGL(conv_splitk_finish_v4, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
-    } else {
-      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
-      hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
-    }
+    const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
+    hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0,
+                       st, k);
     rc = p2l_check_launch();
   }
   if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
