@@ -123,11 +123,14 @@ def test_basincma_generation_on_biggan(dev):
     for j in range(2):
         opt.step(variables, optimize=True, transform=(j == 0))
     _, l1, _ = opt.step(variables, optimize=False)
-    _, l2, _ = opt.step(variables, optimize=False)
-    l1, l2 = np.array(l1), np.array(l2)
+    l1 = np.array(l1)
     assert l0.shape == (18,) and np.isfinite(l1).all()
     assert l1.mean() < l0.mean()
-    assert np.array_equal(l1, l2), 're-score must be bit-reproducible'
+    # (eight repetitions: a finish kernel that was NOT deterministic showed in one candidate of 18 in
+    #  about one re-score of three -- tools/rescore_repeat.py, CHANGELOG round 4)
+    for _ in range(8):
+        _, l2, _ = opt.step(variables, optimize=False)
+        assert np.array_equal(l1, np.array(l2)), 're-score must be bit-reproducible'
     opt.cma_update(variables, loss=l1)
 
 
