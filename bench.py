@@ -257,9 +257,8 @@ def extra_configs(dev, n_steps=3):
                 opt.step(variables, optimize=True)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            f, m, c, b, x, mf = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
-                                 (C.c_double * 2)(), (C.c_double * 2)())
-            N.check(lib.p2l_prof_end4(f, m, c, b, x, mf), 'p2l_prof_end4')
+            T = N.prof_end()
+            f, m, c, b, x, mf = T.flops, T.ms, T.count, T.bytes, T.exec_flops, T.mfma_flops
             opt.use_graph = saved
             if m[0] > 0:
                 tf = f[0] / (m[0] * 1e-3) / 1e12
@@ -437,14 +436,9 @@ def main():
             opt.step(variables, optimize=True)
         sync()
         elapsed = time.perf_counter() - t0
-    flops = (C.c_double * 2)()
-    ms = (C.c_double * 2)()
-    cnt = (C.c_int32 * 2)()
-    abytes = (C.c_double * 2)()
-    xflops = (C.c_double * 2)()
-    mflops = (C.c_double * 2)()
-    wbytes = (C.c_double * 2)()
-    N.check(lib.p2l_prof_end5(flops, ms, cnt, abytes, xflops, mflops, wbytes), 'p2l_prof_end5')
+    T = N.prof_end()
+    flops, ms, cnt, abytes, xflops, mflops, wbytes = (T.flops, T.ms, T.count, T.bytes, T.exec_flops,
+                                                      T.mfma_flops, T.write_bytes)
     last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()

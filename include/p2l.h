@@ -99,6 +99,11 @@ typedef struct P2LConv {
  * channel chunk q and output channel n, KC consecutive input channels.
  * p2l_pack_conv_weight builds it (and the input-gradient copy) from OIHW. */
 size_t p2l_conv_workspace_bytes(const P2LConv* d);
+/* K slices for this layer: a function of the LAYER SHAPE (H, W, Cin, Cout, taps, ups, format) only,
+ * never of d->B -- the slices are summed in a fixed order that follows their count, so a count that
+ * followed the batch would make a candidate's low bits depend on who shares its launch (it did for
+ * the 4^2 ... 16^2 layers until round 5).  With the suggested count a candidate's result is
+ * bit-identical for every batch size and position in the batch.  */
 int p2l_conv_suggest_splitk(const P2LConv* d);
 int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                  const float* bias, const float* pro_s, const float* pro_t,
@@ -168,25 +173,25 @@ void p2l_arb_defer_cancel(void);
  * stream (bench.py roofline leg).  begin() pre-creates the event pool; end()
  * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */
 int p2l_prof_begin(int max_launches);
-int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]);
-/* same, plus the algorithmic bytes of the timed launches (each operand tensor once +
- * packed weights); index 0 = 3x3 launches, 1 = 1x1 launches */
-int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]);
-/* same, plus the FLOPs the matrix pipe actually executed for those launches (padded channel
- * counts; sub-pixel forms: 4 phase-taps per output pixel where `flops` counts the 9 taps of
- * the upsample-then-convolve definition) */
-int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                  double exec_flops[2]);
-/* same, plus the 16-bit MFMA FLOPs issued for those launches: exec_flops x the products per fp32
- * product of each launch's arithmetic (6 = bf16 x 3, 3 = fp16 x 2; a launch on the fp32 MFMA
- * counts 16, its cost in 16-bit-MFMA time) -- mfma_flops / time / dense 16-bit peak is the
- * fraction of the time the matrix pipe is busy */
-int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                  double exec_flops[2], double mfma_flops[2]);
-/* same, plus the WRITTEN share of `bytes` (outputs y / yp), so that the PMC read (FETCH_SIZE) and
- * write (WRITE_SIZE) traffic can each be set against its own algorithmic count */
-int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                  double exec_flops[2], double mfma_flops[2], double write_bytes[2]);
+/* Totals per conv family, index 0 = 3x3 launches, 1 = 1x1 launches.  `size` is set by the CALLER to
+ * sizeof(P2LProfTotals) as it was compiled; the library fills the members that fit (later versions of
+ * the library only ever append members), so one entry point serves every generation of callers.      */
+typedef struct P2LProfTotals {
+  uint32_t size;           /* in: sizeof(P2LProfTotals)                                             */
+  int32_t count[2];        /* timed launches                                                         */
+  int32_t reserved0;
+  double flops[2];         /* algorithmic FLOPs (9 taps on the output grid, un-padded channels)       */
+  double ms[2];            /* event time of those launches (conv + its split-K finish)                */
+  double bytes[2];         /* algorithmic bytes: every operand tensor once + the packed weights       */
+  double exec_flops[2];    /* FLOPs the matrix pipe executed (padded channels; sub-pixel forms: 4     *
+                            * phase-taps per output pixel; Winograd: 16 products per 2x2 quad)        */
+  double mfma_flops[2];    /* 16-bit MFMA FLOPs issued: exec_flops x products per fp32 product (6 =   *
+                            * bf16 x 3, 3 = fp16 x 2; a launch on the fp32 MFMA counts 16, its cost   *
+                            * in 16-bit-MFMA time): / time / dense 16-bit peak = matrix-pipe busy      */
+  double write_bytes[2];   /* the WRITTEN share of `bytes` (y / yp): PMC FETCH_SIZE and WRITE_SIZE     *
+                            * can each be set against their own algorithmic count                     */
+} P2LProfTotals;
+int p2l_prof_end(P2LProfTotals* out);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
  * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;
@@ -194,7 +199,7 @@ int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], double bytes[
  * steps every launch of the step has been timed once.  Without the call every launch is
  * timed. */
 int p2l_prof_step(int step, int period);
-/* p2l_prof_end* also write one line per timed launch to `path` (taps B H W Cin Cout ups pro arb
+/* p2l_prof_end also writes one line per timed launch to `path` (taps B H W Cin Cout ups pro arb
  * splitk flops bytes ms) when a path was given; NULL switches it off.  The profiler is the one
  * process-wide object of the library (the backward pass of a torch program runs on the autograd
  * engine's thread and must be timed too): opt-in, every access under a mutex. */
@@ -211,9 +216,6 @@ typedef struct P2LConvExtra {
 } P2LConvExtra;
 /* partial maxima per image a launch of d writes into P2LAmax.out / outp (0: it writes none) */
 int p2l_conv_amax_slots(const P2LConv* d);
-/* test hook, host logic only: the bookkeeping rules of the plans' per-run maxima registry
- * (csrc/p2l_plan.hip AmaxReg); 0 = all hold */
-int p2l_selftest_amaxreg(void);
 int p2l_conv_fwd_ex(const P2LConv* d, const P2LConvExtra* ex, const float* x,
                     const float* w, const float* bias, const float* pro_s,
                     const float* pro_t, const float* res, const float* mask, float* y,
@@ -593,18 +595,6 @@ int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c, int Bn,
 int p2l_biggan_bwd(const P2LBigGAN* m, int Bn, void* ws, size_t ws_bytes,
                    const float* img16, float* dimg16, float* dz, float* dc,
                    void* stream);
-/* debug/test hook: float offset + shape of a saved activation in ws.        */
-/* what: 0 = output of layer L (ModuleList index, SelfAttn included),        */
-/*       1 = gen_z output, 2 = folded CBN s, 3 = folded CBN t,               */
-/*       4 = d s, 5 = d t (after bwd),                                       */
-/*       6 = d loss / d (CBN gains | CBN biases) [B][2*cbn_total] (after bwd):*/
-/*           the per-layer gradients the parity tests compare with the oracle */
-/*       7 = input of bn_1 | bn_2 | bn_3 of GenBlock L / 3 (k = L % 3),         */
-/*       8 / 9 = un-pooled phi / g of the self-attention: with 0-3 every       */
-/*           discrete decision of a forward pass (ReLU signs, max-pool winners) */
-/*           can be read back (tests/test_fixed_mask_grad_gpu.py)              */
-int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int L,
-                         size_t* float_off, int32_t shape[4]);
 
 typedef struct P2LVggLpips {
   const float* w[13];             /* packed forward (conv0: Cin padded to 16) */
@@ -627,9 +617,6 @@ typedef struct P2LLossCache {
 size_t p2l_loss_cache_floats(int Bn, int H, int W, size_t nft_off[5],
                              size_t wt_off[5], size_t* wsum_off);
 size_t p2l_projloss_ws_bytes(int Bn, int H, int W);
-/* debug/test hook: float offset + shape [B,h,w,C] of the post-ReLU output of VGG conv idx
- * (0..12) inside ws after p2l_projloss_fwd */
-int p2l_projloss_ws_lookup(int Bn, int H, int W, int idx, size_t* float_off, int32_t shape[4]);
 /* target/weight/loss_mask: NCHW3 [B,3,H,W] (loss_mask may be NULL)           */
 int p2l_projloss_prepare(const P2LVggLpips* v, const float* target,
                          const float* weight, const float* loss_mask, int Bn,
@@ -800,9 +787,6 @@ int p2l_sg2_mapping_fwd(const P2LStyleGAN2* m, const float* z, float* w, float* 
 int p2l_sg2_mapping_bwd(const P2LStyleGAN2* m, const float* z, const float* acts, const float* dw,
                         float* dz, float* scratch /* 2*B*512 */, int Bn, void* stream);
 
-/* MFMA layout self-test: C[32x32] = A[32xK] * B[Kx32] via one wave. */
-int p2l_mfma_probe(const float* A, const float* B, float* C, int K,
-                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,21 @@ class P2LLossCache(C.Structure):
     _fields_ = [('nft', C.c_void_p * 5), ('wt', C.c_void_p * 5), ('wsum', C.c_void_p)]
 
 
+class P2LProfTotals(C.Structure):
+    _fields_ = [('size', C.c_uint32), ('count', C.c_int32 * 2), ('reserved0', C.c_int32),
+                ('flops', C.c_double * 2), ('ms', C.c_double * 2), ('bytes', C.c_double * 2),
+                ('exec_flops', C.c_double * 2), ('mfma_flops', C.c_double * 2),
+                ('write_bytes', C.c_double * 2)]
+
+
+def prof_end():
+    """p2l_prof_end: totals of the timed conv launches per family (index 0 = 3x3, 1 = 1x1)"""
+    t = P2LProfTotals()
+    t.size = C.sizeof(P2LProfTotals)
+    check(lib().p2l_prof_end(C.byref(t)), 'p2l_prof_end')
+    return t
+
+
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
 WFMT_F32, WFMT_BF16X3, WFMT_BF16X3W, WFMT_PW, WFMT_BF16X3T = 0, 1, 2, 3, 4
 WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM, WFMT_FLAG_NO_AMAX = 0x10, 0x20, 0x40, 0x80
@@ -135,10 +150,14 @@ FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN
 
 
 def default_wfmt():
-    """weight / arithmetic format of the 3x3 convs (include/p2l.h): bf16x3 = fp32-equivalent
-    3-way split on the bf16 matrix pipe, with the Winograd-domain weight image appended so that
-    eligible layers run in the F(2x2,3x3) form; P2L_CONV_WFMT=bf16x3-direct keeps every layer
-    on the direct kernel, =f32 asks for the exact-fp32 MFMA."""
+    """weight format of the 3x3 convs (include/p2l.h).  Default `bf16x3` = P2L_WFMT_BF16X3W: the
+    buffer carries the bf16 x 3 direct image, the Winograd-domain images and the fp16 x 2 images, and
+    every launch of such a model runs in the fp32-grade fp16 x 2 arithmetic (two fp16 pieces of
+    power-of-two scaled operands, three MFMA products: Winograd F(2x2,3x3) from 128 input channels
+    up, the direct / sub-pixel kernel otherwise); the bf16 x 3 images (three pieces, six products)
+    serve the three-channel image convs, launches without a workspace and P2L_FORM_WINO_BF3.
+    P2L_CONV_WFMT=bf16x3-direct keeps every layer on the bf16 x 3 direct kernel, =f32 asks for the
+    exact-fp32 MFMA."""
     v = os.environ.get('P2L_CONV_WFMT', 'bf16x3').lower()
     if v in ('f32', 'fp32', '0'):
         return WFMT_F32
@@ -168,8 +187,10 @@ def default_no_amax():
 
 
 def default_pw():
-    """1x1 convs in the same fp32-equivalent bf16x3 arithmetic (csrc/p2l_pw.hip) unless
-    P2L_PW=0 or the 3x3 convs were asked to run on the exact-fp32 MFMA"""
+    """1x1 convs on the 16-bit matrix pipe (csrc/p2l_pw.hip; P2L_WFMT_PW buffers: fp32 | bf16 x 3 |
+    fp16 x 2 images) -- fp16 x 2 wherever the producer of the input handed its maxima over or the
+    layer is a 4^2 ... 16^2 one, bf16 x 3 otherwise -- unless P2L_PW=0 or the 3x3 convs were asked
+    to run on the exact-fp32 MFMA"""
     return os.environ.get('P2L_PW', '1') != '0' and default_wfmt() != WFMT_F32
 
 
@@ -229,7 +250,7 @@ EXPORTS = [
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_affine_grid_sample_bwd', 'p2l_affine_grid_sample_bwd_ws_bytes', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_ws_lookup', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_end2', 'p2l_prof_end3', 'p2l_prof_end4', 'p2l_prof_end5', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
     'p2l_sg2_pixelnorm_fwd', 'p2l_sg2_pixelnorm_bwd', 'p2l_sg2_bias_lrelu_fwd', 'p2l_sg2_lrelu_bwd',
     'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
     'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',

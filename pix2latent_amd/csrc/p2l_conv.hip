@@ -42,6 +42,8 @@
 #include "p2l_conv_k.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <cstddef>
 #include <array>
 #include <atomic>
 #include <cstdio>
@@ -833,6 +835,71 @@ __global__ __launch_bounds__(256) void conv_splitk_finish4(const ConvK k) {
   }
 }
 
+// The split-K finish of the direct / pointwise kernels with 16-byte accesses (round 4; the scalar kernel
+// above moves 64-byte segments: 2 TB/s on tensors of a few MB).  Item = one 2x2 quad x FOUR consecutive
+// channels; wave = 16 items x 4 z-parts, lane z sums slabs z, z+4, ... and the four partial sums meet in
+// the SAME fixed order ((z0 + z1) + (z2 + z3)): bit-identical sums.  The epilogue is the shared item
+// (epi_item), the maxima one partial per block of 64 items.
+__global__ __launch_bounds__(256) void conv_splitk_finish_v4(const ConvK k) {
+  const int Hh = k.H >> 1, Wh = k.W >> 1, C4 = k.n_store >> 2;
+  const size_t total = (size_t)k.B * Hh * Wh * C4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int zp = lane >> 4;
+  const size_t idx = ((size_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const bool live = idx < total;
+  const size_t id2 = live ? idx : 0;
+  const int n = (int)(id2 % C4) * 4;
+  size_t q = id2 / C4;
+  const int qx = (int)(q % Wh);
+  q /= Wh;
+  const int qy = (int)(q % Hh);
+  const int b = (int)(q / Hh);
+  const size_t mtot = (size_t)k.B * k.H * k.W;
+  f32x4 v[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const size_t pix = ((size_t)b * k.H + 2 * qy + (s >> 1)) * k.W + 2 * qx + (s & 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int zz = zp; zz < k.splitk; zz += 4)
+      acc += *reinterpret_cast<const f32x4*>(k.ws + ((size_t)zz * mtot + pix) * k.Cout + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[e];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      acc[e] = t;
+    }
+    v[s] = acc * k.alpha;
+  }
+  EpiSums S;
+  if (live && zp == 0) {
+    epi_item(k, v, b, 2 * qy, 2 * qx, n, 0, 0, 0, S);
+    if (k.arb_x != nullptr) {
+      const size_t po = ((size_t)b * k.arb_nblk + (size_t)qy * Wh + qx) * k.Cout + n;
+      *reinterpret_cast<f32x4*>(k.arb_partial + po) = S.sgx;
+      *reinterpret_cast<f32x4*>(k.arb_partial + (size_t)k.B * k.arb_nblk * k.Cout + po) = S.sg;
+    }
+  }
+  if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+    __shared__ float red[8];
+    float mx = S.amax, mxp = S.amaxp;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mxp = fmaxf(mxp, __shfl_xor(mxp, o, 64)); }
+    if (lane == 0) { red[wave] = mx; red[4 + wave] = mxp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const size_t first = (size_t)blockIdx.x * 64;                // first item of the block
+      const size_t per_image = (size_t)Hh * Wh * C4;
+      if (first < total) {
+        const size_t bb = first / per_image;
+        const size_t slot = bb * k.amax_out_n + (first - bb * per_image) / 64;
+        if (k.amax_out != nullptr) k.amax_out[slot] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (k.amax_outp != nullptr) k.amax_outp[slot] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+      }
+    }
+  }
+}
+
 // src is OIHW [O][I][taps].  flip=0 packs the conv I->O (K=I, N=O); flip=1 packs
 // its input-gradient conv O->I (K=O, N=I, taps mirrored).
 // bf16x3 packed element: row (idx / 16) holds [x1 k0-15 | x2 k0-15 | x3 k0-15] (96 bytes)
@@ -1014,10 +1081,11 @@ static bool wino_shape(const P2LConv* d) {
   return s > 1 && d->splitk == s;
 }
 
-// bf16x3 form of the 1x1 conv (p2l_pw.hip): weights carry the pre-split image
-// (P2L_WFMT_PW), whole 128-pixel tiles of one image, 64-channel stages and tiles.  Like the
-// Winograd form a function of the layer shape only; the 4^2 .. 16^2 layers stay on the
-// exact-fp32 kernel (split-K regime).  P2L_FORM_NO_PW keeps the exact-fp32 kernel.
+// full-tile form of the 1x1 conv on the 16-bit pipe (p2l_pw.hip: bf16 x 3, or fp16 x 2 when the
+// launch gets maxima): weights carry the pre-split images (P2L_WFMT_PW), whole 128-pixel tiles of one
+// image, 64-channel tiles.  Like the Winograd form a function of the layer shape only; the 4^2 ..
+// 16^2 layers take the small-grid fp16 x 2 form of the same kernel (pw_small_h2 below: multi-image
+// tiles, split-K slices).  P2L_FORM_NO_PW keeps the exact-fp32 kernel.
 static bool pw_shape(const P2LConv* d) {
   if ((d->form & P2L_FORM_NO_PW) || d->wfmt != P2L_WFMT_PW || d->taps != 1 || d->ups != 0) return false;
   if (d->Cin % 64 || d->Cout % 64 || d->x_ld % 4 || d->H % 8 || d->W % 16) return false;
@@ -1116,25 +1184,43 @@ int launch_conv(const ConvK& k, int pro, int ups, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+// K slices of a launch of the direct / pointwise kernels: a function of the LAYER SHAPE only (round 5).
+// Until round 4 the factor followed the grid (cdiv(512, blocks), blocks ~ batch), so the fp32 summation
+// order of the 4^2 ... 16^2 layers -- and with it a candidate's low bits -- depended on how many others
+// shared its launch: an 8-GPU run (2-3 local candidates) did not reproduce a 1-GPU run's bits.  Measured
+// per shape and local batch (tools/splitk_sweep.py -> profiles/round5_splitk_sweep.txt: conv + finish
+// kernel, 13 shapes x batches 2 ... 18 x every slice count) ONE count per shape is within 0-4 % of the
+// best count of every batch and better than the old grid rule from 3 candidates up (sum over the 13
+// shapes at 2 / 3 / 5 / 9 / 18 candidates: 256 / 269 / 306 / 377 / 519 us, old rule 255 / 275 / 322 /
+// 378 / 519): a slice must be worth its share of the finish launch, and more slices than ~64 blocks per
+// image only add partial-sum traffic.
+//   work term:  Cin * taps / 128   (>= 4 pointwise stages, >= 1.8 3x3 chunks per slice)
+//   grid term:  64 blocks per image:  64 / (H W / 128 * Cout / 64)
+//   at most 8 slices, 4 where an image has several tiles (H W >= 256); 2 slices never pay: 1
+static int p2f(long v) { int p = 1; while (2L * p <= v) p <<= 1; return p; }
+static int direct_split(const P2LConv* d) {
+  const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
+  const int nchunks = d->Cin / kc;
+  const long hw = (long)d->H * d->W;
+  int s = p2f((long)d->Cin * d->taps / 128);
+  const int g = p2f(524288L / (hw * d->Cout > 0 ? hw * d->Cout : 1));
+  if (g < s) s = g;
+  const int cap = hw >= 256 ? 4 : 8;
+  if (s > cap) s = cap;
+  // keep >= 2 chunks of work per slice for 3x3 (18 tap-chunks), >= 4 for 1x1
+  const int min_chunks = (d->taps == 9) ? 2 : 4;
+  while (s > 1 && nchunks / s < min_chunks) s >>= 1;
+  return s <= 2 ? 1 : s;
+}
+
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
-  if (d->ups >= 2) return 1;             // sub-pixel modes never split K
+  if (!d || d->ups >= 2) return 1;       // sub-pixel modes never split K
   if (choose_tile(d, k) == P2L_OK && wino_split(d) > 1 && !(d->form & P2L_FORM_WINO_ANY) &&
       (d->H / 8) * (d->W / 16) * (d->Cout / 64) < 64)
     return wino_split(d);                // small-grid Winograd layer: a function of the shape only
-  if (choose_tile(d, k) != P2L_OK || wino_shape(d) || pw_any(d)) return 1;
-  const int bn = choose_bn(d, k.n_mtiles);
-  const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
-  const int nblk = k.n_mtiles * (d->Cout / bn);
-  const int nchunks = d->Cin / kc;
-  if (nblk >= 192) return 1;   // (splitting the 192...255-block launches too measured slower)
-  int s = cdiv(512, nblk);
-  // keep >= 2 chunks of work per split for 3x3 (18 tap-chunks), >= 4 for 1x1
-  const int min_chunks = (d->taps == 9) ? 2 : 4;
-  if (s > nchunks / min_chunks) s = nchunks / min_chunks;
-  if (s > 32) s = 32;
-  if (s < 1) s = 1;
-  return s;
+  if (choose_tile(d, k) != P2L_OK || k.partial || wino_shape(d) || pw_any(d)) return 1;
+  return direct_split(d);
 }
 
 // the 16x16 Winograd kernel in the fp16 x 2 arithmetic: 64 partial maxima per image in front of
@@ -1146,9 +1232,19 @@ static bool wino_h2(const P2LConv* d) {
 // P2LAmax producers: launches whose blocks each cover one tile of ONE image and end in the shared
 // epilogue -- the unsplit 16x16 Winograd kernel (16x16 pixels x 64 channels) and the kernels that
 // go through epilogue_vec (direct 3x3, sub-pixel forward: 4 phases, 1x1 in both arithmetics:
-// 128 pixels x 32 / 64 channels); every WAVE of a block writes its own partial.  Split-K launches (finish kernel), the 8x16 Winograd kernel, the
-// three-channel image kernels and tiles that span images write none.
+// 128 pixels x 32 / 64 channels); every WAVE of a block writes its own partial.  Split-K launches leave
+// theirs through the finish kernel (one per 64 items).  The 8x16 Winograd kernel, the thin-output
+// image kernel and unsplit tiles that span images write none.
 static int effective_splitk(const P2LConv* d);
+// the 16-byte finish kernel of a split-K launch: every pitch it touches a multiple of four floats
+// (descriptor only: p2l_conv_amax_slots and the launch must agree)
+static bool finish_v4_ok(const P2LConv* d) {
+#ifdef P2L_AB_SCALAR_FINISH           // (A/B build: the 4-byte finish kernel for every split-K launch)
+  return false;
+#endif
+  return d->n_store % 4 == 0 && d->Cout % 4 == 0 && d->y_ld % 4 == 0 && d->yp_ld % 4 == 0 &&
+         d->res_ld % 4 == 0 && d->mask_ld % 4 == 0;
+}
 extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
   if (!d) return 0;
   if (wino_shape(d)) {
@@ -1162,10 +1258,11 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
   if (effective_splitk(d) > 1) {
-    // split-K launch of the direct kernels: the scalar finish kernel writes the tensor, one partial
-    // per block of 64 (quad, channel) items -- when a block never straddles two images.  (The
-    // hand-over thereby follows the LAYER, not the split-K choice a batch size brings with it.)
-    const int per_image = (d->H / 2) * (d->W / 2) * d->n_store;
+    // split-K launch of the direct kernels: a finish kernel writes the tensor, one partial per block of
+    // 64 items -- (quad, 4 channels) for the 16-byte kernel, (quad, channel) for the scalar one -- when
+    // a block never straddles two images.  (The hand-over thereby follows the LAYER, not the split-K
+    // choice a batch size brings with it.)
+    const int per_image = (d->H / 2) * (d->W / 2) * (finish_v4_ok(d) ? d->n_store / 4 : d->n_store);
     return (per_image % 64 == 0) ? per_image / 64 : 0;
   }
   ConvK k{};
@@ -1175,7 +1272,15 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     const bool geom = k.tw_log == 4 && k.th_log == 3;
     return (tm == 1 && geom) ? k.tiles_x * k.tiles_y * 4 : 0;
   }
+  // (both pointwise forms tile 64 output channels whatever choose_bn says for the grid.  Until round 5
+  //  the small-grid form was counted with choose_bn's 32 where the grid made it say so -- 16^2 256->1024 at
+  //  9 and 18 candidates: twice the slots its blocks write, the reader took the maximum over stale ring
+  //  contents as well and an image's power of two followed what had used the ring set before.)
+#ifdef P2L_AB_PW_SLOTS_R4             // (A/B build: the round-4 count, for the test that has to fail on it)
   const int nnt = pw_shape(d) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
+#else
+  const int nnt = (pw_shape(d) || pw_small_h2(d)) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
+#endif
   return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1) * 4;
 }
 extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
@@ -1290,6 +1395,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
     int nslots = (am && (am->out || am->outp)) ? p2l_conv_amax_slots(d) : 0;
     if (thin_shape(d) >= 0 && ex && (ex->oscale || ex->noise)) nslots = 0;   // (generic kernel then)
+    // (the slot count was promised for the fp16 x 2 small-grid pointwise kernel: 64-channel tiles)
+    if (nslots > 0 && h2_pw_small && !use_h2 && effective_splitk(d) <= 1) return P2L_EWS;
     if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
     if (nslots > 0 && am->out && am->next_s && am->next_t && !arb) {
       k.amax_ps = am->next_s; k.amax_pt = am->next_t; k.amax_pbstride = am->next_bstride;
@@ -1567,9 +1674,15 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   if (rc) return rc;
   if (k.splitk > 1) {
-    const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
-    hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0,
-                       st, k);
+    const bool arb_al = !arb || (k.arb_x_ld % 4 == 0 && (!k.arb_skip || k.arb_skip_ld % 4 == 0));
+    if (finish_v4_ok(d) && !arb_al) return P2L_EINVAL;   // (the maxima slots were sized for the 16-byte kernel)
+    if (finish_v4_ok(d)) {
+      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * (k.n_store >> 2);
+      hipLaunchKernelGGL(conv_splitk_finish_v4, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+    } else {
+      const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
+      hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+    }
     rc = p2l_check_launch();
   }
   if (prof_slot >= 0) (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
@@ -1718,29 +1831,14 @@ extern "C" int p2l_prof_step(int step, int period) {
   return P2L_OK;
 }
 
-extern "C" int p2l_prof_end(double flops[2], double ms[2], int32_t count[2]) {
-  return p2l_prof_end2(flops, ms, count, nullptr);
-}
-
-extern "C" int p2l_prof_end2(double flops[2], double ms[2], int32_t count[2], double bytes[2]) {
-  return p2l_prof_end3(flops, ms, count, bytes, nullptr);
-}
-
-extern "C" int p2l_prof_end3(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                             double exec_flops[2]) {
-  return p2l_prof_end4(flops, ms, count, bytes, exec_flops, nullptr);
-}
-
-extern "C" int p2l_prof_end4(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                             double exec_flops[2], double mfma_flops[2]) {
-  return p2l_prof_end5(flops, ms, count, bytes, exec_flops, mfma_flops, nullptr);
-}
-
-extern "C" int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], double bytes[2],
-                             double exec_flops[2], double mfma_flops[2], double write_bytes[2]) {
-  if (write_bytes) write_bytes[0] = write_bytes[1] = 0.0;
-  if (exec_flops) exec_flops[0] = exec_flops[1] = 0.0;
-  if (mfma_flops) mfma_flops[0] = mfma_flops[1] = 0.0;
+extern "C" int p2l_prof_end(P2LProfTotals* out) {
+  // the caller's struct may be older (shorter) than this library's: totals are gathered in a full one
+  // and the leading out->size bytes are copied back
+  if (!out || out->size < offsetof(P2LProfTotals, flops)) return P2L_EINVAL;
+  P2LProfTotals T{};
+  double *flops = T.flops, *ms = T.ms, *bytes = T.bytes, *exec_flops = T.exec_flops,
+         *mfma_flops = T.mfma_flops, *write_bytes = T.write_bytes;
+  int32_t* count = T.count;
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = false;
   flops[0] = flops[1] = ms[0] = ms[1] = 0.0;
@@ -1769,6 +1867,9 @@ extern "C" int p2l_prof_end5(double flops[2], double ms[2], int32_t count[2], do
   }
   if (dump) fclose(dump);
   g_prof.n = 0;
+  const uint32_t n = out->size < sizeof(T) ? out->size : (uint32_t)sizeof(T);
+  T.size = n;
+  memcpy(out, &T, n);
   return P2L_OK;
 }
 

@@ -212,7 +212,9 @@ int launch_gemm(const GemmK& g, int akm, int bkm, int batch, hipStream_t st) {
 static int gemm_suggest_split(const P2LGemm* d) {
   if (!d || d->M % 128 || d->N % 32 || d->K < 1024) return 1;
   const int bn = (d->N % 64 == 0) ? 64 : 32;
-  const int blocks = (d->M / 128) * (d->N / bn) * d->batch;
+  // (counted for a reference batch of 4, NOT d->batch: the slice count -- hence the fp32 summation order
+  //  of an image's product -- must not depend on how many images share the launch; round 5)
+  const int blocks = (d->M / 128) * (d->N / bn) * 4;
   if (blocks >= 192) return 1;
   int s = cdiv(512, blocks);
   if (s > d->K / 256) s = d->K / 256;      // >= 16 chunks per slice

@@ -510,6 +510,15 @@ extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Li
     shape[3] = what == 8 ? m->attn_ch / 8 : m->attn_ch / 2;
     return P2L_OK;
   }
+  if (what == 10) {  // the shared split-K workspace (whatever launch used it last)
+    *float_off = L.skws; shape[0] = 1; shape[1] = 1; shape[2] = 1; shape[3] = (int32_t)L.skws_floats;
+    return P2L_OK;
+  }
+  if (what == 11) {  // the maxima ring: NSETS sets of [B][slots per image]
+    *float_off = L.amax_ring; shape[0] = AmaxReg::NSETS; shape[1] = 1; shape[2] = 1;
+    shape[3] = (int32_t)L.amax_set_floats;
+    return P2L_OK;
+  }
   if (what != 0) return P2L_EINVAL;
   // ModuleList index -> block index (SelfAttn occupies index attn_before)
   int idx = 0;

@@ -21,10 +21,14 @@ def lib():
     return N.lib()
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, 'include', 'p2l.h')).read()
-    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(p2l_[a-z0-9_]+)\s*\(', txt)))
+def header_symbols(names=('p2l.h', 'p2l_test.h')):
+    """every function the boundary header (p2l.h) and the test-hook header (p2l_test.h) declare"""
+    out = set()
+    for name in names:
+        txt = open(os.path.join(ROOT, 'include', name)).read()
+        txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+        out |= set(re.findall(r'\b(p2l_[a-z0-9_]+)\s*\(', txt))
+    return sorted(out)
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -34,6 +38,11 @@ def test_every_declared_symbol_is_exported(lib):
     for s in syms:
         assert hasattr(lib, s), 'libp2l_hip.so does not export %s' % s
     assert sorted(N.EXPORTS) == syms, set(N.EXPORTS) ^ set(syms)
+    # the test hooks live in their own header: the drop-in boundary declares none of them
+    hooks = header_symbols(('p2l_test.h',))
+    assert hooks == sorted(['p2l_selftest_amaxreg', 'p2l_biggan_ws_lookup', 'p2l_projloss_ws_lookup', 'p2l_mfma_probe'])
+    assert not set(hooks) & set(header_symbols(('p2l.h',)))
+    assert len([s for s in syms if s.startswith('p2l_prof_end')]) == 1       # one signature, sized struct
 
 
 def test_version_and_errors(lib):
@@ -58,6 +67,7 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
         'P2LArb': ['x', 'x_ld', 's', 't', 'st_bstride', 'skip', 'skip_ld', 'skip_C', 'skip_ups', 'ds', 'dt',
                    'dsdt_bstride', 'partial', 'nomask', 'amax'],
         'P2LConv': ['wfmt', 'form', 'algo_flops'],
+        'P2LProfTotals': ['size', 'count', 'flops', 'ms', 'bytes', 'exec_flops', 'mfma_flops', 'write_bytes'],
     }
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "p2l.h"', 'int main(void) {']
     for st, ms in members.items():
@@ -77,6 +87,21 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
         for m in ms:
             f = getattr(ct, 'in_' if m == 'in' else m)
             assert int(got['%s.%s' % (st, m)]) == f.offset, (st, m)
+
+
+def test_prof_end_fills_what_fits(lib):
+    """one p2l_prof_end for every generation of callers: the library writes the leading `size` bytes of
+    its totals and nothing behind them; a struct too short for the counts is refused"""
+    from pix2latent_amd import _native as N
+    t = N.P2LProfTotals()                            # (nothing was timed: no device needed)
+    t.size = N.P2LProfTotals.bytes.offset            # a caller compiled before `bytes` existed
+    t.bytes[0] = t.write_bytes[1] = -7.0
+    assert lib.p2l_prof_end(C.byref(t)) == 0
+    assert t.size == N.P2LProfTotals.bytes.offset and t.count[0] == 0 and t.ms[1] == 0.0
+    assert t.bytes[0] == -7.0 and t.write_bytes[1] == -7.0
+    t.size = 8
+    assert lib.p2l_prof_end(C.byref(t)) == -1
+    assert lib.p2l_prof_end(None) == -1
 
 
 def test_maxima_registry_rules(lib):
@@ -105,12 +130,39 @@ def test_host_side_planning_calls(lib):
     d.B, d.H, d.W, d.Cin, d.Cout, d.taps = 9, 4, 4, 512, 512, 9
     d.splitk = 1
     s = lib.p2l_conv_suggest_splitk(C.byref(d))
-    assert 1 < s <= 32                       # 4x4 layers must split K to fill the chip
+    assert 1 < s <= 32                       # 4x4 layers split K (shape-only rule: 8 slices)
     d.splitk = s
     assert lib.p2l_conv_workspace_bytes(C.byref(d)) == s * 9 * 16 * 512 * 4
     d.H = d.W = 256
     d.Cin = d.Cout = 64
     assert lib.p2l_conv_suggest_splitk(C.byref(d)) == 1
+    # the slice count follows the LAYER, never the batch (round 5: a candidate's bits must not depend on
+    # how many others share its launch -- 1 GPU x 18 vs 8 GPUs x 2-3): every conv shape of BigGAN-deep-256,
+    # VGG16 and StyleGAN2, both weight formats, forward and gradient orientation
+    shapes = set()
+    for H, cin, cout in ((4, 2048, 2048), (8, 2048, 2048), (16, 2048, 1024), (16, 1024, 1024),
+                         (32, 1024, 1024), (64, 1024, 512), (64, 512, 512), (128, 512, 256),
+                         (128, 256, 256), (256, 256, 128)):
+        mid = cin // 4
+        for hh in (H, max(4, H // 2)):
+            shapes |= {(1, hh, cin, mid), (1, hh, mid, cin), (9, hh, mid, mid), (1, hh, mid, cout), (1, hh, cout, mid)}
+    for H, c in ((256, 64), (128, 128), (64, 256), (32, 512), (16, 512), (4, 512), (8, 512)):
+        shapes |= {(9, H, c, c), (9, H, c, max(c // 2, 32)), (9, H, max(c // 2, 32), c)}
+    n_split = 0
+    for taps, H, cin, cout in sorted(shapes):
+        for ups in (0, 1):
+            if ups and taps == 1:
+                continue
+            got = set()
+            for B in (1, 2, 3, 5, 9, 18, 22, 32):
+                d = N.P2LConv()
+                d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.ups = B, H, H, cin, cout, taps, ups
+                d.wfmt = 2 if taps == 9 else 3
+                d.x_ld, d.n_store, d.y_ld = cin, cout, cout
+                got.add(lib.p2l_conv_suggest_splitk(C.byref(d)))
+            assert len(got) == 1, ((taps, H, cin, cout, ups), got)
+            n_split += got.pop() > 1
+    assert n_split >= 10
     assert lib.p2l_projloss_ws_bytes(2, 256, 256) > 0
     assert lib.p2l_projloss_ws_bytes(2, 100, 100) == 0          # not a power of two
     # invalid arguments are rejected before any launch

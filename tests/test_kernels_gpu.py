@@ -556,8 +556,8 @@ def test_two_host_threads_two_streams_bit_identical(dev, O):
         t.start()
     for t in th:
         t.join()
-    f, m, c = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
-    N.check(N.lib().p2l_prof_end(f, m, c), 'prof_end')
+    T = N.prof_end()
+    f, m, c = T.flops, T.ms, T.count
     assert not errors, errors
     assert c[0] + c[1] == 2 * 20 * len(cases)
     for name in ('a', 'b'):
@@ -651,8 +651,8 @@ def test_conv_profiler_sampling(dev, O):
         for _ in range(8):
             O.conv(x, w, 1, 16, 16, 32, 32, 1)
     torch.cuda.synchronize()
-    f, m, c = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)()
-    N.check(lib.p2l_prof_end(f, m, c), 'prof_end')
+    T = N.prof_end()
+    f, m, c = T.flops, T.ms, T.count
     assert c[1] == 8 and c[0] == 0          # 4 steps x 8 launches, every 4th timed
     assert m[1] > 0 and f[1] == 8 * 2.0 * 16 * 16 * 32 * 32
 
@@ -1069,11 +1069,9 @@ def _mfma_products(N, fn):
     lib.p2l_prof_step(0, 1)
     out = fn()
     torch.cuda.synchronize()
-    arr = [(C.c_double * 2)() for _ in range(5)]
-    cnt = (C.c_int32 * 2)()
-    N.check(lib.p2l_prof_end4(arr[0], arr[1], cnt, arr[2], arr[3], arr[4]), 'p2l_prof_end4')
-    assert cnt[0] >= 1
-    return out, arr[4][0] / arr[3][0]
+    T = N.prof_end()
+    assert T.count[0] >= 1
+    return out, T.mfma_flops[0] / T.exec_flops[0]
 
 
 H2_DIRECT_CASES = [
@@ -1257,10 +1255,8 @@ def test_pointwise_small_grid_fp16x2(dev, O, case):
         lib.p2l_prof_step(0, 1)
         out = fn()
         torch.cuda.synchronize()
-        arr = [(C.c_double * 2)() for _ in range(5)]
-        cnt = (C.c_int32 * 2)()
-        N.check(lib.p2l_prof_end4(arr[0], arr[1], cnt, arr[2], arr[3], arr[4]), 'p2l_prof_end4')
-        return out, arr[4][1] / arr[3][1]
+        T = N.prof_end()
+        return out, T.mfma_flops[1] / T.exec_flops[1]
 
     O.DEFAULT_FORM = N.FORM_AUTO
     (y, _), mm = products(lambda: O.conv(xs, wp, B, H, H, Cin, Cout, 1, **kw))
@@ -1289,3 +1285,38 @@ def test_pointwise_small_grid_fp16x2(dev, O, case):
     ya, _ = O.conv(xs, wp, B, H, H, Cin, Cout, 1, **dict(kw, splitk=sk))
     y1, _ = O.conv(xs[1:2].contiguous(), wp, 1, H, H, Cin, Cout, 1, **kw1)
     assert torch.equal(y1[0], ya[1]), 'result depends on the batch composition'
+
+
+AMAX_SLOT_CASES = [
+    # taps, B, H, Cin, Cout, wfmt  (the launches of a BigGAN / VGG step that leave maxima, at the batch
+    # sizes whose grids make choose_bn pick 32-channel tiles: 9 and 18 candidates)
+    (1, 9, 16, 256, 1024, 3),      # small-grid pointwise kernel, unsplit (the round-5 finding)
+    (1, 18, 16, 256, 1024, 3),
+    (1, 2, 16, 256, 1024, 3),      # ... in split-K slices (finish kernel)
+    (1, 9, 8, 512, 2048, 3),
+    (1, 3, 32, 256, 1024, 3),      # full-tile pointwise kernel
+    (9, 9, 16, 256, 256, 2),       # direct 3x3, split-K
+    (9, 9, 64, 64, 64, 2),         # direct 3x3, one image per tile
+    (9, 5, 32, 128, 96, 2),        # ... 32-channel tiles
+    (9, 2, 32, 256, 256, 2),       # Winograd in K slices
+    (9, 2, 64, 128, 128, 2),       # Winograd
+]
+
+
+@pytest.mark.parametrize('case', AMAX_SLOT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_every_promised_maxima_slot_is_written(dev, O, case):
+    """P2LAmax: the reader of a tensor takes its power of two from ALL p2l_conv_amax_slots(d) partial maxima
+    per image, so the launch has to write every one of them (round 5: the small-grid pointwise kernel wrote
+    half of what was promised where choose_bn said 32 -- the other half was whatever the ring set held
+    before, and the first re-score after an optimising step differed from the following ones by an ulp)."""
+    from pix2latent_amd import _native as N
+    taps, B, H, Cin, Cout, wfmt = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) / math.sqrt(taps * Cin)
+    wp = O.pack_conv_weight(w.to(dev), taps, Cout, Cin, wfmt=wfmt)
+    O.DEFAULT_FORM = N.FORM_AUTO
+    y, _, (am, _) = O.conv(nhwc(x, dev), wp, B, H, H, Cin, Cout, taps, wfmt=wfmt, want_amax=True)
+    assert am is not None, 'this launch was expected to leave maxima'
+    assert bool((am >= 0).all()), '%d of %d promised slots were not written' % (int((am < 0).sum()), am.numel())
+    assert torch.equal(am.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))

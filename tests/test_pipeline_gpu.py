@@ -363,7 +363,7 @@ def test_random_hook_under_graph_replay_draws_fresh_noise(dev):
 def test_launch_profiler_survives_graph_capture(dev):
     """bench.py's per-launch profiler next to the automatic HIP-graph execution of small local
     batches (what one rank of a 4- or 8-GPU job runs): event pairs must not be recorded into a
-    capture -- they could never be read back and p2l_prof_end3 failed for every rank -- and the
+    capture -- they could never be read back and p2l_prof_end failed for every rank -- and the
     eager steps before the capture are still timed"""
     import ctypes as C
     from pix2latent_amd import _native as N
@@ -378,8 +378,7 @@ def test_launch_profiler_survives_graph_capture(dev):
         lib.p2l_prof_step(i, 1)
         opt.step(variables, optimize=True, transform=(i == 0))
     torch.cuda.synchronize()
-    f, m, c, b, x = ((C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)(),
-                     (C.c_double * 2)())
-    N.check(lib.p2l_prof_end3(f, m, c, b, x), 'p2l_prof_end3')
+    T = N.prof_end()
+    f, m, c, b, x = T.flops, T.ms, T.count, T.bytes, T.exec_flops
     assert any(isinstance(v, tuple) for v in opt._graphs.values()), 'no graph was captured'
     assert c[0] > 0 and m[0] > 0.0           # the eager steps were timed

@@ -40,11 +40,10 @@ def test_full_population_18_ranks_like_the_oracle(dev):
         scored[ebs] = (asked, np.array(losses, dtype=np.float64))
     assert torch.equal(scored[18][0], scored[None][0])
     assert scored[18][0].shape == (18, 128)
-    # chunks of 9 vs one pass of 18: the 4^2 ... 16^2 layers pick their split-K factor from the grid
-    # size, i.e. the fp32 summation order of those layers follows the chunk -- same values to
-    # rounding, same order
-    assert np.abs(scored[18][1] - scored[None][1]).max() < 1e-5
-    assert np.array_equal(np.argsort(scored[18][1]), np.argsort(scored[None][1]))
+    # chunks of 9 vs one pass of 18: the same BITS (round 5: the split-K factor of the 4^2 ... 16^2 layers
+    # is a function of the layer shape, no longer of the grid size; tests/test_shard_bits_gpu.py has the
+    # 2- and 4-rank runs with Adam steps)
+    assert np.array_equal(scored[18][1], scored[None][1]), np.abs(scored[18][1] - scored[None][1]).max()
     z = scored[18][0].clamp(-2.0, 2.0)           # (the Clamp hook runs on a re-score too)
     c = c_default.unsqueeze(0).repeat(18, 1)
     ref = []

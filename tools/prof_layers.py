@@ -48,8 +48,8 @@ def main():
         opt.step(variables, optimize=True)
     torch.cuda.synchronize()
     step_ms = (time.perf_counter() - t0) / steps * 1e3
-    f, m, c, b = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)()
-    N.check(lib.p2l_prof_end2(f, m, c, b), 'prof_end2')
+    T = N.prof_end()
+f, m, c, b = T.flops, T.ms, T.count, T.bytes
     lib.p2l_prof_dump(None)
     rows = collections.OrderedDict()
     for line in open(DUMP):

@@ -52,8 +52,8 @@ for _ in range(K):
     opt.step(variables, optimize=True)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
-f, m, c, b = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int32 * 2)(), (C.c_double * 2)()
-N.check(lib.p2l_prof_end2(f, m, c, b), 'prof_end2')
+T = N.prof_end()
+f, m, c, b = T.flops, T.ms, T.count, T.bytes
 lib.p2l_prof_dump(None)
 head = 'StyleGAN2 %s %d^2, %d candidates: %.2f ms/step = %.1f evals/s (with the per-launch profiler)' % (
     'cars' if cfg == 'c4' else 'ffhq', size, n, ms, n / ms * 1e3)
