@@ -725,16 +725,20 @@ int run_core(const AttnK& a, hipStream_t st) {
 
 // slices of the query range in the d(values) form: 8 row blocks x 2 halves per sample alone
 // leave most of the chip idle
+// (counted for a REFERENCE batch, not d->B: the slices are summed in a fixed order that follows their
+//  count, and an image's gradient must not depend on how many images share the launch -- round 5;
+//  until then 18 / 9 / 2 candidates ran 4 / 8 / 8 slices here and 2 / 4 / 8 in the d(queries) form)
+constexpr int AT_REF_B_DV = 18, AT_REF_B_APPLY = 9;
 int dv_tsplit(const P2LAttn* d) {
   int s = 1;
-  while (s < 8 && (long)d->B * (d->Nk >> 7) * 2 * s < 1024 && (d->Nq >> 5) % (2 * s) == 0) s *= 2;
+  while (s < 8 && (long)AT_REF_B_DV * (d->Nk >> 7) * 2 * s < 1024 && (d->Nq >> 5) % (2 * s) == 0) s *= 2;
   return s;
 }
 
 // slices of the streamed range when 128-row blocks alone do not fill the chip
-int apply_tsplit(int B, int NR, int NT) {
+int apply_tsplit(int /*B*/, int NR, int NT) {
   int s = 1;
-  while (s < 8 && (long)B * (NR >> 7) * s < 1024 && NT % (2 * s) == 0) s *= 2;
+  while (s < 8 && (long)AT_REF_B_APPLY * (NR >> 7) * s < 1024 && NT % (2 * s) == 0) s *= 2;
   return s;
 }
 

@@ -339,15 +339,32 @@ __device__ __forceinline__ void epi_item(const ConvK& k, f32x4 (&v)[4], int b, i
 // ((image * arb_nblk + tile) of the 128-pixel tiling the caller sized the buffer for).
 template <int COLS, int C4>
 __device__ __forceinline__ void epi_arb_reduce(const ConvK& k, EpiSums& S, float* smem, int wave,
-                                               int lane, int tid, size_t slot, int n0) {
+                                               int lane, int tid, size_t slot, int n0,
+                                               const EpiSums* S2 = nullptr) {
+  // The 8 quads of a wave meet in ONE tree whatever the channel width of the tile: q ^ 1, then q ^ 2,
+  // then q ^ 4.  A 32-channel tile (C4 = 8) holds one quad per lane: shuffles 8, 16, 32.  A 64-channel
+  // tile (C4 = 16) holds quads q and q + 4 in one lane (S and *S2, kept apart by epilogue_vec): each is
+  // reduced over q ^ 1, q ^ 2 (shuffles 16, 32) and the two meet last.  Until round 5 the second quad
+  // was added onto the first pixel by pixel -- another order, an ulp apart -- and 32 vs 64 channels is
+  // chosen from the GRID, i.e. from the batch: d s / d t of the 64-channel layers and of the sub-pixel
+  // gradients depended on who shared the launch.
   f32x4 sgx = S.sgx, sg = S.sg;
+  f32x4 sgx2 = {0, 0, 0, 0}, sg2 = {0, 0, 0, 0};
+  if (C4 == 16 && S2 != nullptr) { sgx2 = S2->sgx; sg2 = S2->sg; }
 #pragma unroll
   for (int o = C4; o < 64; o <<= 1) {
     sgx.x += __shfl_xor(sgx.x, o, 64); sgx.y += __shfl_xor(sgx.y, o, 64);
     sgx.z += __shfl_xor(sgx.z, o, 64); sgx.w += __shfl_xor(sgx.w, o, 64);
     sg.x += __shfl_xor(sg.x, o, 64); sg.y += __shfl_xor(sg.y, o, 64);
     sg.z += __shfl_xor(sg.z, o, 64); sg.w += __shfl_xor(sg.w, o, 64);
+    if (C4 == 16 && S2 != nullptr) {
+      sgx2.x += __shfl_xor(sgx2.x, o, 64); sgx2.y += __shfl_xor(sgx2.y, o, 64);
+      sgx2.z += __shfl_xor(sgx2.z, o, 64); sgx2.w += __shfl_xor(sgx2.w, o, 64);
+      sg2.x += __shfl_xor(sg2.x, o, 64); sg2.y += __shfl_xor(sg2.y, o, 64);
+      sg2.z += __shfl_xor(sg2.z, o, 64); sg2.w += __shfl_xor(sg2.w, o, 64);
+    }
   }
+  if (C4 == 16 && S2 != nullptr) { sgx = sgx + sgx2; sg = sg + sg2; }
   __syncthreads();                      // everyone is done reading the tile dumps
   float* red = smem;                    // [2][4 waves][COLS]
   if (lane < C4 && wave < 4) {
@@ -391,9 +408,10 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
   __syncthreads();
 
   const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
-  EpiSums S;
+  EpiSums S, S2;                           // S2: the second quad of a lane (64-channel tiles), see epi_arb_reduce
 #pragma unroll
   for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+    EpiSums& Sx = (it0 == 0) ? S : S2;
     const int it = it0 + lane;
     const int q = it / C4, c4 = it - q * C4;
     const int n = n0 + c4 * 4;
@@ -406,11 +424,13 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       v[s] = *reinterpret_cast<const f32x4*>(tb + (4 * q + s) * EP + c4 * 4) * k.alpha;
-    epi_item(k, v, b, oy0, ox0, n, osh, ph_y, ph_x, S);
+    epi_item(k, v, b, oy0, ox0, n, osh, ph_y, ph_x, Sx);
   }
+  static_assert(ITEMS == 64 || ITEMS == 128, "one or two items per lane");
   if (k.arb_x != nullptr)
     epi_arb_reduce<COLS, C4>(k, S, smem, wave, lane, threadIdx.x,
-                             (size_t)b0 * k.arb_nblk + tile_in_image, n0);
+                             (size_t)b0 * k.arb_nblk + tile_in_image, n0, &S2);
+  S.amax = fmaxf(S.amax, S2.amax); S.amaxp = fmaxf(S.amaxp, S2.amaxp);
   // this block's partial maxima of what it stored (one per wave), for the launch that reads the
   // tensor next (P2LAmax; the launcher only sets the pointers for tiles inside one image)
   if (k.amax_out != nullptr || k.amax_outp != nullptr) {
