@@ -22,6 +22,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -328,6 +329,71 @@ def extra_configs(dev, n_steps=3):
     return out
 
 
+def full_schedule_and_default_loss(dev, ms_per_step):
+    """Two side measurements of the headline problem, outside the timed region:
+
+    * `full_basincma_30x30_300`: ONE complete run of the schedule the reference's example hard-codes
+      (examples/invert_biggan_basincma.py:108-109: optimize(meta_steps=30, grad_steps=30,
+      last_grad_steps=300) = 1 200 inner steps = 21 600 candidate evals + 30 re-scores of 18), with
+      track() on as the reference has it (base_optimizer.py:100-107): wall seconds, evals/s over the
+      whole run, what a generation costs on top of its inner steps (ask, fresh variables + Adam state,
+      re-score, tell, tracking copies), and the mean loss the first `tell` saw next to the final one.
+    * `biggan_basincma_alex`: the same inner step with ProjectionLoss() as every unmodified example
+      constructs it (loss_functions.py:89: lpips_net='alex')."""
+    import contextlib
+    out = {}
+    with contextlib.redirect_stdout(sys.stderr):
+        torch.manual_seed(0)
+        opt, vm, _ = build_problem(dev, exec_batch_size=POP)
+        opt.show_iter = 10 ** 9
+        told = []
+        score = opt.losses_for_tell
+
+        def recording(variables):
+            t = score(variables)
+            told.append(float(np.mean(t)))
+            return t
+        opt.losses_for_tell = recording
+        opt.optimize(meta_steps=1, grad_steps=2, last_grad_steps=2)      # (warm-up: workspaces, caches)
+        del told[:]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, losses = opt.optimize(meta_steps=30, grad_steps=30, last_grad_steps=300)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        final = [float(x) for x in losses[-1][1]['loss']]
+        n_steps = 30 * 30 + 300
+        tracked = opt.tracked
+        assert len(told) == 30 and len(tracked['z']) >= n_steps, (len(told), len(tracked['z']))
+        assert np.mean(final) < told[0], 'the run did not reduce the loss (%g -> %g)' % (told[0], np.mean(final))
+        out['full_basincma_30x30_300'] = {
+            'what': 'opt.optimize(meta_steps=30, grad_steps=30, last_grad_steps=300) on the bench problem, '
+                    'track() on (reference examples/invert_biggan_basincma.py:102-109)',
+            'wall_s': round(wall, 3), 'inner_steps': n_steps, 'candidate_evals': POP * n_steps,
+            'rescored_candidates': POP * 30,
+            'evals_per_s_over_the_run': round(POP * n_steps / wall, 1),
+            'ms_per_step_of_the_timed_region': round(ms_per_step, 3),
+            'per_generation_overhead_ms': round((wall - n_steps * ms_per_step * 1e-3) / 30 * 1e3, 2),
+            'overhead_share_of_the_run': round((wall - n_steps * ms_per_step * 1e-3) / wall, 4),
+            'mean_loss_first_tell': round(told[0], 5), 'mean_loss_last_tell': round(told[-1], 5),
+            'mean_loss_final': round(float(np.mean(final)), 5), 'best_loss_final': round(min(final), 5),
+            'tracked_steps': len(tracked['z'])}
+        del opt, vm, tracked
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        opt, vm, _ = build_problem(dev, exec_batch_size=POP, lpips_net='alex')
+        opt.setup_cma(vm)
+        variables = opt.cma_init(vm)
+        dt = _time_steps(lambda first: opt.step(variables, optimize=True, transform=first), 3, 5)
+        losses = [float(x) for x in opt.loss]
+        assert all(l == l for l in losses)
+        out['biggan_basincma_alex'] = {
+            'what': 'the headline inner step with the examples\' default loss, ProjectionLoss(lpips_net=\'alex\') '
+                    '(reference loss_functions.py:89): L1 + 10*LPIPS-AlexNet',
+            'evals_per_s': round(POP / dt, 1), 'ms_per_step': round(1e3 * dt, 2), 'candidates': POP}
+    return out
+
+
 def exact_fp32_leg(dev, args):
     """evals/s of the same inner step with P2L_CONV_WFMT=f32 (outside the timed K steps)."""
     import contextlib
@@ -603,6 +669,10 @@ def main():
                 rec['config']['extra'] = extra_configs(dev)
             except Exception as e:          # the headline must not be lost to a side measurement
                 rec['config']['extra'] = {'error': repr(e)[:300]}
+            try:
+                rec['config']['extra'].update(full_schedule_and_default_loss(dev, 1e3 * elapsed / args.steps))
+            except Exception as e:
+                rec['config']['extra']['full_schedule_error'] = repr(e)[:300]
         if world == 1 and not args.no_cpu_baseline:
             rec['cpu_baseline'] = cpu_baseline(problem)
         print(json.dumps(rec), flush=True)

@@ -304,7 +304,12 @@ enum {
   P2L_FORM_WINO_8X16 = 4,    /* the 8x16-pixel Winograd kernel even where 16x16 fits (tests)   */
   P2L_FORM_NO_PW = 8,        /* P2L_WFMT_PW weights, but the exact-fp32 1x1 kernel             */
   P2L_FORM_NO_THIN = 16,     /* P2L_WFMT_BF16X3T weights, but the generic 3x3 kernel           */
-  P2L_FORM_WINO_BF3 = 32     /* bf16 x 3 arithmetic, not fp16 x 2: 16x16 Winograd and 1x1 kernels */
+  P2L_FORM_WINO_BF3 = 32,    /* bf16 x 3 arithmetic, not fp16 x 2: 16x16 Winograd and 1x1 kernels */
+  /* block shape of the fp16 x 2 Winograd kernel.  Default: 16x16-pixel blocks (8 waves), 8x16-pixel
+   * blocks (4 waves) while the launch has <= 128 blocks of 16x16 -- chosen from the grid, i.e. from the
+   * batch, which is allowed because the two shapes give bit-identical results and maxima slots.     */
+  P2L_FORM_WINO_H2_8X16 = 64,   /* always the 4-wave block (tests)                                   */
+  P2L_FORM_WINO_H2_16X16 = 128  /* always the 8-wave block (tests, A/B)                              */
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

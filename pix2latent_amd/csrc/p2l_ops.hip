@@ -738,6 +738,9 @@ __global__ void affine_grid_sample_kernel(const float* src, const float* theta, 
 // sampling position (ix, iy) lies in (sx-1, sx+1) x (sy-1, sy+1); that set is the pre-image of a
 // 2x2 box under the affine map, a parallelogram whose bounding box follows from the inverse of
 // theta's 2x2 part (the whole image when the map is singular).  Visited row-major: no atomics.
+// Cost: sum over source pixels of their box = H W C max(4, 4 / |det|) products -- fine for the scales a
+// transform search visits (|det| ~ 0.25 ... 4), quadratic in the image when a search drives the scale
+// towards 0 (the price of a fixed summation order; the reference's scatter-add is not reproducible).
 __global__ void affine_grid_sample_bwd_src_kernel(const float* dout, const float* theta, float* dsrc,
                                                   int Bn, int C, int H, int W) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -762,8 +765,11 @@ __global__ void affine_grid_sample_bwd_src_kernel(const float* dout, const float
       mnx = fminf(mnx, ox); mxx = fmaxf(mxx, ox); mny = fminf(mny, oy); mxy = fmaxf(mxy, oy);
     }
     // (one pixel of slack against rounding of the inverse; every candidate is re-tested below)
-    x_lo = max(0, (int)floorf(fmaxf(mnx, -1.f)) - 1); x_hi = min(W - 1, (int)ceilf(fminf(mxx, (float)W)) + 1);
-    y_lo = max(0, (int)floorf(fmaxf(mny, -1.f)) - 1); y_hi = min(H - 1, (int)ceilf(fminf(mxy, (float)H)) + 1);
+    // (clamped on BOTH sides before the int cast: a near-singular theta sends the corners to 1e30 or NaN,
+    //  and converting those is undefined; fminf / fmaxf drop a NaN operand)
+    const float Wf = (float)W + 2.f, Hf = (float)H + 2.f;
+    x_lo = max(0, (int)floorf(fminf(fmaxf(mnx, -2.f), Wf)) - 1); x_hi = min(W - 1, (int)ceilf(fmaxf(fminf(mxx, Wf), -2.f)) + 1);
+    y_lo = max(0, (int)floorf(fminf(fmaxf(mny, -2.f), Hf)) - 1); y_hi = min(H - 1, (int)ceilf(fmaxf(fminf(mxy, Hf), -2.f)) + 1);
   }
   for (int c = 0; c < C; ++c) {
     const float* g = dout + ((size_t)b * C + c) * H * W;

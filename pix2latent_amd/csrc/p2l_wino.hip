@@ -301,6 +301,8 @@ constexpr int W16_V_FLOATS = 16 * 64 * 16;                            // one buf
 constexpr size_t W16_LDS_BYTES = (size_t)(W16_RAW_FLOATS + 2 * W16_V_FLOATS) * sizeof(float);
 static_assert(W16_LDS_BYTES <= 160 * 1024, "one block per CU");
 static_assert(16 * 64 * WN_DUMP_PITCH <= 2 * W16_V_FLOATS, "epilogue dump fits");
+// the 4-wave block of the fp16 x 2 form (MT = 1): 10x18 patch rows, 32 tiles
+constexpr size_t W8_LDS_BYTES = (size_t)(10 * 18 * WN_RAW_PITCH + 2 * 16 * 32 * 16) * sizeof(float);
 
 // ---- 16x16-pixel blocks, hand-scheduled multiply phase ------------------------------------
 // Left to hipcc, a multiply step comes out as [read fragment | 36 VALU of the 3-way split | 12
@@ -360,11 +362,23 @@ struct TxTableH {
   }
 };
 constexpr TxTableH kTxH{};
-template <int PRO, int ABL = 0, bool H2 = false>
-__global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const ConvK k) {
+// MT = M-tiles of 32 quads per block: 2 = 16x16 pixels, 8 waves (wave w: frequencies 2w, 2w+1, both
+// M-tiles); 1 = 8x16 pixels, 4 waves (wave w: frequencies 4w .. 4w+3) -- round 5, the small-batch form
+// of the fp16 x 2 arithmetic: at 2-3 candidates per GPU a 32^2 / 64^2 layer is 48-128 blocks of 16x16 on
+// 256 CUs and the launch lasts one block's latency; halved blocks are twice as many and, with ONE wave per
+// SIMD instead of two sharing its issue slots, about half as long.  The launcher picks it from the grid
+// size.  Re-tiling along M changes no output's summation order: same transform, same products, same
+// chunk order, same partial sums per 8x16-pixel tile, same maxima slots -- bit-identical to the 16x16 form
+// (tests/test_kernels_gpu.py).  A step of the multiply phase is fragment (fi, m) = (s / MT, s % MT).
+template <int PRO, int ABL = 0, bool H2 = false, int MT = 2>
+__global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k) {
+  static_assert(MT == 2 || (MT == 1 && H2), "the 4-wave block exists in the fp16 x 2 arithmetic only");
+  constexpr int THREADS = 256 * MT, TILES = 32 * MT, NW = 4 * MT, NF = 4 / MT;
+  constexpr int RAW_ROWS = (8 * MT + 2) * 18, RAW_FLOATS = RAW_ROWS * WN_RAW_PITCH, V_FLOATS = 16 * TILES * 16;
+  constexpr int FV = TILES * 16;                         // floats of one frequency of V
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* raw = smem;
-  float* Vs = smem + W16_RAW_FLOATS;
+  float* Vs = smem + RAW_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,11 +386,11 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
 
   const int swz = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = swz / k.n_ntiles, nt = swz - mt * k.n_ntiles;
-  const int tiles_per_image = k.tiles_x * k.tiles_y;                  // 16x16-pixel tiles
+  const int tiles_per_image = k.tiles_x * k.tiles_y;                  // (8 MT)x16-pixel tiles
   const int b = __builtin_amdgcn_readfirstlane(mt / tiles_per_image);   // (scalar address bases)
   const int tile_in_image = mt - b * tiles_per_image;
   const int by = tile_in_image / k.tiles_x, bx = tile_in_image - by * k.tiles_x;
-  const int y0 = by * 16, x0 = bx * 16, n0 = __builtin_amdgcn_readfirstlane(nt * 64);
+  const int y0 = by * (8 * MT), x0 = bx * 16, n0 = __builtin_amdgcn_readfirstlane(nt * 64);
 
   // split-K (blockIdx.y = slice z of the input channels): chunks c_lo .. c_lo + nchunks - 1 of the
   // layer; the un-scaled partial outputs go to k.ws[z] and conv_splitk_finish adds the slices in
@@ -394,13 +408,13 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   // item `it` of a thread is pixel (tid >> 2) + 128 * it: LDS offsets differ by a constant
   unsigned a_goff[A_ITERS];                              // (scalar base + 32-bit lane offset)
   const int a_loff0 = (tid >> 2) * WN_RAW_PITCH + sv * 4;
-  const bool a_third = tid < 4 * (W16_RAW_ROWS - 256);          // items 0, 1 always exist
+  const bool a_third = tid < 4 * (RAW_ROWS - THREADS / 2);      // items 0, 1 always exist
   unsigned a_valid = 0;
 #pragma unroll
   for (int it = 0; it < A_ITERS; ++it) {
-    const int p = (tid + W16_THREADS * it) >> 2;
+    const int p = (tid + THREADS * it) >> 2;
     a_goff[it] = 0x80000000u;
-    if (p < W16_RAW_ROWS) {
+    if (p < RAW_ROWS) {
       const int hy = p / 18, hx = p - hy * 18;
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
       if (iy >= 0 && iy < k.H && ix >= 0 && ix < k.W) {
@@ -439,12 +453,12 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     }
     if (PRO != P2L_PRO_NONE && !((a_valid >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};   // padding is 0 AFTER the prologue
     if (H2) v = v * x_scale;
-    *reinterpret_cast<f32x4*>(raw + a_loff0 + it * 128 * WN_RAW_PITCH) = v;
+    *reinterpret_cast<f32x4*>(raw + a_loff0 + it * (THREADS / 4) * WN_RAW_PITCH) = v;
   };
 
   // ---- input transform item: (half h, tile tt of 64, channel quad tv) --------------------
-  const int th = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int tt = (tid >> 2) & 63, tv = tid & 3;
+  const int th = __builtin_amdgcn_readfirstlane(tid / (THREADS / 2));
+  const int tt = (tid >> 2) & (TILES - 1), tv = tid & 3;
   const int tty = tt >> 3, ttx = tt & 7;
   const float* t_src = raw + (2 * tty * 18 + 2 * ttx) * WN_RAW_PITCH + tv * 4;
   const int t_dst = tt * 16 + ((tv ^ ((tt >> 2) & 3)) << 2);
@@ -472,17 +486,17 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   // 1, 2 = R[2], R[3] of an odd part
   auto t_cols = [&](int part, int which, float* Vn) {
     const int fr = 2 * th + (part >> 1);
-    float* d = Vn + fr * 4 * 1024 + t_dst;
+    float* d = Vn + fr * 4 * FV + t_dst;
     const f32x4 Ra = tRa, Rb = tRb;
     if ((part & 1) == 0) {                              // R[0]; Rb is R[2]'s second operand
       *reinterpret_cast<f32x4*>(d) = Ra - Rb;
       tR2 = Rb;
     } else if (which == 0) {
-      *reinterpret_cast<f32x4*>(d + 1024) = Ra + tR2;
+      *reinterpret_cast<f32x4*>(d + FV) = Ra + tR2;
     } else if (which == 1) {
-      *reinterpret_cast<f32x4*>(d + 2048) = tR2 - Ra;
+      *reinterpret_cast<f32x4*>(d + 2 * FV) = tR2 - Ra;
     } else {
-      *reinterpret_cast<f32x4*>(d + 3072) = Ra - Rb;
+      *reinterpret_cast<f32x4*>(d + 3 * FV) = Ra - Rb;
     }
   };
 
@@ -494,9 +508,9 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       __builtin_amdgcn_readfirstlane(k.Cout * k.nchunks * (16 * (H2 ? 64 : 96))), 0x00020000);
   const int w_lane = lane * 16;
   constexpr int NP = H2 ? 2 : 3;                       // pieces of a weight
-  f32x4 bw[2][2][NP];                                  // [set][N-tile][piece]
+  f32x4 bw[NF][2][NP];                                 // [frequency of the wave][N-tile][piece]
   auto load_b = [&](int c, int fi, int set) {
-    const int base = (((c_lo + c) * 16 + (2 * wave + fi)) * n_t32 + (n0 >> 5)) * (NP * 64 * 16);
+    const int base = (((c_lo + c) * 16 + (NF * wave + fi)) * n_t32 + (n0 >> 5)) * (NP * 64 * 16);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -505,11 +519,11 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane + p * 1024, base + j * (NP * 1024), 0));
   };
 
-  f32x16 acc[2][2][2];                                 // [freq][M-tile][N-tile]
+  f32x16 acc[NF][MT][2];                               // [freq][M-tile][N-tile]
 #pragma unroll
-  for (int fi = 0; fi < 2; ++fi)
+  for (int fi = 0; fi < NF; ++fi)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   bf16x2 hh[4];                                        // h pieces
   bf16x2 mm[4], ll[4];                                 // m, l pieces of the current fragment
   auto lda = [&](const float* Vc, int s) {
-    const float* rowp = Vc + ((2 * wave + (s >> 1)) * 64 + (s & 1) * 32) * 16;
+    const float* rowp = Vc + ((NF * wave + s / MT) * TILES + (s % MT) * 32) * 16;
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(rowp + a_off0);
     const f32x4 q1 = *reinterpret_cast<const f32x4*>(rowp + a_off1);
     rr[0] = f32x2{q0.x, q0.y}; rr[1] = f32x2{q0.z, q0.w};
@@ -679,7 +693,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   auto stepH = [&](auto S_, auto MORE_, const float* Vc, float* Vn, int c) {
     constexpr int s = decltype(S_)::value;
     constexpr bool more = decltype(MORE_)::value;
-    constexpr int fi = s >> 1, m = s & 1;
+    constexpr int fi = s / MT, m = s % MT;
     const h16x8 a1 = cat8H(hhH);
     P2L_MFH(a1, fi, 0, 0, m);
 #pragma unroll
@@ -701,10 +715,12 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
     if (s + 1 < 4 && !(ABL & 32)) lda(Vc, s + 1);   // (the residuals are dead)
     P2L_SB();
     P2L_MFH(a2, fi, 0, 0, m);
-    // gap 4: weight fragments / next patch
-    if (s == 0 && !(ABL & 1)) load_b(c, 1, 1);
-    else if (s == 2 && more && !(ABL & 1)) load_b(c + 1, 0, 0);
-    else if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
+    // gap 4: weight fragments (two steps ahead of their first use) / next patch
+    if ((s + 2) % MT == 0 && !(ABL & 1)) {
+      if (s + 2 < 4) load_b(c, (s + 2) / MT, (s + 2) / MT);
+      else if (more) load_b(c + 1, (s - 2) / MT, (s - 2) / MT);
+    }
+    if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
     P2L_TXH(6 * s + 4);
     P2L_SB();
     P2L_MFH(a2, fi, 1, 0, m);
@@ -720,6 +736,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   P2L_TR(0, 63);                                       // (lab) block phases: start | loop | epilogue | pass 1 | end
   load_raw(0);
   load_b(0, 0, 0);
+  if (MT == 1) load_b(0, 1, 1);                        // (4 frequencies per wave: two steps ahead from the start)
   // (round 4: the scale is only needed when the patch is WRITTEN, so the first patch and weight
   //  requests are in flight while the partial maxima are reduced: ~1 k cycles of every block)
   // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
@@ -729,13 +746,13 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       // maxima handed over by the launch that wrote x (P2LAmax): its per-block partials of this
       // image; a fused prologue x*s+t (ReLU or not) is bounded by max|s| max|x| + max|t|
       a = 0.f;
-      for (int i = tid; i < k.amax_in_n; i += W16_THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+      for (int i = tid; i < k.amax_in_n; i += THREADS) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
       float ms = 0.f, mt = 0.f;
       const bool bound = PRO != P2L_PRO_NONE && !k.amax_in_applied;   // (applied: the maxima ARE those of x*s+t)
       if (bound) {
         const float* ps = k.pro_s + (size_t)b * k.pro_bstride;
         const float* pt = k.pro_t + (size_t)b * k.pro_bstride;
-        for (int c = tid; c < k.Cin; c += W16_THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
+        for (int c = tid; c < k.Cin; c += THREADS) { ms = fmaxf(ms, fabsf(ps[c])); mt = fmaxf(mt, fabsf(pt[c])); }
       }
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -746,7 +763,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       __syncthreads();
       a = 0.f; ms = 0.f; mt = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
+      for (int w = 0; w < NW; ++w) { a = fmaxf(a, raw[w * 4]); ms = fmaxf(ms, raw[w * 4 + 1]); mt = fmaxf(mt, raw[w * 4 + 2]); }
       __syncthreads();                                   // (the patch is staged there next)
       if (PRO != P2L_PRO_NONE) a = (bound ? ms * a + mt : a) * 1.001f;
     } else {
@@ -775,8 +792,8 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   if (ABL & 1) load_b(0, 1, 1);
   P2L_TR(1, 63);
   for (int c = 0; c + 1 < nchunks; ++c) {
-    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
-    float* Vn = Vs + ((c + 1) & 1) * W16_V_FLOATS;
+    float* Vc = Vs + (c & 1) * V_FLOATS;
+    float* Vn = Vs + ((c + 1) & 1) * V_FLOATS;
     P2L_TR(0, c);
     if constexpr (H2) {
       if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstageH(); }
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
   }
   {
     const int c = nchunks - 1;
-    float* Vc = Vs + (c & 1) * W16_V_FLOATS;
+    float* Vc = Vs + (c & 1) * V_FLOATS;
     lda(Vc, 0);
     if constexpr (H2) {
       hstageH();
@@ -823,24 +840,24 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
 #undef P2L_MF
 #undef P2L_SB
 
-  // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..63][32 channels] ----------
+  // ---- epilogue: 2 passes of 32 output channels; dump[f][tile 0..TILES-1][32 channels] -----
   float* dump = Vs;
   const int e_t = tid >> 3, e_c4 = tid & 7;             // item: (tile, 4 channels)
   const int ety = e_t >> 3, etx = e_t & 7;
-  float* red = raw;                                      // [2 kinds][8 waves][32]
+  float* red = raw;                                      // [2 kinds][NW waves][32]
   const bool split = k.splitk > 1;
   const float alpha = (split ? 1.f : k.alpha) * out_scale;   // (the finish kernel scales the sum)
   float blk_amax = 0.f, blk_amaxp = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
-    for (int fi = 0; fi < 2; ++fi)
+    for (int fi = 0; fi < NF; ++fi)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int tile = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          dump[((2 * wave + fi) * 64 + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
+          dump[((NF * wave + fi) * TILES + tile) * WN_DUMP_PITCH + l31] = acc[fi][m][j][r];
         }
     if (j == 0) { P2L_TR(1, 62); }
     __syncthreads();
@@ -852,10 +869,10 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       f32x4 T[2][4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {                  // A^T M, column jj
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
-        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * 64 + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(dump + ((0 + jj) * TILES + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(dump + ((4 + jj) * TILES + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(dump + ((8 + jj) * TILES + e_t) * WN_DUMP_PITCH + e_c4 * 4);
+        const f32x4 m3 = *reinterpret_cast<const f32x4*>(dump + ((12 + jj) * TILES + e_t) * WN_DUMP_PITCH + e_c4 * 4);
         T[0][jj] = (m0 + m1) + m2;
         T[1][jj] = (m1 - m2) - m3;
       }
@@ -897,15 +914,16 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       }
       if (lane < 8) {
         *reinterpret_cast<f32x4*>(red + wave * 32 + lane * 4) = sgx;
-        *reinterpret_cast<f32x4*>(red + 256 + wave * 32 + lane * 4) = sg;
+        *reinterpret_cast<f32x4*>(red + NW * 32 + wave * 32 + lane * 4) = sg;
       }
       __syncthreads();
-      if (tid < 64 && nb + (tid & 31) < k.n_store) {
+      if (tid < 32 * MT && nb + (tid & 31) < k.n_store) {
+        // one partial sum per 8x16-pixel tile of the caller's buffer (4 waves each), whatever the block
         const int g = tid >> 5, col = tid & 31;
         const float* r0 = red + g * 128 + col;
         const float s0 = (r0[0] + r0[32]) + (r0[64] + r0[96]);
-        const float s1 = (r0[256] + r0[288]) + (r0[320] + r0[352]);
-        const size_t slot = (size_t)b * k.arb_nblk + (size_t)(2 * by + g) * k.tiles_x + bx;
+        const float s1 = (r0[NW * 32] + r0[NW * 32 + 32]) + (r0[NW * 32 + 64] + r0[NW * 32 + 96]);
+        const size_t slot = (size_t)b * k.arb_nblk + (size_t)(MT * by + g) * k.tiles_x + bx;
         const size_t o = slot * k.Cout + nb + col;
         k.arb_partial[o] = s0;
         k.arb_partial[(size_t)k.B * k.arb_nblk * k.Cout + o] = s1;
@@ -925,7 +943,10 @@ __global__ __launch_bounds__(W16_THREADS, 1) void wino16s_conv_kernel(const Conv
       blk_amaxp = fmaxf(blk_amaxp, __shfl_xor(blk_amaxp, o, 64));
     }
     if (lane == 0) {
-      const size_t slot = (size_t)b * k.amax_out_n + ((size_t)tile_in_image * k.n_ntiles + (n0 >> 6)) * 8 + wave;
+      // 8 partials per 16x16-pixel tile and 64 channels in both block shapes (the reader must not see
+      // which one ran): an 8x16 block is the upper / lower half (by & 1) of its 16x16 tile
+      const size_t t16 = MT == 2 ? (size_t)tile_in_image : (size_t)(by >> 1) * k.tiles_x + bx;
+      const size_t slot = (size_t)b * k.amax_out_n + (t16 * k.n_ntiles + (n0 >> 6)) * 8 + (MT == 2 ? 0 : (by & 1) * 4) + wave;
       if (k.amax_out != nullptr) k.amax_out[slot] = blk_amax;
       if (k.amax_outp != nullptr) k.amax_outp[slot] = blk_amaxp;
     }
@@ -1172,22 +1193,38 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     }                                                                                        \
     hipLaunchKernelGGL(wino16s_conv_kernel<PRO>, grid, block, W16_LDS_BYTES, st, k);         \
   } while (0)
-#define P2L_W16H(PRO)                                                                        \
+#define P2L_W16H(PRO, MTV, LDSB)                                                             \
   do {                                                                                       \
     static std::atomic<bool> attr_set{false};                                                \
     if (!attr_set) {                                                                         \
-      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO, 0, true>,              \
+      (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<PRO, 0, true, MTV>,         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
     if (k.amax_in == nullptr)                                                                \
       hipLaunchKernelGGL(wino_amax_kernel<PRO>, dim3(64, k.B), dim3(256), 0, st, k);         \
-    hipLaunchKernelGGL((wino16s_conv_kernel<PRO, 0, true>), grid, block, W16_LDS_BYTES, st, k); \
+    hipLaunchKernelGGL((wino16s_conv_kernel<PRO, 0, true, MTV>), grid, block, LDSB, st, k);  \
   } while (0)
     if (k.amax != nullptr) {                           // fp16 x 2 arithmetic (conv_launch_impl decides)
-      if (pro == P2L_PRO_NONE) P2L_W16H(P2L_PRO_NONE);
-      else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16H(P2L_PRO_AFFINE_RELU);
-      else P2L_W16H(P2L_PRO_AFFINE);
+      // Block shape from the GRID (round 5): while the 16x16 blocks of the launch leave half the CUs
+      // without one, 8x16-pixel blocks of 4 waves -- twice as many, one wave per SIMD, about half as long.
+      // Bit-identical results and maxima slots (MT in the kernel), so the batch may decide.
+      const long blocks16 = (long)k.n_mtiles * k.n_ntiles * k.splitk;
+      const bool half = (k.form & P2L_FORM_WINO_H2_8X16) ||
+                        (!(k.form & P2L_FORM_WINO_H2_16X16) && blocks16 <= 128);
+      if (half) {
+        k.tiles_y = k.H / 8;
+        k.n_mtiles = k.B * k.tiles_x * k.tiles_y;
+        grid = dim3(k.n_mtiles * k.n_ntiles, k.splitk);
+        block = dim3(256);
+        if (pro == P2L_PRO_NONE) P2L_W16H(P2L_PRO_NONE, 1, W8_LDS_BYTES);
+        else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16H(P2L_PRO_AFFINE_RELU, 1, W8_LDS_BYTES);
+        else P2L_W16H(P2L_PRO_AFFINE, 1, W8_LDS_BYTES);
+        return p2l_check_launch();
+      }
+      if (pro == P2L_PRO_NONE) P2L_W16H(P2L_PRO_NONE, 2, W16_LDS_BYTES);
+      else if (pro == P2L_PRO_AFFINE_RELU) P2L_W16H(P2L_PRO_AFFINE_RELU, 2, W16_LDS_BYTES);
+      else P2L_W16H(P2L_PRO_AFFINE, 2, W16_LDS_BYTES);
       return p2l_check_launch();
     }
 #undef P2L_W16H

@@ -76,8 +76,10 @@ class PycmaSampler(PopulationSampler):
         return np.asarray(asked).reshape((n,) + self.shape), asked
 
     def draw(self, variables, shard=None):
-        values = PopulationSampler.draw(self, variables, shard)
         self._replica = bool(CMA_EXTERNAL and shard is not None and shard.enabled and shard.rank != 0)
+        values = PopulationSampler.draw(self, variables, shard)      # (a replica is not asked either)
+        if self._replica:
+            return values
         if shard is not None and shard.enabled:
             # every replica tells rank 0's population, so the replicas stay identical
             self._handle = values.reshape(len(values), -1)

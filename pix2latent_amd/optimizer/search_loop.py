@@ -86,10 +86,21 @@ class PopulationSampler(object):
         self.var_type, self.var_name = var_type, var_name
         self._handle = None
 
+    #: True on a rank whose strategy object is NOT the authoritative one (an installed pycma /
+    #: nevergrad on rank != 0): it is neither asked nor told -- an ask without its tell grows pycma's
+    #: archive of sent solutions while mean / sigma / stop() freeze, and nevergrad's sequential or
+    #: recast optimizers (Powell, SQPCMA) may block or fall back to random points -- and takes rank
+    #: 0's population from the broadcast (its shape is known from the variable)
+    _replica = False
+
     def draw(self, variables, shard=None):
         """ask for `variables.num_samples` candidates and write them into the variable"""
         n = variables.num_samples
-        values, self._handle = self._ask(n)
+        if self._replica:
+            leaf0 = variables[self.var_type][self.var_name].data[0]
+            values, self._handle = np.zeros((n,) + tuple(leaf0.shape), dtype=np.float64), None
+        else:
+            values, self._handle = self._ask(n)
         values = np.asarray(values, dtype=np.float64)
         if shard is not None and shard.enabled:
             values = shard.broadcast_numpy(values, src=0)

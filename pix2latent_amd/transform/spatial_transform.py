@@ -33,6 +33,7 @@ class _WarpFn(torch.autograd.Function):
         return dst
 
     @staticmethod
+    @torch.autograd.function.once_differentiable     # (a double backward raises instead of returning no gradient)
     def backward(ctx, dout):
         from .. import _native as N
         src, th = ctx.saved_tensors

@@ -103,6 +103,54 @@ def test_replicas_of_an_external_backend_are_not_told(fresh, monkeypatch):
         class V(dict):
             num_samples = n
         v = V(input={'z': types.SimpleNamespace(data=leaves)})
-        s.draw(v, Shard(rank))
-        s.report(np.arange(n, dtype=np.float64))
+        asks = []
+        real_ask = s.es.ask
+        s.es.ask = lambda *a, **k: (asks.append(1), real_ask(*a, **k))[1]
+        for _ in range(3):                       # three generations
+            s.draw(v, Shard(rank))
+            s.report(np.arange(n, dtype=np.float64))
         assert bool(FakeCMAES.log) == told
+        # a replica is not ASKED either (an ask without its tell grows pycma's archive of
+        # sent solutions and leaves a sequential nevergrad optimizer waiting)
+        assert len(asks) == (3 if told else 0)
+
+
+def test_replicas_of_an_external_nevergrad_are_neither_asked_nor_told(fresh, monkeypatch):
+    """the same rule for the ask/tell sampler, with a backend that RAISES on an ask that follows an
+    un-told ask (what nevergrad's sequential optimizers effectively do)"""
+    class Strict(FakeNGOpt):
+        pending = 0
+        def ask(self):
+            assert type(self).pending < self.num_workers_allowed, 'ask without the matching tell'
+            type(self).pending += 1
+            return FakeNGOpt.ask(self)
+        def tell(self, cand, value):
+            type(self).pending -= 1
+            return FakeNGOpt.tell(self, cand, value)
+        num_workers_allowed = 4
+    mod = _fake_module('nevergrad', optimizers=types.SimpleNamespace(registry={'CMA': Strict}),
+                       p=fake_nevergrad().p)
+    monkeypatch.setitem(sys.modules, 'nevergrad', mod)
+    monkeypatch.delenv('P2L_SAMPLERS', raising=False)
+    B, C, G = fresh()
+    import torch
+
+    class Shard(object):
+        enabled = True
+        def __init__(self, rank): self.rank = rank
+        def broadcast_numpy(self, a, src=0): return a
+
+    for rank in (0, 1):
+        Strict.pending = 0
+        FakeNGOpt.log = []
+        s = G.AskTellSampler('input', 'z', 'CMA', np.zeros(5), budget=40, seed=None)
+        leaves = [torch.zeros(5) for _ in range(4)]
+        class V(dict):
+            num_samples = 4
+        v = V(input={'z': types.SimpleNamespace(data=leaves)})
+        for _ in range(3):
+            s.draw(v, Shard(rank))
+            s.report(np.arange(4, dtype=np.float64))
+        assert Strict.pending == 0
+        kinds = [e[0] for e in FakeNGOpt.log]
+        assert kinds.count('tell') == (12 if rank == 0 else 0) and kinds.count('ask') == kinds.count('tell')

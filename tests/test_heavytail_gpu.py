@@ -162,7 +162,9 @@ def test_maxima_with_the_readers_affine_applied(dev, H):
     import torch.nn.functional as F
     from pix2latent_amd import _native as N, ops as O
     g = torch.Generator().manual_seed(21 + H)
-    B, C0, C1, C2 = 2, 64, 128, 64
+    # (8x8: deep enough for K slices -- the finish kernel is the producer there; an unsplit tile that
+    #  spans two images writes no maxima.  The slice count follows the layer shape since round 5.)
+    B, C0, C1, C2 = 2, (64 if H == 32 else 256), 128, 64
     x0 = torch.randn(B, C0, H, H, generator=g)
     big = torch.randperm(C1, generator=g)[:6]
     w1 = torch.randn(C1, C0, 3, 3, generator=g) / math.sqrt(9 * C0)

@@ -1320,3 +1320,73 @@ def test_every_promised_maxima_slot_is_written(dev, O, case):
     assert am is not None, 'this launch was expected to leave maxima'
     assert bool((am >= 0).all()), '%d of %d promised slots were not written' % (int((am < 0).sum()), am.numel())
     assert torch.equal(am.amax(dim=1), y.abs().amax(dim=(1, 2, 3)))
+
+
+H2_BLOCK_CASES = [
+    # B, H, Cin, Cout, base form: 'auto' = what the plans run (K slices where the layer shape asks for them),
+    # 'any' = P2L_FORM_WINO_ANY (Winograd form for a shape the default leaves to the direct kernel)
+    (2, 32, 512, 512, 'auto'),     # a 32^2 layer of the generator at 2 local candidates (64 blocks of 16x16)
+    (3, 64, 256, 128, 'auto'),     # 64^2, 2 N-tiles
+    (2, 32, 256, 256, 'auto'),     # K-sliced small-grid layer (2 slices + finish kernel)
+    (1, 16, 512, 512, 'auto'),     # 16^2: 4 slices
+    (5, 48, 128, 64, 'any'),       # H not a power of two, odd batch
+]
+
+
+@pytest.mark.parametrize('mode', ['forward', 'forward-pool-max', 'dgrad-fused-arb', 'dgrad-fused-arb-pool-sum'])
+@pytest.mark.parametrize('case', H2_BLOCK_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_winograd_f16x2_block_shapes_bit_identical(dev, O, case, mode):
+    """Round 5: the 8x16-pixel / 4-wave block of the hand-scheduled fp16 x 2 Winograd kernel (the
+    small-batch form: twice the blocks, one wave per SIMD) against its 16x16-pixel / 8-wave block.
+    Re-tiling along M changes no output's summation order, so the launcher may pick the shape from the
+    GRID SIZE: outputs, pooled outputs, the fused activation-backward sums (d s, d t) and the partial
+    maxima handed to the next launch -- slot for slot -- are bit-identical, with and without K slices,
+    and so is the consumer that reads those maxima."""
+    from pix2latent_amd import _native as N
+    B, H, Cin, Cout, base = case
+    base = N.FORM_WINO_ANY if base == 'any' else N.FORM_AUTO
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, H, H, Cin, generator=g)
+    x[0] *= 1e-3
+    x = x.to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+    arb = mode.startswith('dgrad')
+    s = (0.5 + torch.rand(B, Cout if arb else Cin, generator=g)).to(dev)
+    t = (0.3 * torch.randn(B, Cout if arb else Cin, generator=g)).to(dev)
+    bias = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+    res = torch.randn(B, H, H, Cout, generator=g).to(dev)
+    pooled = mode.endswith('pool-sum')
+    Ho = H // 2 if pooled else H
+    xa = torch.randn(B, Ho, Ho, Cout, generator=g).to(dev)
+    skip = torch.randn(B, Ho, Ho, Cout, generator=g).to(dev)
+    outs = []
+    for form in (base | N.FORM_WINO_H2_16X16, base | N.FORM_WINO_H2_8X16, base):
+        O.DEFAULT_FORM = form
+        if not arb:
+            wp = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=2)
+            kw = dict(wfmt=2, bias=bias, pro=N.PRO_AFFINE_RELU, pro_s=s, pro_t=t, pro_bstride=Cin, alpha=0.5,
+                      want_amax=True)
+            if mode == 'forward':
+                kw['res'] = res
+            else:
+                kw.update(pool=N.POOL_MAX, act=N.ACT_RELU)
+            (y, yp, (am, amp)), mm = _mfma_products(N, lambda: O.conv(x, wp, B, H, H, Cin, Cout, 9, **kw))
+            assert abs(mm - 3.0) < 1e-6, 'expected the fp16 x 2 Winograd kernel'
+            assert am is not None and bool((am >= 0).all())
+            # the consumer of the maxima
+            w2 = O.pack_conv_weight((torch.randn(64, Cout, 3, 3, generator=torch.Generator().manual_seed(1)) / math.sqrt(9 * Cout)).to(dev), 9, 64, Cout, wfmt=2)
+            z, _ = O.conv(y, w2, B, H, H, Cout, 64, 9, wfmt=2, amax_in=am)
+            outs.append([y.clone(), am.clone(), z.clone()] + ([yp.clone(), amp.clone()] if yp is not None else []))
+        else:
+            wt = O.pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), 9, Cout, Cin, flip=True, wfmt=2)
+            dd = N.P2LConv()
+            dd.B, dd.H, dd.W, dd.Cin, dd.Cout, dd.taps, dd.wfmt, dd.x_ld, dd.form = B, H, H, Cin, Cout, 9, 2, Cin, form
+            dd.n_store = dd.y_ld = dd.yp_ld = Cout
+            dd.pool = N.POOL_SUM if pooled else N.POOL_NONE
+            dx, ds, dt = O.conv_dgrad_arb(x, wt, B, H, H, Cin, Cout, 9, xa, s, t, Cout, wfmt=2, skip=skip, skip_C=Cout,
+                                          pool_sum=pooled, splitk=N.lib().p2l_conv_suggest_splitk(C.byref(dd)))
+            outs.append([dx.clone(), ds.clone(), dt.clone()])
+    torch.cuda.synchronize()
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b), 'the 8x16 block differs from the 16x16 block'
+        assert torch.equal(a, c), 'the block shape picked from the grid differs'
