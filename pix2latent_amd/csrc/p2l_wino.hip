@@ -508,14 +508,18 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
       __builtin_amdgcn_readfirstlane(k.Cout * k.nchunks * (16 * (H2 ? 64 : 96))), 0x00020000);
   const int w_lane = lane * 16;
   constexpr int NP = H2 ? 2 : 3;                       // pieces of a weight
-  f32x4 bw[NF][2][NP];                                 // [frequency of the wave][N-tile][piece]
-  auto load_b = [&](int c, int fi, int set) {
+  // (a second bank for MT = 1 -- the next chunk's fragments requested a whole chunk ahead -- put 128 more
+  //  registers under the loop: spills; instead the 4-wave block re-fills a frequency's registers right
+  //  behind the last MFMA that reads them, see stepH)
+  constexpr int NBK = 1;
+  f32x4 bw[NBK][NF][2][NP];                            // [bank][frequency of the wave][N-tile][piece]
+  auto load_b = [&](int c, int fi, int bank) {
     const int base = (((c_lo + c) * 16 + (NF * wave + fi)) * n_t32 + (n0 >> 5)) * (NP * 64 * 16);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int p = 0; p < NP; ++p)
-        bw[set][j][p] = __builtin_bit_cast(
+        bw[bank][fi][j][p] = __builtin_bit_cast(
             f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_lane + p * 1024, base + j * (NP * 1024), 0));
   };
 
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
 #define P2L_MF(A, FI, J, P, M)                                                                \
   if (!(ABL & 16))                                                                            \
     acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                  \
-        A, __builtin_bit_cast(bf16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                 \
+        A, __builtin_bit_cast(bf16x8, bw[0][FI][J][P]), acc[FI][M][J], 0, 0, 0);              \
   P2L_SB()
 
 #ifdef P2L_LAB
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
     P2L_SB();
     P2L_MF(a2, fi, 1, 1, m);
     // gap 9: weight fragments / next patch (address arithmetic + loads)
-    if (s == 0 && !(ABL & 1)) load_b(c, 1, 1);
+    if (s == 0 && !(ABL & 1)) load_b(c, 1, 0);
     else if (s == 2 && more && !(ABL & 1)) load_b(c + 1, 0, 0);
     else if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);   // (last one: a harmless re-read)
     P2L_SB();
@@ -686,13 +690,14 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
 #define P2L_MFH(A, FI, J, P, M)                                                               \
   if (!(ABL & 16))                                                                            \
     acc[FI][M][J] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
-        A, __builtin_bit_cast(h16x8, bw[FI][J][P]), acc[FI][M][J], 0, 0, 0);                  \
+        A, __builtin_bit_cast(h16x8, bw[BK][FI][J][P]), acc[FI][M][J], 0, 0, 0);              \
   P2L_SB()
 #define P2L_TXH(G)                                                                            \
   if (more && !(ABL & 2) && kTxH.slot[G] >= 0) tx(kTxH.slot[G] >> 3, kTxH.slot[G] & 7, Vn)
-  auto stepH = [&](auto S_, auto MORE_, const float* Vc, float* Vn, int c) {
+  auto stepH = [&](auto S_, auto MORE_, auto BK_, const float* Vc, float* Vn, int c) {
     constexpr int s = decltype(S_)::value;
     constexpr bool more = decltype(MORE_)::value;
+    constexpr int BK = decltype(BK_)::value;           // bank of THIS chunk's weight fragments
     constexpr int fi = s / MT, m = s % MT;
     const h16x8 a1 = cat8H(hhH);
     P2L_MFH(a1, fi, 0, 0, m);
@@ -715,16 +720,20 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
     if (s + 1 < 4 && !(ABL & 32)) lda(Vc, s + 1);   // (the residuals are dead)
     P2L_SB();
     P2L_MFH(a2, fi, 0, 0, m);
-    // gap 4: weight fragments (two steps ahead of their first use) / next patch
-    if ((s + 2) % MT == 0 && !(ABL & 1)) {
-      if (s + 2 < 4) load_b(c, (s + 2) / MT, (s + 2) / MT);
-      else if (more) load_b(c + 1, (s - 2) / MT, (s - 2) / MT);
+    // gap 4: weight fragments (16x16 blocks: two steps ahead of their first use) / next patch
+    if (MT == 2 && s % 2 == 0 && !(ABL & 1)) {
+      if (s == 0) load_b(c, 1, 0);
+      else if (more) load_b(c + 1, 0, 0);
     }
     if (s == 1 && more && !(ABL & 64)) load_raw(c + 2 < nchunks ? c + 2 : c + 1);
     P2L_TXH(6 * s + 4);
     P2L_SB();
     P2L_MFH(a2, fi, 1, 0, m);
-    // gap 5: h pieces of the next fragment
+    // gap 5: h pieces of the next fragment.  8x16 blocks (one wave per SIMD: a step is ~400 cycles and a
+    // fragment requested two steps ahead arrives late -- lab build, 64^2 256->256 at 2 candidates: weights
+    // loaded once 30.8 us against 37.3): frequency s of the NEXT chunk goes into the registers the last
+    // MFMA of this step has just read, four steps ahead of its use
+    if (MT == 1 && more && !(ABL & 1)) load_b(c + 1, s, 0);
     if (s + 1 < 4 && !(ABL & 32)) hstageH();
     P2L_TXH(6 * s + 5);
     P2L_SB();
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
   P2L_TR(0, 63);                                       // (lab) block phases: start | loop | epilogue | pass 1 | end
   load_raw(0);
   load_b(0, 0, 0);
-  if (MT == 1) load_b(0, 1, 1);                        // (4 frequencies per wave: two steps ahead from the start)
+  if (MT == 1) { load_b(0, 1, 0); load_b(0, 2, 0); load_b(0, 3, 0); }   // (the whole first chunk)
   // (round 4: the scale is only needed when the patch is WRITTEN, so the first patch and weight
   //  requests are in flight while the partial maxima are reduced: ~1 k cycles of every block)
   // fp16 x 2: the image's scale from the 64 partial maxima of the pass in front of the launch
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
   }
   __syncthreads();
   using T_ = std::true_type; using F_ = std::false_type;
-  if (ABL & 1) load_b(0, 1, 1);
+  if ((ABL & 1) && MT == 2) load_b(0, 1, 0);
   P2L_TR(1, 63);
   for (int c = 0; c + 1 < nchunks; ++c) {
     float* Vc = Vs + (c & 1) * V_FLOATS;
@@ -798,10 +807,11 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
     if constexpr (H2) {
       if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstageH(); }
       P2L_SB();
-      stepH(std::integral_constant<int, 0>{}, T_{}, Vc, Vn, c);
-      stepH(std::integral_constant<int, 1>{}, T_{}, Vc, Vn, c);
-      stepH(std::integral_constant<int, 2>{}, T_{}, Vc, Vn, c);
-      stepH(std::integral_constant<int, 3>{}, T_{}, Vc, Vn, c);
+      using B0_ = std::integral_constant<int, 0>;
+      stepH(std::integral_constant<int, 0>{}, T_{}, B0_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 1>{}, T_{}, B0_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 2>{}, T_{}, B0_{}, Vc, Vn, c);
+      stepH(std::integral_constant<int, 3>{}, T_{}, B0_{}, Vc, Vn, c);
     } else {
       if (!(ABL & 32) || c == 0) { lda(Vc, 0); hstage(); }
       P2L_SB();
@@ -820,10 +830,11 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
     if constexpr (H2) {
       hstageH();
       P2L_SB();
-      stepH(std::integral_constant<int, 0>{}, F_{}, Vc, Vc, c);
-      stepH(std::integral_constant<int, 1>{}, F_{}, Vc, Vc, c);
-      stepH(std::integral_constant<int, 2>{}, F_{}, Vc, Vc, c);
-      stepH(std::integral_constant<int, 3>{}, F_{}, Vc, Vc, c);
+      using B0_ = std::integral_constant<int, 0>;
+      stepH(std::integral_constant<int, 0>{}, F_{}, B0_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 1>{}, F_{}, B0_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 2>{}, F_{}, B0_{}, Vc, Vc, c);
+      stepH(std::integral_constant<int, 3>{}, F_{}, B0_{}, Vc, Vc, c);
     } else {
       hstage();
       P2L_SB();
@@ -1158,6 +1169,26 @@ int p2l_wino_launch(const ConvK& k_in, int pro, hipStream_t st) {
     hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL>), grid, block, W16_LDS_BYTES, st, k); \
     return p2l_check_launch();                                                               \
   }
+    if (pro == P2L_PRO_NONE && k.amax != nullptr && (k.form & P2L_FORM_WINO_H2_8X16)) {
+      // the 4-wave block (MT = 1) under the same ablations
+      ConvK k8 = k;
+      k8.tiles_y = k.H / 8;
+      k8.n_mtiles = k.B * k.tiles_x * k8.tiles_y;
+      dim3 grid8(k8.n_mtiles * k8.n_ntiles, k8.splitk), block8(256);
+#define P2L_W8LH(ABL)                                                                        \
+  case ABL: {                                                                                \
+    (void)hipFuncSetAttribute((const void*)wino16s_conv_kernel<P2L_PRO_NONE, ABL, true, 1>,  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
+    hipLaunchKernelGGL(wino_amax_kernel<P2L_PRO_NONE>, dim3(64, k.B), dim3(256), 0, st, k8); \
+    hipLaunchKernelGGL((wino16s_conv_kernel<P2L_PRO_NONE, ABL, true, 1>), grid8, block8, W8_LDS_BYTES, st, k8); \
+    return p2l_check_launch();                                                               \
+  }
+      switch (g_lab_abl) {
+        P2L_W8LH(0) P2L_W8LH(1) P2L_W8LH(2) P2L_W8LH(4) P2L_W8LH(8) P2L_W8LH(16) P2L_W8LH(64) P2L_W8LH(3) P2L_W8LH(67) P2L_W8LH(79)
+        default: return P2L_EINVAL;
+      }
+#undef P2L_W8LH
+    }
     if (pro == P2L_PRO_NONE && k.amax != nullptr) {
 #define P2L_W16LH(ABL)                                                                       \
   case ABL: {                                                                                \

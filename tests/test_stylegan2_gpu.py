@@ -1,11 +1,11 @@
 """StyleGAN2 native path vs the CPU oracle (oracle/stylegan2_ref.py) on seeded synthetic
 weights: mapping, synthesis forward pixels, gradients to z / w+ / noise.
 
-Gradient tolerance: the leaky-ReLU kinks make fp32 gradients of this network noisy - the
-oracle run in fp32 differs from the same oracle in fp64 by relL2 ~1e-3 (w+, noise) to
-~5e-3 (z, through the 8-layer mapping).  The tests therefore take the fp64 oracle as
-truth and require the native fp32 path to be no further from it than FLOOR_X times the
-fp32 oracle's own distance (plus a small absolute slack), measured in the same test."""
+Gradient tolerance: the leaky-ReLU kinks make fp32 gradients of this network piecewise - the
+oracle run in fp32 differs from the same oracle in fp64 by ~2e-6 per candidate, or by a flip
+step of 2e-4 ... 4e-3.  The tests take the fp64 oracle as truth and hold EVERY candidate to the
+arithmetic floor (FLOOR_X times the fp32 oracle's own distance for that candidate + 2e-5) unless
+the exact-fp32 MFMA build of the same model takes the same step (grad_close)."""
 import numpy as np
 import pytest
 import torch
@@ -55,23 +55,45 @@ def rel_rows(a, b):
     return (a - b).norm(dim=1) / b.norm(dim=1)
 
 
-def grad_close(got, ref32, ref64, what, strict):
+def grad_close(got, ref32, ref64, what, strict, got_f32=None):
     """The gradient of this network is piecewise: every leaky-ReLU unit whose pre-activation two
     arithmetics put on different sides of zero moves a candidate's gradient by a STEP.  Measured per
     candidate (tools/sg2_ab.py, three seeds x {exact fp32, bf16 x 3, fp16 x 2} kernels): the distance
     from the fp64 oracle is either ~2e-6 -- the arithmetic alone, the same for all three native
     arithmetics and for the fp32 CPU oracle -- or one of a few values between 2e-4 and 4e-3 that
-    whichever arithmetics take the same flip SHARE (1.81e-3 for one candidate in all three).  The
-    wide network flips in most candidates, the narrow one hardly ever.  So, per candidate:
-      * none beyond 1e-2, the typical one within FLOOR_X x the fp32 oracle's typical distance plus
-        one flip (2e-3);
-      * narrow network (strict): the typical candidate within FLOOR_X x the fp32 oracle's typical
-        distance + 2e-5 -- arithmetic level, no flip allowance."""
+    whichever arithmetics take the same flip SHARE.  The wide network flips in most candidates, the
+    narrow one hardly ever.
+
+    EVERY candidate is therefore held to the arithmetic-level bound (a median lets half the
+    candidates be off by 1e-3 -- exactly what a scale bug in one image of a multi-image tile costs):
+      * at floor level: within FLOOR_X x the fp32 oracle's distance for THAT candidate + 2e-5; or
+      * a flip step, and then one that the exact-fp32 MFMA build of the same model (`got_f32`: no operand
+        split, no per-image scale, no maxima hand-over) takes as well: the two native distances agree to
+        30 %; and none beyond 1e-2;
+      * narrow network (strict): no flip allowance -- every candidate at floor level."""
     dist, floor = rel_rows(got, ref64), rel_rows(ref32, ref64)
+    at_floor = dist <= FLOOR_X * floor + 2e-5
     assert dist.max().item() < 1e-2, (what, dist, floor)
-    assert dist.median().item() < FLOOR_X * floor.median().item() + 2e-3, (what, dist, floor)
     if strict:
-        assert dist.median().item() < FLOOR_X * floor.median().item() + 2e-5, (what, dist, floor)
+        assert bool(at_floor.all()), (what, 'a candidate of the narrow network is above the arithmetic floor', dist, floor)
+        return
+    if got_f32 is None:
+        assert bool(at_floor.all()), (what, dist, floor)
+        return
+    d32 = rel_rows(got_f32, ref64)
+    shared = (dist - d32).abs() <= 0.3 * torch.maximum(dist, d32)
+    assert bool((at_floor | shared).all()), (
+        what, 'a candidate is off by more than its arithmetic floor where the exact-fp32 build is not',
+        dist, d32, floor)
+
+
+def f32_model(sg, dev, search):
+    """the same generator on the exact-fp32 MFMA kernels (P2L_WFMT_F32)"""
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent_amd import _native as N
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    return StyleGAN2(model='cars', search=search, weights=sg['W'], size=SIZE, device=dev, wfmt=N.WFMT_F32)
 
 
 def test_mapping(sg, dev):
@@ -100,7 +122,10 @@ def test_gradient_to_z(sg, dev):
     zd = sg['z'].to(dev).requires_grad_(True)
     out = sg['model'].forward_z(zd, noises=[n.to(dev) for n in sg['noises']])
     (out * sg['probe'].to(dev)).sum().backward()
-    grad_close(zd.grad, zr.grad, z64.grad, 'dz', sg['strict'])
+    zf = sg['z'].to(dev).requires_grad_(True)
+    outf = f32_model(sg, dev, 'z').forward_z(zf, noises=[n.to(dev) for n in sg['noises']])
+    (outf * sg['probe'].to(dev)).sum().backward()
+    grad_close(zd.grad, zr.grad, z64.grad, 'dz', sg['strict'], zf.grad)
 
 
 def test_forward_w_and_noise_gradients(sg, dev):
@@ -122,8 +147,10 @@ def test_forward_w_and_noise_gradients(sg, dev):
     (out * sg['probe'].to(dev)).sum().backward()
     w64, n64 = wplus.double().requires_grad_(True), flat.double().requires_grad_(True)
     (R.forward_w(d64(sg['W']), w64, n64, SIZE) * sg['probe'].double()).sum().backward()
-    grad_close(wd.grad, wr.grad, w64.grad, 'dw+', sg['strict'])
-    grad_close(nd.grad, nr.grad, n64.grad, 'dnoise', sg['strict'])
+    wf, nf = wplus.to(dev).requires_grad_(True), flat.to(dev).requires_grad_(True)
+    (f32_model(sg, dev, 'w+')(wf, nf) * sg['probe'].to(dev)).sum().backward()
+    grad_close(wd.grad, wr.grad, w64.grad, 'dw+', sg['strict'], wf.grad)
+    grad_close(nd.grad, nr.grad, n64.grad, 'dnoise', sg['strict'], nf.grad)
     assert hasattr(model, 'latent_mean') and hasattr(model, 'latent_std')
 
 

@@ -44,9 +44,10 @@ static int lab_main(int B) {
   d.pro_bstride = Cin; d.alpha = 1.f; d.y_ld = Cout; d.n_store = Cout; d.splitk = 1; d.wfmt = P2L_WFMT_BF16X3W; d.form = P2L_FORM_WINO_ANY;
   void* dws; CK(hipMalloc(&dws, (size_t)B * 64 * 4));
   const size_t wsb = (size_t)B * 64 * 4;
-  for (int arith = 0; arith < 2; ++arith) {
-  d.form = P2L_FORM_WINO_ANY | (arith == 0 ? P2L_FORM_WINO_BF3 : 0);
-  printf("---- %s\n", arith == 0 ? "bf16 x 3" : "fp16 x 2 (times include the max-|x| pass)");
+  for (int arith = 0; arith < 3; ++arith) {
+  d.form = P2L_FORM_WINO_ANY | (arith == 0 ? P2L_FORM_WINO_BF3 : arith == 1 ? P2L_FORM_WINO_H2_16X16 : P2L_FORM_WINO_H2_8X16);
+  printf("---- %s\n", arith == 0 ? "bf16 x 3" : arith == 1 ? "fp16 x 2, 16x16-pixel blocks of 8 waves (times include the max-|x| pass)"
+                                                              : "fp16 x 2, 8x16-pixel blocks of 4 waves (round 5)");
   const struct { int abl; const char* what; } A[] = {
       {0, "full"}, {1, "weights once"}, {2, "no transform"}, {4, "no barriers"}, {8, "no m (/l) pieces"},
       {16, "no MFMAs"}, {64, "no patch traffic"}, {3, "weights once, no transform"},
@@ -62,6 +63,8 @@ static int lab_main(int B) {
   for (int pass = 0; pass < 2; ++pass)
   for (auto a : A) {
     if (arith == 0 && a.abl >= 128) continue;
+    if (arith == 2 && !(a.abl == 0 || a.abl == 1 || a.abl == 2 || a.abl == 4 || a.abl == 8 || a.abl == 16 ||
+                        a.abl == 64 || a.abl == 3 || a.abl == 67 || a.abl == 79)) continue;
     PK(p2l_lab_set(a.abl, nullptr));
     for (int i = 0; i < 3; ++i)
       PK(p2l_conv_fwd(&d, dx, dwp, nullptr, nullptr, nullptr, nullptr, nullptr, dy, nullptr, dws, wsb, st));
@@ -73,6 +76,7 @@ static int lab_main(int B) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("pass %d abl %4d  %.4f ms   %s\n", pass, a.abl, ms / 20, a.what);
   }
+  if (arith == 2) continue;               // (the trace layout is the 8-wave block's)
   // phase trace of the full kernel
   CK(hipMemset(dtr, 0, 8 * 64 * 8 * 8));
   PK(p2l_lab_set(0, dtr));
