@@ -537,7 +537,7 @@ def main():
         # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
         traffic, traffic_src, traffic_rw = None, None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        for name in ('round4_traffic.json', 'round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
+        for name in ('round5_traffic.json', 'round4_traffic.json', 'round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
             tpath = os.path.join(prof_dir, name)
             if os.path.exists(tpath):
                 with open(tpath) as f:
@@ -656,7 +656,7 @@ def main():
                             'peak_tb_per_s': HBM_PEAK_TBS,
                             'measured_stream_tb_per_s': {'write': 4.5, 'read': 6.5, 'copy': 5.0},
                             'frac': round(abytes[1] / (ms[1] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if ms[1] > 0 else None,
-                            'per_layer_table': 'profiles/round4_conv1x1_roofline.txt'},
+                            'per_layer_table': 'profiles/round5_conv1x1_roofline.txt'},
             },
             'telemetry': telemetry.summary(),
         }

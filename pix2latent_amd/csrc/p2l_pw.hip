@@ -29,6 +29,7 @@
 //   * B (weights): pre-split at pack time into the same row format (p2l_pack_conv_weight_pw),
 //     copied global -> registers -> LDS as an image.
 #include "p2l_conv_k.h"
+#include <type_traits>
 
 #include <atomic>
 
@@ -346,28 +347,80 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
   }
   const int b_stage = PWH_SUB * (k.Cout >> 5) * 32 * 16;   // floats per stage of the image
 
-  f32x4 xr[A_ITERS], wr[B_ITERS], sr[SM ? A_ITERS : 1], tr[SM ? A_ITERS : 1];
-  auto load_regs = [&](int st) {
+  // Full-tile form (DEEP): the activations of stage st + 2 are requested while stage st is multiplied
+  // -- two register sets for A, one for the weights (L2 hits, one stage ahead) and the prologue vector.
+  // Round 5: a launch with fewer blocks than the chip has slots (32^2 1024->256: 576 blocks on 1 024
+  // slots; 64^2 512->256: 2.25 rounds) took stages x (load -> split -> multiply), 1.8 us per stage of
+  // 0.2 us of MFMA work, the one-stage-ahead request exposed in front of every split
+  // (profiles/round4_conv1x1_roofline.txt: 2.0-3.9 x floor on those layers).  The loads are issued weights
+  // first, so the wait in front of write_lds leaves the youngest A_ITERS requests in flight.
+#ifdef P2L_AB_PW_SHALLOW              // (A/B build: the round-4 pipeline, one stage ahead)
+  constexpr bool DEEP = false;
+#else
+  constexpr bool DEEP = !SM;
+#endif
+  constexpr int NSET = DEEP ? 2 : 1;
+  f32x4 xr[NSET][A_ITERS], wr[B_ITERS], sr[SM ? A_ITERS : 1], tr[SM ? A_ITERS : 1];
+  // DEEP: image b0 and the weight image as buffer resources -- 32-bit lane offsets that never change and
+  // the stage as the SCALAR offset: no address arithmetic in the loop (with 64-bit pointers hipcc builds
+  // each address in the destination registers of the load and waits for whatever was last loaded there)
+  __amdgpu_buffer_rsrc_t x_rs, w_rs;
+  unsigned a_boff[A_ITERS], b_boff[B_ITERS];
+  if (DEEP) {
+    auto sgpr = [](const void* p) {
+      const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo);
+    };
+    const size_t img = (size_t)k.H * k.W * k.x_ld;
+    x_rs = __builtin_amdgcn_make_buffer_rsrc(sgpr(k.x + (size_t)b0 * img), 0,
+                                             __builtin_amdgcn_readfirstlane((int)(img * 4)), 0x00020000);
+    w_rs = __builtin_amdgcn_make_buffer_rsrc(sgpr(k.w), 0,
+                                             __builtin_amdgcn_readfirstlane(k.Cin * k.Cout * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) a_boff[it] = (unsigned)(a_goff[it] - b0 * (int)img) * 4u;
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) b_boff[it] = (unsigned)b_goff[it] * 4u;
+  }
+  auto load_a = [&](int st, auto SET_) {
+    constexpr int set = decltype(SET_)::value;
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      xr[it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + st * KS);
+      if (DEEP) {
+        xr[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, a_boff[it], st * (KS * 4), 0));
+        continue;
+      }
+      xr[set][it] = *reinterpret_cast<const f32x4*>(k.x + (size_t)a_goff[it] + st * KS);
       if (SM && PRO != P2L_PRO_NONE) {
         sr[it] = *reinterpret_cast<const f32x4*>(k.pro_s + a_soff[it] + st * KS);
         tr[it] = *reinterpret_cast<const f32x4*>(k.pro_t + a_soff[it] + st * KS);
       }
     }
-    if (!SM && PRO != P2L_PRO_NONE) {
+  };
+  // DEEP: the image's prologue vectors sit in LDS (copied once, below): no registers held for them
+  // across the multiply phase (with them the two A sets spilled: 128 VGPR + 40 B of scratch)
+  float* st_lds = smem + PWH_LDS_BYTES / sizeof(float) + 32;           // [2][Cin]
+  auto load_b = [&](int st) {
+    if (!SM && !DEEP && PRO != P2L_PRO_NONE) {
       sr[0] = *reinterpret_cast<const f32x4*>(k.pro_s + s_off + st * KS);
       tr[0] = *reinterpret_cast<const f32x4*>(k.pro_t + s_off + st * KS);
     }
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it)
-      wr[it] = *reinterpret_cast<const f32x4*>(k.w + (size_t)st * b_stage + b_goff[it]);
+    for (int it = 0; it < B_ITERS; ++it) {
+      if (DEEP) wr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, b_boff[it], st * (b_stage * 4), 0));
+      else wr[it] = *reinterpret_cast<const f32x4*>(k.w + (size_t)st * b_stage + b_goff[it]);
+    }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](auto SET_, int st) {
+    constexpr int set = decltype(SET_)::value;
+    if (!SM && DEEP && PRO != P2L_PRO_NONE) {
+      sr[0] = *reinterpret_cast<const f32x4*>(st_lds + st * KS + av * 4);
+      tr[0] = *reinterpret_cast<const f32x4*>(st_lds + k.Cin + st * KS + av * 4);
+    }
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      f32x4 v = xr[it];
+      f32x4 v = xr[set][it];
       if (PRO != P2L_PRO_NONE) {
         v = v * sr[SM ? it : 0] + tr[SM ? it : 0];
         if (PRO == P2L_PRO_AFFINE_RELU) {
@@ -397,12 +450,22 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
   const int nstages = k.Cin / KS;
   const int st_lo = SM ? (int)blockIdx.y * k.chunks_per_split : 0;
   const int st_hi = SM ? min(nstages, st_lo + k.chunks_per_split) : nstages;
-  load_regs(st_lo);
-  write_lds();
-  __syncthreads();
-  for (int st = st_lo; st < st_hi; ++st) {
-    const bool more = st + 1 < st_hi;
-    if (more && !(P2L_PW_ABL & 2)) load_regs(st + 1);
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, NSET - 1>;
+  // one stage: LDS holds stage st; P = the A set that is FREE (stage st came from it)
+  // (FULL_: a steady-state stage -- stages st + 1 and st + 2 exist, nothing is conditional: with the
+  //  requests under `if (more)` hipcc's wait insertion has to cover the path on which none was issued
+  //  and drains the A set it has just requested in front of every split, i.e. no deeper than before)
+  auto stage = [&](int st, auto P_, auto Q_, auto FULL_) {
+    constexpr bool full = decltype(FULL_)::value;
+    const bool more = full || st + 1 < st_hi;
+    if (DEEP) {
+      if (more && !(P2L_PW_ABL & 2)) load_b(st + 1);
+      if ((full || st + 2 < st_hi) && !(P2L_PW_ABL & 2)) load_a(st + 2, P_);
+    } else if (more && !(P2L_PW_ABL & 2)) {
+      load_a(st + 1, P_);
+      load_b(st + 1);
+    }
 #pragma unroll
     for (int sub = 0; sub < PWH_SUB; ++sub) {
       const float* ar = As + (sub * 128 + a_row) * 16;
@@ -423,8 +486,35 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void pw_h2_kernel(const ConvK k) {
       }
     }
     if (!(P2L_PW_ABL & 16)) __syncthreads();
-    if (more && !(P2L_PW_ABL & 1)) write_lds();
+    if (more && !(P2L_PW_ABL & 1)) write_lds(Q_, st + 1);   // stage st + 1: set Q (DEEP: the other one)
     if (!(P2L_PW_ABL & 16)) __syncthreads();
+  };
+  load_a(st_lo, S0_{});
+  load_b(st_lo);
+  if (!SM && DEEP && PRO != P2L_PRO_NONE) {
+    const float* ps = k.pro_s + (size_t)b0 * k.pro_bstride;
+    const float* pt = k.pro_t + (size_t)b0 * k.pro_bstride;
+    for (int c = tid * 4; c < k.Cin; c += 1024) {
+      *reinterpret_cast<f32x4*>(st_lds + c) = *reinterpret_cast<const f32x4*>(ps + c);
+      *reinterpret_cast<f32x4*>(st_lds + k.Cin + c) = *reinterpret_cast<const f32x4*>(pt + c);
+    }
+    __syncthreads();
+  }
+  write_lds(S0_{}, st_lo);
+  if (DEEP && st_lo + 1 < st_hi) load_a(st_lo + 1, S1_{});
+  __syncthreads();
+  if (DEEP) {
+    int st = st_lo;
+    for (; st + 3 < st_hi; st += 2) {                    // steady state, two stages per trip
+      stage(st, S0_{}, S1_{}, std::true_type{});
+      stage(st + 1, S1_{}, S0_{}, std::true_type{});
+    }
+    for (; st < st_hi; st += 2) {                        // the last <= 3 stages
+      stage(st, S0_{}, S1_{}, std::false_type{});
+      if (st + 1 < st_hi) stage(st + 1, S1_{}, S0_{}, std::false_type{});
+    }
+  } else {
+    for (int st = st_lo; st < st_hi; ++st) stage(st, S0_{}, S0_{}, std::false_type{});
   }
   if (!SM) {
 #pragma unroll
@@ -545,7 +635,8 @@ int p2l_pw_launch(const ConvK& k, int pro, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
       attr_set = true;                                                                       \
     }                                                                                        \
-    hipLaunchKernelGGL((pw_h2_kernel<PRO, SMV>), gridh, block, PWH_LDS_BYTES + 128, st, k);  \
+    hipLaunchKernelGGL((pw_h2_kernel<PRO, SMV>), gridh, block,                               \
+                       PWH_LDS_BYTES + 128 + ((!SMV && PRO != P2L_PRO_NONE) ? (size_t)k.Cin * 8 : 0), st, k); \
   } while (0)
   if (k.amax_in != nullptr || k.amax != nullptr) {     // fp16 x 2 (conv_launch_impl decides)
     // k.amax set: the small-grid form (multi-image tiles, split-K slices in blockIdx.y)
