@@ -322,6 +322,12 @@ int p2l_pack_conv_weight_bf3w(const float* w_oihw, int O, int I, int taps, int N
                               int K_pad, int transpose_flip, float* w_packed, void* stream);
 int p2l_pack_conv_weight_bf3(const float* w_oihw, int O, int I, int taps, int N_pad,
                              int K_pad, int transpose_flip, float* w_packed, void* stream);
+/* Sub-pixel buffer of format P2L_WFMT_BF16X3 ONLY (16 phase-tap slabs, bf16 x 3 image, nothing behind
+ * it).  A P2L_WFMT_BF16X3W launch reads the fp16 x 2 image BEHIND the bf16 x 3 one at a fixed offset: its
+ * sub-pixel buffers must come from p2l_pack_conv_weight_subpix_h2 (sized by
+ * p2l_packed_subpix_weight_floats(.., P2L_WFMT_BF16X3W)); handing a _subpix_bf3 buffer to such a launch
+ * reads past its end -- the formats are not tagged on the device, the format field of the call is the
+ * contract. */
 int p2l_pack_conv_weight_subpix_bf3(const float* w_oihw, int O, int I, int N_pad, int K_pad,
                                     int transpose_flip, int mode, float* w_packed,
                                     void* stream);

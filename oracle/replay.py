@@ -89,3 +89,20 @@ def native_decisions(model, loss_fn, W, B, dev, out, target, diag=None):
             items.append(('vgg.pool%d' % ci, 'pool', winner_mask(_nchw(vgg_y(ci - 1))).cpu()))
         items.append(('vgg.conv%d' % ci, 'relu', _nchw(vgg_y(ci) > 0).cpu()))
     return items
+
+
+def sg2_decisions(model, B, out, with_mapping):
+    """StyleGAN2: the leaky-ReLU decisions of the LAST native forward of `model` on B candidates in the
+    order oracle/stylegan2_ref.py takes them -- the 8 mapping layers (when the run went through the mapping),
+    the styled convs (signs of the saved post-activation outputs, read through p2l_sg2_ws_lookup: the
+    activation keeps the sign of its pre-activation) -- and which pixels the final clamp let through
+    (`out` = the image the native run returned, NCHW)."""
+    items = []
+    if with_mapping:
+        acts = model._last_acts                      # [9][B][D]: slot i + 1 = output of mapping layer i
+        for i in range(8):
+            items.append((acts[i + 1] > 0).cpu())
+    for l in range(model._desc.n_conv):
+        items.append(_nchw(model.saved_activation(l, B) > 0).cpu())
+    items.append((out.detach().abs() < 1.0).cpu())
+    return items

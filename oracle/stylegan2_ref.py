@@ -57,9 +57,46 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     return x[:, :, ::down, ::down]
 
 
+# Decision replay (tests of the piecewise gradients): while a tape is set, every fused_leaky_relu takes the
+# sign of its pre-activation -- and the final clamp its pass-through mask -- from the tape, in call order
+# (mapping layers 1..8 when the mapping runs, styled convs 0..n-1, then the clamp), instead of deciding for
+# itself.  oracle/replay.py builds the tape from a native run's saved activations.
+_TAPE = None
+
+
+class replay(object):
+    """with replay(items): ... -- items = list of bool tensors (True = pre-activation > 0 / not clamped)"""
+
+    def __init__(self, items):
+        self.items = list(items)
+
+    def __enter__(self):
+        global _TAPE
+        _TAPE = iter(self.items)
+        return self
+
+    def __exit__(self, *exc):
+        global _TAPE
+        left = sum(1 for _ in _TAPE)
+        _TAPE = None
+        assert exc[0] is not None or left == 0, '%d replayed decisions were not consumed' % left
+
+
 def fused_leaky_relu(x, bias, negative_slope=0.2, scale=2 ** 0.5):
     shape = [1, -1] + [1] * (x.dim() - 2)
+    if _TAPE is not None:
+        pre = x + bias.view(*shape)
+        mask = next(_TAPE).to(pre.device)
+        assert mask.shape == pre.shape, (mask.shape, pre.shape)
+        return torch.where(mask, pre, pre * negative_slope) * scale
     return F.leaky_relu(x + bias.view(*shape), negative_slope) * scale
+
+
+def _clamp(img):
+    if _TAPE is not None:
+        keep = next(_TAPE).to(img.device)
+        return torch.where(keep, img, img.detach().clamp(-1.0, 1.0))
+    return img.clamp(-1.0, 1.0)
 
 
 def equal_linear(x, weight, bias, lr_mul=1.0, activation=False):
@@ -149,7 +186,7 @@ def forward_z(W, z, noises, size):
     """StyleGAN2.forward_z (reference stylegan2.py:116-119), noise made explicit."""
     w = mapping(W, z)
     latent = w.unsqueeze(1).repeat(1, n_latent(size), 1)
-    return synthesis(W, latent, noises, size).clamp(-1.0, 1.0)
+    return _clamp(synthesis(W, latent, noises, size))
 
 
 def reshape_noise(z, size):
@@ -166,4 +203,4 @@ def reshape_noise(z, size):
 def forward_w(W, wplus, noises_flat, size):
     """StyleGAN2.forward_w (reference stylegan2.py:122-125): w+ latents and flat noises."""
     latent = wplus if wplus.dim() == 3 else wplus.unsqueeze(1).repeat(1, n_latent(size), 1)
-    return synthesis(W, latent, reshape_noise(noises_flat, size), size).clamp(-1.0, 1.0)
+    return _clamp(synthesis(W, latent, reshape_noise(noises_flat, size), size))

@@ -256,7 +256,7 @@ EXPORTS = [
     'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
     'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',
     'p2l_sg2_clamp16_fwd', 'p2l_sg2_clamp16_bwd', 'p2l_broadcast_rows', 'p2l_add_inplace',
-    'p2l_sg2_ws_bytes', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
+    'p2l_sg2_ws_bytes', 'p2l_sg2_ws_lookup', 'p2l_sg2_synthesis_fwd', 'p2l_sg2_synthesis_bwd', 'p2l_sg2_mapping_fwd',
     'p2l_sg2_mapping_bwd', 'p2l_conv_arb_fusable', 'p2l_conv_arb_nblk',
     'p2l_conv_dgrad_arb', 'p2l_conv_arb_split_fusable', 'p2l_conv_arb_nblk_ws',
     'p2l_conv_dgrad_arb_ws', 'p2l_arb_finish', 'p2l_arb_defer_begin', 'p2l_arb_defer_flush',

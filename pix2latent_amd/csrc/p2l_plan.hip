@@ -146,7 +146,6 @@ struct AmaxScope {                                     // one per plan entry poi
   ~AmaxScope() { g_amax = nullptr; }
 };
 inline void amax_drop(const float* t) { if (g_amax) g_amax->drop(t); }
-inline void amax_clear() { if (g_amax) for (auto& x : g_amax->e) x = AmaxReg::Ent(); }
 // slots per image a plan has to provide for this conv's maxima (ring sizing)
 int conv_amax_slots(ConvCall& c) {
   c.d.splitk = p2l_conv_suggest_splitk(&c.d);
@@ -756,7 +755,9 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
 
     if (i == m->attn_before) {
       // ---- SelfAttn backward; ga = d out [B,H,H,C] ------------------------
-      amax_clear();                                    // (gb is a scratch matrix of the attention kernels)
+      // (gb becomes a scratch matrix of the attention kernels: ITS maxima die.  Until round 5 every entry was
+      //  cleared here, the incoming gradient's too, and the o_conv gradient below ran in bf16 x 3 for want of them)
+      amax_drop(gb);
       const int C = m->attn_ch, H = L.att_H, P = H * H;
       const float* x = (i == 0) ? W + L.x0 : W + L.blk[i - 1].y;
       (void)x;

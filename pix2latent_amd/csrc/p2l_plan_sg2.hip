@@ -124,6 +124,17 @@ extern "C" size_t p2l_sg2_ws_bytes(const P2LStyleGAN2* m, int Bn) {
   return L.total * sizeof(float);
 }
 
+// test hook (include/p2l_test.h): where the post-activation output of styled conv l lives in ws after
+// p2l_sg2_synthesis_fwd, NHWC [B, res, res, cout] -- its signs are the leaky-ReLU decisions of the run
+// (oracle/replay.py replays them in the CPU oracle)
+extern "C" int p2l_sg2_ws_lookup(const P2LStyleGAN2* m, int Bn, int l, size_t* float_off, int32_t shape[4]) {
+  SgLayout L;
+  if (!m || !float_off || !shape || sg_layout(m, Bn, L) || l < 0 || l >= m->n_conv) return P2L_EINVAL;
+  *float_off = L.y[l];
+  shape[0] = Bn; shape[1] = m->conv[l].res; shape[2] = m->conv[l].res; shape[3] = m->conv[l].cout;
+  return P2L_OK;
+}
+
 // acts: [9][B][D]: slot 0 = PixelNorm(z), slot i+1 = output of mapping layer i
 extern "C" int p2l_sg2_mapping_fwd(const P2LStyleGAN2* m, const float* z, float* w, float* acts,
                                    int B, void* st) {

@@ -80,6 +80,7 @@ class _MappingFn(torch.autograd.Function):
                                                B, N.stream()), 'p2l_sg2_mapping_fwd')
         ctx.model = model
         ctx.save_for_backward(z, acts)
+        model._last_acts = acts              # (test hook: oracle/replay.py reads the run's decisions)
         return w
 
     @staticmethod
@@ -215,6 +216,16 @@ class StyleGAN2(nn.Module):
             self._dimg16 = torch.empty(B, S, S, 16, device=self._dev, dtype=torch.float32)
             self._ws_B = B
             self.ws_generation += 1          # captured HIP graphs hold the old pointers
+
+    def saved_activation(self, layer, B):
+        """test hook: view of the post-activation output of styled conv `layer` inside the workspace
+        of the last synthesis forward on B candidates, NHWC"""
+        off = C.c_size_t(0)
+        shape = (C.c_int32 * 4)()
+        N.check(self._lib.p2l_sg2_ws_lookup(C.byref(self._desc), B, layer, C.byref(off), shape),
+                'p2l_sg2_ws_lookup')
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        return self._ws[off.value:off.value + n].view(*list(shape))
 
     # -------------------------------------------------------------- pieces
     def mapping(self, z):

@@ -40,7 +40,8 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(N.EXPORTS) == syms, set(N.EXPORTS) ^ set(syms)
     # the test hooks live in their own header: the drop-in boundary declares none of them
     hooks = header_symbols(('p2l_test.h',))
-    assert hooks == sorted(['p2l_selftest_amaxreg', 'p2l_biggan_ws_lookup', 'p2l_projloss_ws_lookup', 'p2l_mfma_probe'])
+    assert hooks == sorted(['p2l_selftest_amaxreg', 'p2l_biggan_ws_lookup', 'p2l_projloss_ws_lookup', 'p2l_sg2_ws_lookup',
+                            'p2l_mfma_probe'])
     assert not set(hooks) & set(header_symbols(('p2l.h',)))
     assert len([s for s in syms if s.startswith('p2l_prof_end')]) == 1       # one signature, sized struct
 

@@ -4,8 +4,8 @@ weights: mapping, synthesis forward pixels, gradients to z / w+ / noise.
 Gradient tolerance: the leaky-ReLU kinks make fp32 gradients of this network piecewise - the
 oracle run in fp32 differs from the same oracle in fp64 by ~2e-6 per candidate, or by a flip
 step of 2e-4 ... 4e-3.  The tests take the fp64 oracle as truth and hold EVERY candidate to the
-arithmetic floor (FLOOR_X times the fp32 oracle's own distance for that candidate + 2e-5) unless
-the exact-fp32 MFMA build of the same model takes the same step (grad_close)."""
+arithmetic floor (1.5 times the fp32 oracle's own distance for that candidate + 2e-5), with
+the decisions (leaky-ReLU signs, clamp) being the native run's own, replayed in the oracle (grad_close)."""
 import numpy as np
 import pytest
 import torch
@@ -36,7 +36,6 @@ def sg(request, dev):
     return dict(W=W, model=model, z=z, noises=noises, probe=probe, B=B, R=R, strict=(request.param == 'narrow'))
 
 
-FLOOR_X, SLACK = 3.0, 2e-4
 
 
 def d64(W):
@@ -55,45 +54,23 @@ def rel_rows(a, b):
     return (a - b).norm(dim=1) / b.norm(dim=1)
 
 
-def grad_close(got, ref32, ref64, what, strict, got_f32=None):
+def grad_close(got, ref32, ref64, what):
     """The gradient of this network is piecewise: every leaky-ReLU unit whose pre-activation two
-    arithmetics put on different sides of zero moves a candidate's gradient by a STEP.  Measured per
-    candidate (tools/sg2_ab.py, three seeds x {exact fp32, bf16 x 3, fp16 x 2} kernels): the distance
-    from the fp64 oracle is either ~2e-6 -- the arithmetic alone, the same for all three native
-    arithmetics and for the fp32 CPU oracle -- or one of a few values between 2e-4 and 4e-3 that
-    whichever arithmetics take the same flip SHARE.  The wide network flips in most candidates, the
-    narrow one hardly ever.
-
-    EVERY candidate is therefore held to the arithmetic-level bound (a median lets half the
-    candidates be off by 1e-3 -- exactly what a scale bug in one image of a multi-image tile costs):
-      * at floor level: within FLOOR_X x the fp32 oracle's distance for THAT candidate + 2e-5; or
-      * a flip step, and then one that the exact-fp32 MFMA build of the same model (`got_f32`: no operand
-        split, no per-image scale, no maxima hand-over) takes as well: the two native distances agree to
-        30 %; and none beyond 1e-2;
-      * narrow network (strict): no flip allowance -- every candidate at floor level."""
+    arithmetics put on different sides of zero (and every output pixel at the clamp) moves a candidate's
+    gradient by a STEP -- 2e-4 ... 4e-3 per flip measured (tools/sg2_ab.py), not always shared between
+    arithmetics, against an arithmetic-level distance of ~2e-6.  Until round 5 these tests bounded the
+    MEDIAN candidate (half the candidates could be off by 1e-3, exactly what a scale bug in one
+    image of a multi-image tile costs).  Now arithmetic and decisions are separated as in the BigGAN tests:
+    the oracle REPLAYS the native run's decisions (oracle/stylegan2_ref.replay, read back from the native
+    workspace by oracle/replay.sg2_decisions), and EVERY candidate has to sit at the arithmetic floor:
+    within 1.5 x the fp32 oracle's own distance from fp64 for that candidate + 2e-5."""
     dist, floor = rel_rows(got, ref64), rel_rows(ref32, ref64)
-    at_floor = dist <= FLOOR_X * floor + 2e-5
-    assert dist.max().item() < 1e-2, (what, dist, floor)
-    if strict:
-        assert bool(at_floor.all()), (what, 'a candidate of the narrow network is above the arithmetic floor', dist, floor)
-        return
-    if got_f32 is None:
-        assert bool(at_floor.all()), (what, dist, floor)
-        return
-    d32 = rel_rows(got_f32, ref64)
-    shared = (dist - d32).abs() <= 0.3 * torch.maximum(dist, d32)
-    assert bool((at_floor | shared).all()), (
-        what, 'a candidate is off by more than its arithmetic floor where the exact-fp32 build is not',
-        dist, d32, floor)
+    assert bool((dist <= 1.5 * floor + 2e-5).all()), (what, 'native vs fp64', dist, 'fp32 oracle vs fp64', floor)
 
 
-def f32_model(sg, dev, search):
-    """the same generator on the exact-fp32 MFMA kernels (P2L_WFMT_F32)"""
-    import warnings
-    warnings.simplefilter('ignore')
-    from pix2latent_amd import _native as N
-    from pix2latent_amd.model.stylegan2 import StyleGAN2
-    return StyleGAN2(model='cars', search=search, weights=sg['W'], size=SIZE, device=dev, wfmt=N.WFMT_F32)
+def free_running_bound(got, ref64, what):
+    """against the oracle that decides for itself: gross errors only (a flip is a step of up to 4e-3)"""
+    assert rel_rows(got, ref64).max().item() < 1e-2, (what, rel_rows(got, ref64))
 
 
 def test_mapping(sg, dev):
@@ -113,44 +90,54 @@ def test_forward_z_pixels(sg, dev):
 
 
 def test_gradient_to_z(sg, dev):
+    from oracle import replay as RP
     R = sg['R']
-    zr = sg['z'].clone().requires_grad_(True)
-    (R.forward_z(sg['W'], zr, sg['noises'], SIZE) * sg['probe']).sum().backward()
-    z64 = sg['z'].double().requires_grad_(True)
-    (R.forward_z(d64(sg['W']), z64, [n.double() for n in sg['noises']], SIZE)
-     * sg['probe'].double()).sum().backward()
     zd = sg['z'].to(dev).requires_grad_(True)
     out = sg['model'].forward_z(zd, noises=[n.to(dev) for n in sg['noises']])
     (out * sg['probe'].to(dev)).sum().backward()
-    zf = sg['z'].to(dev).requires_grad_(True)
-    outf = f32_model(sg, dev, 'z').forward_z(zf, noises=[n.to(dev) for n in sg['noises']])
-    (outf * sg['probe'].to(dev)).sum().backward()
-    grad_close(zd.grad, zr.grad, z64.grad, 'dz', sg['strict'], zf.grad)
+    tape = RP.sg2_decisions(sg['model'], sg['B'], out, with_mapping=True)
+    zr = sg['z'].clone().requires_grad_(True)
+    with R.replay(tape):
+        (R.forward_z(sg['W'], zr, sg['noises'], SIZE) * sg['probe']).sum().backward()
+    z64 = sg['z'].double().requires_grad_(True)
+    with R.replay(tape):
+        (R.forward_z(d64(sg['W']), z64, [n.double() for n in sg['noises']], SIZE)
+         * sg['probe'].double()).sum().backward()
+    grad_close(zd.grad, zr.grad, z64.grad, 'dz')
+    zf = sg['z'].double().requires_grad_(True)          # ... and the oracle deciding for itself
+    (R.forward_z(d64(sg['W']), zf, [n.double() for n in sg['noises']], SIZE) * sg['probe'].double()).sum().backward()
+    free_running_bound(zd.grad, zf.grad, 'dz')
 
 
 def test_forward_w_and_noise_gradients(sg, dev):
     import warnings
     warnings.simplefilter('ignore')
     from pix2latent_amd.model.stylegan2 import StyleGAN2
+    from oracle import replay as RP
     R = sg['R']
     B = sg['B']
     model = StyleGAN2(model='cars', search='w+', weights=sg['W'], size=SIZE, device=dev)
     g = torch.Generator().manual_seed(4)
     wplus = torch.randn(B, R.n_latent(SIZE), 512, generator=g) * 0.5
     flat = torch.cat([n.reshape(B, -1) for n in sg['noises']], dim=1)
-    wr, nr = wplus.clone().requires_grad_(True), flat.clone().requires_grad_(True)
-    ref = R.forward_w(sg['W'], wr, nr, SIZE)
-    (ref * sg['probe']).sum().backward()
     wd, nd = wplus.to(dev).requires_grad_(True), flat.to(dev).requires_grad_(True)
     out = model(wd, nd)
-    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 2e-5
     (out * sg['probe'].to(dev)).sum().backward()
+    tape = RP.sg2_decisions(model, B, out, with_mapping=False)
+    ref = R.forward_w(sg['W'], wplus, flat, SIZE)
+    assert (out.detach().cpu() - ref).abs().max().item() < 2e-5
+    wr, nr = wplus.clone().requires_grad_(True), flat.clone().requires_grad_(True)
+    with R.replay(tape):
+        (R.forward_w(sg['W'], wr, nr, SIZE) * sg['probe']).sum().backward()
     w64, n64 = wplus.double().requires_grad_(True), flat.double().requires_grad_(True)
-    (R.forward_w(d64(sg['W']), w64, n64, SIZE) * sg['probe'].double()).sum().backward()
-    wf, nf = wplus.to(dev).requires_grad_(True), flat.to(dev).requires_grad_(True)
-    (f32_model(sg, dev, 'w+')(wf, nf) * sg['probe'].to(dev)).sum().backward()
-    grad_close(wd.grad, wr.grad, w64.grad, 'dw+', sg['strict'], wf.grad)
-    grad_close(nd.grad, nr.grad, n64.grad, 'dnoise', sg['strict'], nf.grad)
+    with R.replay(tape):
+        (R.forward_w(d64(sg['W']), w64, n64, SIZE) * sg['probe'].double()).sum().backward()
+    grad_close(wd.grad, wr.grad, w64.grad, 'dw+')
+    grad_close(nd.grad, nr.grad, n64.grad, 'dnoise')
+    wf, nf = wplus.double().requires_grad_(True), flat.double().requires_grad_(True)
+    (R.forward_w(d64(sg['W']), wf, nf, SIZE) * sg['probe'].double()).sum().backward()
+    free_running_bound(wd.grad, wf.grad, 'dw+')
+    free_running_bound(nd.grad, nf.grad, 'dnoise')
     assert hasattr(model, 'latent_mean') and hasattr(model, 'latent_std')
 
 
