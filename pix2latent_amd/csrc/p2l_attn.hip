@@ -727,8 +727,12 @@ int run_core(const AttnK& a, hipStream_t st) {
 // leave most of the chip idle
 // (counted for a REFERENCE batch, not d->B: the slices are summed in a fixed order that follows their
 //  count, and an image's gradient must not depend on how many images share the launch -- round 5;
-//  until then 18 / 9 / 2 candidates ran 4 / 8 / 8 slices here and 2 / 4 / 8 in the d(queries) form)
-constexpr int AT_REF_B_DV = 18, AT_REF_B_APPLY = 9;
+//  until then 18 / 9 / 2 candidates ran 4 / 8 / 8 slices here and 2 / 4 / 8 in the d(queries) form.
+//  Reference batch 9 for both: 8 slices here, 4 / 8 in the d(queries) / d(keys) forms -- what every local
+//  batch <= 9 ran before; 18 candidates pay ~110 MB more partial-sum traffic per step (0.2 %); with 18 as
+//  the reference here the d(values) kernel of a 2-candidate rank went 31 -> 51 us,
+//  profiles/round5_small_batch_kernel_stats.csv)
+constexpr int AT_REF_B_DV = 9, AT_REF_B_APPLY = 9;
 int dv_tsplit(const P2LAttn* d) {
   int s = 1;
   while (s < 8 && (long)AT_REF_B_DV * (d->Nk >> 7) * 2 * s < 1024 && (d->Nq >> 5) % (2 * s) == 0) s *= 2;

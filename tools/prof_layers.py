@@ -49,7 +49,7 @@ def main():
     torch.cuda.synchronize()
     step_ms = (time.perf_counter() - t0) / steps * 1e3
     T = N.prof_end()
-f, m, c, b = T.flops, T.ms, T.count, T.bytes
+    f, m, c, b = T.flops, T.ms, T.count, T.bytes
     lib.p2l_prof_dump(None)
     rows = collections.OrderedDict()
     for line in open(DUMP):
