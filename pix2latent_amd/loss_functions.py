@@ -219,7 +219,8 @@ class _LossEngine(object):
                                                       lib.p2l_projloss_bwd)
         self.shape = None
         self.ws = None
-        self.slots = {}          # key -> _CacheSlot (insertion order = LRU order)
+        self.slots = {}          # key -> _CacheSlot (insertion order = LRU order; equal content shares a slot)
+        self.keep = {}           # key -> the tensors it identifies (kept alive)
         self.cache = None        # P2LLossCache of the slot bound by the last prepare()
         self._memo = {}
         self._fwd_ticket = 0
@@ -234,7 +235,7 @@ class _LossEngine(object):
         if self.shape is not None and self.shape[1:] == (H, W):
             B = max(B, self.shape[0])
         else:
-            self.slots = {}                          # resolution changed: caches are void
+            self.slots, self.keep = {}, {}           # resolution changed: caches are void
         nbytes = self.f_ws(B, H, W)
         if nbytes == 0:
             raise N.NativeError('loss workspace sizing rejected shape %s' % ((B, H, W),))
@@ -297,24 +298,74 @@ class _LossEngine(object):
             self._memo[name] = (key, self._conform(name, t.to(like.device), B, like), t)
         return self._memo[name][1]
 
+    def _same_content(self, target, weight, loss_mask, use_lpips, B):
+        """A generation of a CMA run starts from FRESH variables (reference base_cma_optimizer.py:79):
+        new target / weight tensors with the old CONTENT; and the chunks of one population carry copies
+        of the same default target.  Instead of running the LPIPS network over the targets again
+        (round 5, tools/gen_overhead.py: the first step of a generation took 32 ms instead of 17), a slot
+        whose tensors are unmodified since it was prepared and EQUAL to the new ones -- compared
+        exactly, on the device, one host sync -- serves the new tensors too (a second key for the slot)."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return None                                   # (no host sync inside a graph capture)
+        seen = set()
+        for old_key in reversed(list(self.slots)):
+            slot = self.slots[old_key]
+            if id(slot) in seen:
+                continue
+            seen.add(id(slot))
+            if getattr(slot, 'use_lpips', None) != use_lpips or slot.B != B or slot.held is None:
+                continue
+            differ = None
+            for new, old, ver in zip((target, weight, loss_mask), slot.held, slot.versions):
+                if (new is None) != (old is None):
+                    differ = True
+                    break
+                if new is None:
+                    continue
+                if old._version != ver or new.shape != old.shape or new.device != old.device:
+                    differ = True                      # (modified in place since: its old content is gone)
+                    break
+                if new.data_ptr() == old.data_ptr():
+                    continue
+                d = (new != old).any()
+                differ = d if differ is None else (differ | d)
+            if differ is True:
+                continue
+            if differ is None or not bool(differ):
+                return slot
+        return None
+
     def prepare(self, out, target, weight, loss_mask, use_lpips):
         B, _, H, W = out.shape
         self._alloc(B, H, W, out.device)
         key = (self._ident(target), self._ident(weight), self._ident(loss_mask), use_lpips)
         slot = self.slots.pop(key, None)
         if slot is None:
+            slot = self._same_content(target, weight, loss_mask, use_lpips, B)
+        if slot is None:
             if len(self.slots) >= self.MAX_SLOTS:
-                old = self.slots.pop(next(iter(self.slots)))      # evict the LRU slot ...
-                slot = old if old.B == B else None                # ... and reuse its memory
+                lru = next(iter(self.slots))
+                old = self.slots.pop(lru)                         # evict the LRU key ...
+                self.keep.pop(lru, None)
+                shared = any(v is old for v in self.slots.values())
+                slot = old if (old.B == B and not shared) else None   # ... and reuse its memory
             if slot is None:
                 slot = _CacheSlot(self.f_cache, B, H, W, out.device)
             vref = C.byref(self.vgg.desc) if use_lpips else None
             N.check(self.f_prepare(vref, N.ptr(target), N.ptr(weight), N.ptr(loss_mask), B, H, W,
                                    C.byref(slot.desc), N.ptr(self.ws), C.c_size_t(self.ws_bytes),
                                    N.stream()), 'p2l_%sloss_prepare' % self.prefix)
-            # keep the tensors alive so that data_ptr identity stays meaningful
+            # what the slot was prepared FROM (content comparisons), with the versions of that moment
             slot.held = (target, weight, loss_mask)
+            slot.versions = tuple(None if t is None else t._version for t in slot.held)
+            slot.use_lpips = use_lpips
+        if len(self.slots) >= 2 * self.MAX_SLOTS:                 # (keys, several may share a slot)
+            lru = next(iter(self.slots))
+            self.slots.pop(lru)
+            self.keep.pop(lru, None)
         self.slots[key] = slot      # most recently used last
+        # keep the key's tensors alive so that data_ptr identity stays meaningful
+        self.keep[key] = (target, weight, loss_mask)
         self.cache = slot.desc
         return slot
 
