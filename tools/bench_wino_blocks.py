@@ -27,7 +27,7 @@ for H, Cin, Cout in SHAPES:
     g = torch.Generator().manual_seed(1)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
-    for B in (1, 2, 3, 5, 9):
+    for B in [int(b) for b in os.environ.get('BATCHES', '1,2,3,5,9').split(',')]:
         x = torch.randn(B, H, H, Cin, device=dev)
         am = x.abs().amax(dim=(1, 2, 3)).view(B, 1).contiguous()
         d = N.P2LConv()
