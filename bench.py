@@ -220,7 +220,7 @@ def _time_steps(fn, n_warm, n, reps=3):
     return sorted(per)[len(per) // 2]
 
 
-def extra_configs(dev, n_steps=3):
+def extra_configs(dev, n_steps=6):
     import contextlib
     import warnings
     warnings.simplefilter('ignore')
