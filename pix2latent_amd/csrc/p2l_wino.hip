@@ -742,12 +742,15 @@ __global__ __launch_bounds__(256 * MT, 1) void wino16s_conv_kernel(const ConvK k
 #undef P2L_TXH
 #undef P2L_MFH
 
-#ifdef P2L_AB_WINO_DEPHASE
-  // (A/B experiment, round 5: the blocks of a launch run in lockstep -- one block per CU, equal work -- and
-  //  reach their epilogues together: 256 CUs x 32 KB per pass is an HBM write burst during which nobody
-  //  multiplies (lab trace: 3.5-5 k cycles to ISSUE four stores per thread).  Delay the first round's
-  //  blocks by 0 / 1/4 / 1/2 / 3/4 of a block so that the CUs stay out of phase for the rest of the launch.)
-  if (MT == 2 && blockIdx.y == 0 && blockIdx.x < 256) {
+#ifdef P2L_AB_WINO_DEPHASE              // (A/B build; not in the product: see the last sentence)
+  // Round 5: the blocks of a launch run in lockstep -- one block per CU, equal work -- and reach their
+  // epilogues together: 256 CUs x 32 KB per pass is an HBM write burst during which nobody multiplies (lab
+  // trace: 3.5-5 k cycles to ISSUE four stores per thread).  Launches of >= 8 rounds delay the first round's
+  // blocks by 0 / 1/4 / 1/2 / 3/4 of a block, so that the CUs stay out of phase for the rest of the launch:
+  // 128^2 128->128 at 18 candidates 256 -> 235 us; below ~8 rounds the start-up delay (3/8 of a block on
+  // average) costs what it gains (profiles/round5_wino_dephase.txt).  Timing only: no result depends on it.
+  // On a second box of the pool the un-delayed launch already ran at the de-phased time (233 us): not adopted.
+  if (MT == 2 && gridDim.y == 1 && gridDim.x >= 8 * 256 && blockIdx.x < 256) {
     const int q = (int)(blockIdx.x >> 3) & 3;          // (8 consecutive ids = one per XCD)
     for (int i = 0; i < q * nchunks; ++i) __builtin_amdgcn_s_sleep(19);     // (19 x 64 cycles ~ a quarter chunk-share of a block)
   }
