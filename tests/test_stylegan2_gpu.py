@@ -268,3 +268,34 @@ def test_hybrid_nevergrad_on_stylegan2(sg, dev):
     with torch.no_grad():
         l_asked = opt.loss_fn(model(z=z0.to(dev)), target.to(dev), weight.to(dev), loss_mask.to(dev)).cpu().numpy()
     assert final.mean() < l_asked.mean()
+
+
+def test_repeats_and_batch_composition_bit_identical(sg, dev):
+    """the bit-reproducibility checks of the BigGAN path for StyleGAN2 as well -- the same
+    forward + backward twice gives the same bits (fixed-order reductions everywhere, no stale maxima slots),
+    and a candidate's image and gradients do not depend on who shares its launch (w+ path: candidate 1 of 3
+    alone)."""
+    import warnings
+    warnings.simplefilter('ignore')
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    R, B = sg['R'], sg['B']
+    model = StyleGAN2(model='cars', search='w+', weights=sg['W'], size=SIZE, device=dev)
+    g = torch.Generator().manual_seed(7)
+    wplus = (torch.randn(B, R.n_latent(SIZE), 512, generator=g) * 0.5).to(dev)
+    flat = torch.cat([n.reshape(B, -1) for n in sg['noises']], dim=1).to(dev)
+    probe = sg['probe'].to(dev)
+
+    def run(w, n, p):
+        w, n = w.clone().requires_grad_(True), n.clone().requires_grad_(True)
+        out = model(w, n)
+        (out * p).sum().backward()
+        return out.detach().clone(), w.grad.clone(), n.grad.clone()
+
+    a = run(wplus, flat, probe)
+    for _ in range(3):
+        b = run(wplus, flat, probe)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), 'a repeated forward + backward differs'
+    one = run(wplus[1:2], flat[1:2], probe[1:2])
+    for x, y, what in zip(a, one, ('image', 'd w+', 'd noise')):
+        assert torch.equal(x[1:2], y), '%s of a candidate depends on the batch composition' % what
