@@ -521,6 +521,17 @@ int p2l_lpips_tap_bwd(const float* f, const float* nft, int64_t nft_bstride,
                       const float* lin, const float* wt, int64_t wt_bstride,
                       const float* gscale, float* df, int Bn, int P, int C,
                       void* stream);
+/* The same for a tap that relu -> 2x2 max pool follows (VGG16 conv1_2 / 2_2 / 3_3 / 4_3,
+ * reference /root/reference/pix2latent/loss_functions.py:131-142 through lpips' vgg16 slices): the whole
+ * gradient of the conv output f [Bn][H][W][C] in one pass,
+ *   df = (f > 0) ? tap gradient + (f is the first maximum of its quad ? dyp[quad] : 0) : 0
+ * = p2l_lpips_tap_bwd followed by p2l_maxpool2_bwd_amax(add = tap gradient, relu_mask = 1), bit for bit.
+ * dyp [Bn][H/2][W/2][C]; amax_out [Bn][p2l_lpips_tap_nblk(H * W, C)] partial maxima of |df| (P2LAmax.in of
+ * the conv that reads df next) or NULL.  H even, W a multiple of 2 * (pixels per wave of the tap kernel). */
+int p2l_lpips_tap_pool_bwd(const float* f, const float* nft, int64_t nft_bstride,
+                           const float* lin, const float* wt, int64_t wt_bstride,
+                           const float* gscale, const float* dyp, float* df, float* amax_out,
+                           int Bn, int H, int W, int C, void* stream);
 /* adjoint of F.interpolate(bilinear, align_corners=False) from h x w up to   */
 /* H x W: wt[b,q] = sum_p U[p,q] * wsrc[b,p]                                  */
 int p2l_bilinear_adjoint(const float* wsrc, float* wt, int Bn, int H, int W,

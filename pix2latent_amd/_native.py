@@ -247,7 +247,7 @@ EXPORTS = [
     'p2l_relu_mask', 'p2l_nchw3_to_nhwc16', 'p2l_nhwc16_to_nchw3', 'p2l_tanh_bwd16',
     'p2l_weight_sum', 'p2l_weight_map', 'p2l_l1_loss_nblk', 'p2l_l1_loss_fwd',
     'p2l_l1_loss_bwd', 'p2l_lpips_normalize', 'p2l_lpips_tap_nblk', 'p2l_lpips_tap_fwd',
-    'p2l_lpips_tap_bwd', 'p2l_bilinear_adjoint', 'p2l_reduce_rows', 'p2l_adam_step',
+    'p2l_lpips_tap_bwd', 'p2l_lpips_tap_pool_bwd', 'p2l_bilinear_adjoint', 'p2l_reduce_rows', 'p2l_adam_step',
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_affine_grid_sample_bwd', 'p2l_affine_grid_sample_bwd_ws_bytes', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_ws_lookup', 'p2l_projloss_prepare',

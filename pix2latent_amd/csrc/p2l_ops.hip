@@ -565,17 +565,33 @@ struct LpipsK {
   const float* gscale; float* out;  // partial (fwd) or df (bwd)
   long long nft_bstride, wt_bstride;
   int Bn, P, nblk;
+  // backward of a tap that a 2x2 max pool follows (p2l_lpips_tap_pool_bwd): the pooled gradient, the
+  // tap's width in pixels, one partial maximum of |out| per block
+  const float* dyp; float* amax; int W;
 };
 
-template <int C, bool BWD>
+// POOL (backward only): the tap is also the input of relu -> 2x2 max pool; the kernel adds the pool's
+// backward of k.dyp and applies the ReLU mask, i.e. writes the whole gradient of the conv output in one
+// pass (until round 5: tap gradient written, then read again by maxpool2_bwd_kernel with the tensor itself
+// -- 1.9 GB instead of 1.0 GB at the 256^2 tap of 18 candidates).  A block covers 2 rows x 2 PPW columns,
+// whole quads, so the three partner pixels of a quad come from the block's own loads (L1 hits).
+template <int C, bool BWD, bool POOL = false>
 __global__ __launch_bounds__(256) void lpips_tap_kernel(const LpipsK k) {
   using Cfg = LpipsCfg<C>;
   __shared__ float red[4];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / Cfg::LP, ll = lane % Cfg::LP;
-  const int p = (blockIdx.x * 4 + wave) * Cfg::PPW + sub;
-  float contrib = 0.f;
+  int p = (blockIdx.x * 4 + wave) * Cfg::PPW + sub;
+  int py = 0, px = 0;
+  if (POOL) {
+    constexpr int HALF = 2 * Cfg::PPW;                   // columns of a block
+    const int j = wave * Cfg::PPW + sub, bpr = k.W / HALF;
+    py = 2 * (blockIdx.x / bpr) + j / HALF;
+    px = (blockIdx.x % bpr) * HALF + j % HALF;
+    p = py * k.W + px;
+  }
+  float contrib = 0.f, mx = 0.f;
   if (p < k.P) {
     const float* fp = k.f + ((size_t)b * k.P + p) * C;
     const float* tp = k.nft + (size_t)b * k.nft_bstride + (size_t)p * C;
@@ -618,7 +634,30 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const LpipsK k) {
       float* dp = k.out + ((size_t)b * k.P + p) * C;
 #pragma unroll
       for (int i = 0; i < Cfg::VPL; ++i) {
-        const f32x4 g = gsw * (u[i] * inv - c2 * v[i]);
+        f32x4 g = gsw * (u[i] * inv - c2 * v[i]);
+        if (POOL) {
+          const int c = (i * Cfg::LP + ll) * 4, s_own = (py & 1) * 2 + (px & 1);
+          const size_t quad = ((size_t)b * (k.P / k.W / 2) + (py >> 1)) * (k.W >> 1) + (px >> 1);
+          const f32x4 gp = *reinterpret_cast<const f32x4*>(k.dyp + quad * C + c);
+          f32x4 q[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const size_t pix = ((size_t)b * k.P) + (size_t)((py & ~1) + (s >> 1)) * k.W + (px & ~1) + (s & 1);
+            q[s] = *reinterpret_cast<const f32x4*>(k.f + pix * C + c);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // first maximum in window scan order (row-major), as ATen max_pool2d does
+            int arg = 0;
+            float m = q[0][e];
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+              if (q[s][e] > m) { m = q[s][e]; arg = s; }
+            const float r = __fadd_rn((s_own == arg) ? gp[e] : 0.f, g[e]);   // (no contraction: = the two-pass form)
+            g[e] = v[i][e] > 0.f ? r : 0.f;
+          }
+          mx = fmaxf(fmaxf(mx, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
+        }
         *reinterpret_cast<f32x4*>(dp + (i * Cfg::LP + ll) * 4) = g;
       }
     }
@@ -626,6 +665,14 @@ __global__ __launch_bounds__(256) void lpips_tap_kernel(const LpipsK k) {
   if (!BWD) {
     const float s = block_sum_256(contrib, red);
     if (threadIdx.x == 0) k.out[(size_t)b * k.nblk + blockIdx.x] = s;
+  }
+  if (POOL && k.amax != nullptr) {                       // one partial maximum per block (P2LAmax.in of the next dgrad)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      k.amax[(size_t)b * k.nblk + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -1210,6 +1257,27 @@ extern "C" int p2l_lpips_tap_bwd(const float* f, const float* nft,
   k.Bn = Bn; k.P = P; k.nblk = p2l_lpips_tap_nblk(P, C);
 #define CALL(CC)                                                               \
   hipLaunchKernelGGL((lpips_tap_kernel<CC, true>), dim3(k.nblk, Bn), dim3(256), 0, \
+                     ST(stream), k)
+  P2L_LPIPS_DISPATCH(CALL)
+#undef CALL
+  return p2l_check_launch();
+}
+
+// tap backward + 2x2 max-pool backward + ReLU mask in one pass (see lpips_tap_kernel POOL)
+extern "C" int p2l_lpips_tap_pool_bwd(const float* f, const float* nft, int64_t nft_bstride,
+                                      const float* lin, const float* wt, int64_t wt_bstride,
+                                      const float* gscale, const float* dyp, float* df,
+                                      float* amax_out, int Bn, int H, int W, int C, void* stream) {
+  const int lp = lpips_lp(C / 4), half = 2 * (64 / lp);
+  if (!f || !nft || !lin || !wt || !gscale || !dyp || !df) return P2L_EINVAL;
+  if (Bn < 1 || H < 2 || (H & 1) || W < half || W % half) return P2L_EINVAL;
+  LpipsK k{};
+  k.f = f; k.nft = nft; k.lin = lin; k.wt = wt; k.gscale = gscale;
+  k.out = df; k.nft_bstride = nft_bstride; k.wt_bstride = wt_bstride;
+  k.Bn = Bn; k.P = H * W; k.nblk = p2l_lpips_tap_nblk(H * W, C);
+  k.dyp = dyp; k.amax = amax_out; k.W = W;
+#define CALL(CC)                                                                     \
+  hipLaunchKernelGGL((lpips_tap_kernel<CC, true, true>), dim3(k.nblk, Bn), dim3(256), 0, \
                      ST(stream), k)
   P2L_LPIPS_DISPATCH(CALL)
 #undef CALL

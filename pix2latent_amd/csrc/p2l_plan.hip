@@ -901,6 +901,8 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
     if (vgg_pool_after(i) && i >= 1) {
       const int n3 = p2l_maxpool2_bwd_amax_slots(h, w, kVggCout[i]);
       if (n3 > max_slots) max_slots = n3;
+      const int n4 = p2l_lpips_tap_nblk(h * w, kVggCout[i]);      // (the fused tap + pool backward)
+      if (n4 > max_slots) max_slots = n4;
     }
   }
   L.tgt16 = a.take((size_t)B * H * W * 16);
@@ -1105,15 +1107,23 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
       const int k = vgg_tap_of(prev);
       const int hp = H / kVggDiv[prev], wp = W / kVggDiv[prev];
       const int P = hp * wp, C = kVggCout[prev];
-      RET_IF(p2l_lpips_tap_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k],
-                               cache->wt[k], P, Wk + L.gs, gtap, B, P, C, st));
       // (written by a non-conv kernel, which leaves its own maxima for the dgrad that reads ga next)
       amax_drop(ga);
       float* so = nullptr;
       int set_o = -1;
+#ifdef P2L_AB_TAP_POOL_2PASS      // A/B builds: the two-pass form of rounds 1-4
+      RET_IF(p2l_lpips_tap_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k],
+                               cache->wt[k], P, Wk + L.gs, gtap, B, P, C, st));
       const int ns = p2l_maxpool2_bwd_amax_slots(hp, wp, C);
       if (g_amax && prev >= 1 && ns > 0 && (size_t)ns * B <= g_amax->set_floats) so = g_amax->take(&set_o);
       RET_IF(p2l_maxpool2_bwd_amax(Wk + L.y[prev], C, gb, C, gtap, C, ga, C, B, hp, wp, C, 1, so, st));
+#else
+      // tap gradient + pool backward of gb + ReLU mask in one pass over conv_{i-1}'s output
+      const int ns = p2l_lpips_tap_nblk(P, C);
+      if (g_amax && prev >= 1 && ns > 0 && (size_t)ns * B <= g_amax->set_floats) so = g_amax->take(&set_o);
+      RET_IF(p2l_lpips_tap_pool_bwd(Wk + L.y[prev], cache->nft[k], (int64_t)P * C, v->lin[k], cache->wt[k], P,
+                                    Wk + L.gs, gb, ga, so, B, hp, wp, C, st));
+#endif
       if (so) g_amax->put(ga, B, hp, wp, C, so, ns, set_o);
       --pi;
       continue;  // ga already holds the masked gradient of conv_{i-1}

@@ -222,6 +222,17 @@ def maxpool2_bwd(y, dyp, add=None, relu_mask=False):
     return dy
 
 
+def lpips_tap_pool_bwd(f, nft, lin, wt, gscale, dyp, want_amax=False):
+    """gradient of a VGG tap that relu -> max pool follows, in one pass (p2l_lpips_tap_pool_bwd)"""
+    Bn, H, W, Cc = f.shape
+    df = torch.empty_like(f)
+    am = torch.full((Bn, _lib().p2l_lpips_tap_nblk(H * W, Cc)), -1.0, device=f.device) if want_amax else None
+    N.check(_lib().p2l_lpips_tap_pool_bwd(N.ptr(f), N.ptr(nft), N.i64(H * W * Cc), N.ptr(lin), N.ptr(wt),
+                                          N.i64(H * W), N.ptr(gscale), N.ptr(dyp), N.ptr(df), N.ptr(am),
+                                          Bn, H, W, Cc, N.stream()), 'lpips_tap_pool_bwd')
+    return (df, am) if want_amax else df
+
+
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
     N.check(_lib().p2l_adam_step(N.ptr(p), N.ptr(g), N.ptr(m), N.ptr(v), N.i64(p.numel()),
                                  N.f32(lr), N.f32(beta1), N.f32(beta2), N.f32(eps), int(step),

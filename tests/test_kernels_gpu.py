@@ -826,6 +826,42 @@ def test_lpips_tap(dev, O, C):
     assert relerr(nchw(df), f.grad) < 1e-4
 
 
+@pytest.mark.parametrize('C', [64, 128, 256, 512])
+def test_lpips_tap_pool_bwd(dev, O, C):
+    """Round 5: the gradient of a VGG tap that relu -> 2x2 max pool follows, in ONE pass
+    (p2l_lpips_tap_pool_bwd) = tap backward, then pool backward + ReLU mask (the two kernels of rounds 1-4)
+    bit for bit, and = autograd of the torch composition; ties inside a quad (ReLU zeros) go to the first
+    maximum in scan order as ATen's max_pool2d does; the partial maxima cover what was written."""
+    g = torch.Generator().manual_seed(12)
+    B, h = 3, 32
+    pre = torch.randn(B, C, h, h, generator=g).requires_grad_(True)     # conv output before the ReLU
+    ft = F.relu(torch.randn(B, C, h, h, generator=g))
+    lin = torch.rand(C, generator=g) / C
+    wt = torch.rand(B, h, h, generator=g)
+    gs = torch.tensor([0.7, -1.3, 0.4])
+    dyp = torch.randn(B, C, h // 2, h // 2, generator=g)
+
+    def norm(a):
+        return a / (torch.sqrt((a ** 2).sum(1, keepdim=True)) + 1e-10)
+    f = F.relu(pre)
+    d = ((norm(f) - norm(ft)) ** 2 * lin.view(1, C, 1, 1)).sum(1)
+    ((d * wt).sum((1, 2)) * gs).sum().backward(retain_graph=True)
+    (F.max_pool2d(f, 2) * dyp).sum().backward()
+    fd = nhwc(f.detach(), dev)
+    nft = O.lpips_normalize(nhwc(ft, dev))
+    args = (fd, nft, lin.to(dev), wt.to(dev), gs.to(dev))
+    two = O.maxpool2_bwd(fd, nhwc(dyp, dev), add=O.lpips_tap_bwd(*args), relu_mask=True)
+    one, am = O.lpips_tap_pool_bwd(*args, nhwc(dyp, dev), want_amax=True)
+    assert torch.equal(one, two), 'the one-pass form differs from tap backward + pool backward'
+    assert relerr(nchw(one), pre.grad) < 1e-4
+    assert bool((am >= 0).all()), 'a promised maxima slot was not written'
+    assert torch.equal(am.amax(dim=1), one.abs().amax(dim=(1, 2, 3)))
+    # wrong geometry is refused, not computed
+    from pix2latent_amd import _native as N
+    with pytest.raises(N.NativeError):
+        O.lpips_tap_pool_bwd(fd[:, :31].contiguous(), nft, lin.to(dev), wt.to(dev), gs.to(dev), nhwc(dyp, dev))
+
+
 def test_affine_grid_sample_kernel(dev):
     """fused affine-grid + bilinear grid-sample vs the two torch ops the reference calls"""
     from pix2latent_amd.transform import SpatialTransform
