@@ -209,68 +209,77 @@ __global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const ArbK k) {
 }
 
 // second stage of the per-(sample, channel) sums: partial[2][B][nblk][C] -> ds, dt.
-// grid (C/64, B); 16 segments x 16 channel-float4 lanes per block, each thread adds its
-// segment's tiles in order, then the 16 segments are combined in a fixed order.
-__global__ __launch_bounds__(256) void arb_finish_kernel(const float* partial, float* ds,
-                                                         float* dt, int Bn, int nblk, int C,
-                                                         int out_bstride) {
-  __shared__ f32x4 red_s[256], red_t[256];
+// grid (C/64, B); 16 segments x 16 channel-float4 lanes per block; a thread adds its segment's rows
+// (seg, seg + 16, ...) in FOUR independent chains (row index / 16 mod 4), combined ((0 + 1) + (2 + 3)), then
+// the segments in a fixed order -- an order set by the constants, the same for the per-layer and the
+// grouped launch and for every batch.  (Round 5: four chains instead of one -- the 256^2 layers hold 2048
+// partial rows per image and 36 blocks work on them, a 128-deep chain of dependent loads; 64 segments of
+// 1024 threads were tried first and lost more to dispatching the group's 27 k mostly empty blocks.)
+constexpr int ARB_SEGS = 16, ARB_CHAINS = 4;
+__device__ __forceinline__ void arb_finish_body(const float* partial, float* ds, float* dt, int Bn,
+                                                int nblk, int C, int out_bstride, int cgroup, int b,
+                                                f32x4* red_s, f32x4* red_t) {
   const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
-  const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
+  const int c = cgroup * 64 + cl * 4;
   const size_t half = (size_t)Bn * nblk * C;
-  f32x4 a = {0, 0, 0, 0}, t = {0, 0, 0, 0};
+  f32x4 a[ARB_CHAINS], t[ARB_CHAINS];
+#pragma unroll
+  for (int q = 0; q < ARB_CHAINS; ++q) { a[q] = f32x4{0, 0, 0, 0}; t[q] = f32x4{0, 0, 0, 0}; }
   const bool live = c < C;
-  for (int j = seg; live && j < nblk; j += 16) {
-    const size_t o = ((size_t)b * nblk + j) * C + c;
-    a += *reinterpret_cast<const f32x4*>(partial + o);
-    t += *reinterpret_cast<const f32x4*>(partial + half + o);
+  if (live) {
+    int j = seg;
+    for (; j + (ARB_CHAINS - 1) * ARB_SEGS < nblk; j += ARB_CHAINS * ARB_SEGS) {
+#pragma unroll
+      for (int q = 0; q < ARB_CHAINS; ++q) {
+        const size_t o = ((size_t)b * nblk + j + q * ARB_SEGS) * C + c;
+        a[q] += *reinterpret_cast<const f32x4*>(partial + o);
+        t[q] += *reinterpret_cast<const f32x4*>(partial + half + o);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < ARB_CHAINS - 1; ++q) {
+      if (j + q * ARB_SEGS < nblk) {
+        const size_t o = ((size_t)b * nblk + j + q * ARB_SEGS) * C + c;
+        a[q] += *reinterpret_cast<const f32x4*>(partial + o);
+        t[q] += *reinterpret_cast<const f32x4*>(partial + half + o);
+      }
+    }
+    a[0] = (a[0] + a[1]) + (a[2] + a[3]);
+    t[0] = (t[0] + t[1]) + (t[2] + t[3]);
   }
-  red_s[tid] = a;
-  red_t[tid] = t;
+  red_s[tid] = a[0];
+  red_t[tid] = t[0];
   __syncthreads();
   if (seg == 0 && live) {
+    f32x4 sa = a[0], st = t[0];
 #pragma unroll
-    for (int j = 1; j < 16; ++j) {
-      a += red_s[j * 16 + cl];
-      t += red_t[j * 16 + cl];
+    for (int k = 1; k < ARB_SEGS; ++k) {
+      sa += red_s[k * 16 + cl];
+      st += red_t[k * 16 + cl];
     }
-    *reinterpret_cast<f32x4*>(ds + (size_t)b * out_bstride + c) = a;
-    *reinterpret_cast<f32x4*>(dt + (size_t)b * out_bstride + c) = t;
+    *reinterpret_cast<f32x4*>(ds + (size_t)b * out_bstride + c) = sa;
+    *reinterpret_cast<f32x4*>(dt + (size_t)b * out_bstride + c) = st;
   }
 }
+__global__ __launch_bounds__(ARB_SEGS * 16) void arb_finish_kernel(const float* partial, float* ds,
+                                                                   float* dt, int Bn, int nblk, int C,
+                                                                   int out_bstride) {
+  __shared__ f32x4 red_s[ARB_SEGS * 16], red_t[ARB_SEGS * 16];
+  arb_finish_body(partial, ds, dt, Bn, nblk, C, out_bstride, blockIdx.x, blockIdx.y, red_s, red_t);
+}
 
-// the same reduction for up to ARB_GROUP_MAX recorded layers in one launch:
-// grid (max channel groups, B, layers)
+// the same reduction for up to ARB_GROUP_MAX recorded layers in one launch: grid (all channel groups of
+// all layers, B); e[i].first = the first block of layer i
 constexpr int ARB_GROUP_MAX = 56;
-struct ArbFin { const float* partial; float* ds; float* dt; int nblk, C, bstride, pad; };
+struct ArbFin { const float* partial; float* ds; float* dt; int nblk, C, bstride, first; };
 struct ArbFinGroup { ArbFin e[ARB_GROUP_MAX]; int n, Bn; };
-__global__ __launch_bounds__(256) void arb_finish_group_kernel(const ArbFinGroup g) {
-  __shared__ f32x4 red_s[256], red_t[256];
-  const ArbFin& e = g.e[blockIdx.z];
-  const int C = e.C, nblk = e.nblk;
-  if ((int)blockIdx.x * 64 >= C) return;
-  const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
-  const int c = blockIdx.x * 64 + cl * 4, b = blockIdx.y;
-  const size_t half = (size_t)g.Bn * nblk * C;
-  f32x4 a = {0, 0, 0, 0}, t = {0, 0, 0, 0};
-  const bool live = c < C;
-  for (int j = seg; live && j < nblk; j += 16) {
-    const size_t o = ((size_t)b * nblk + j) * C + c;
-    a += *reinterpret_cast<const f32x4*>(e.partial + o);
-    t += *reinterpret_cast<const f32x4*>(e.partial + half + o);
-  }
-  red_s[tid] = a;
-  red_t[tid] = t;
-  __syncthreads();
-  if (seg == 0 && live) {
-#pragma unroll
-    for (int j = 1; j < 16; ++j) {
-      a += red_s[j * 16 + cl];
-      t += red_t[j * 16 + cl];
-    }
-    *reinterpret_cast<f32x4*>(e.ds + (size_t)b * e.bstride + c) = a;
-    *reinterpret_cast<f32x4*>(e.dt + (size_t)b * e.bstride + c) = t;
-  }
+__global__ __launch_bounds__(ARB_SEGS * 16) void arb_finish_group_kernel(const ArbFinGroup g) {
+  __shared__ f32x4 red_s[ARB_SEGS * 16], red_t[ARB_SEGS * 16];
+  int l = 0;
+  while (l + 1 < g.n && (int)blockIdx.x >= g.e[l + 1].first) ++l;      // (uniform: scalar loads)
+  const ArbFin& e = g.e[l];
+  arb_finish_body(e.partial, e.ds, e.dt, g.Bn, e.nblk, e.C, e.bstride, (int)blockIdx.x - e.first, blockIdx.y,
+                  red_s, red_t);
 }
 thread_local bool g_arb_defer = false;
 thread_local ArbFinGroup g_arb_group;
@@ -975,8 +984,18 @@ extern "C" int p2l_linear_fwd(const float* x, const float* W, const float* bias,
 extern "C" int p2l_linear_fwd_ld(const float* x, int x_ld, const float* W, const float* bias,
                                  float* y, int Bn, int K, int N, void* stream) {
   if (!x || !W || !y || K % 4 || K > 1024 || Bn < 1) return P2L_EINVAL;
-  constexpr int BG = 16;
+  // every launch streams W once: rows in groups of 16, or of 24 when that saves a launch (the
+  // population of 18: one pass over the 33 MB gen_z matrix instead of two); a row's sum does not
+  // depend on its group
+  constexpr int BG = 16, BGW = 24;
   const size_t lds = (size_t)(BG * K + 4 * BG * 64) * sizeof(float);
+  const size_t ldsw = (size_t)(BGW * K + 4 * BGW * 64) * sizeof(float);
+  if (cdiv(Bn, BGW) < cdiv(Bn, BG) && ldsw <= 64 * 1024) {
+    for (int b0 = 0; b0 < Bn; b0 += BGW)
+      hipLaunchKernelGGL(linear_fwd_kernel<BGW>, dim3(cdiv(N, 64)), dim3(256), ldsw,
+                         ST(stream), x, W, bias, y, Bn, b0, K, N, x_ld);
+    return p2l_check_launch();
+  }
   for (int b0 = 0; b0 < Bn; b0 += BG) {
     hipLaunchKernelGGL(linear_fwd_kernel<BG>, dim3(cdiv(N, 64)), dim3(256), lds,
                        ST(stream), x, W, bias, y, Bn, b0, K, N, x_ld);
@@ -993,7 +1012,13 @@ extern "C" int p2l_linear_bwd(const float* dy, const float* W, float* dx, int Bn
 extern "C" int p2l_linear_bwd_ld(const float* dy, const float* W, float* dx, int dx_ld, int Bn,
                                  int K, int N, int accumulate, void* stream) {
   if (!dy || !W || !dx || Bn < 1 || (N % 4)) return P2L_EINVAL;
-  constexpr int BG = 16;
+  constexpr int BG = 16, BGW = 24;      // (as p2l_linear_fwd_ld: 24 rows per pass over W when that saves one)
+  if (cdiv(Bn, BGW) < cdiv(Bn, BG)) {
+    for (int b0 = 0; b0 < Bn; b0 += BGW)
+      hipLaunchKernelGGL(linear_bwd_kernel<BGW>, dim3(K), dim3(1024), 0, ST(stream), dy,
+                         W, dx, Bn, b0, K, N, accumulate, dx_ld);
+    return p2l_check_launch();
+  }
   for (int b0 = 0; b0 < Bn; b0 += BG)
     hipLaunchKernelGGL(linear_bwd_kernel<BG>, dim3(K), dim3(1024), 0, ST(stream), dy,
                        W, dx, Bn, b0, K, N, accumulate, dx_ld);
@@ -1051,9 +1076,9 @@ extern "C" void p2l_arb_defer_cancel(void) {
 static int arb_group_launch(void* stream) {
   ArbFinGroup& g = g_arb_group;
   if (g.n == 0) return P2L_OK;
-  int cmax = 0;
-  for (int i = 0; i < g.n; ++i) cmax = g.e[i].C > cmax ? g.e[i].C : cmax;
-  hipLaunchKernelGGL(arb_finish_group_kernel, dim3(cdiv(cmax, 64), g.Bn, g.n), dim3(256), 0,
+  int total = 0;
+  for (int i = 0; i < g.n; ++i) { g.e[i].first = total; total += cdiv(g.e[i].C, 64); }
+  hipLaunchKernelGGL(arb_finish_group_kernel, dim3(total, g.Bn), dim3(ARB_SEGS * 16), 0,
                      ST(stream), g);
   g.n = 0;
   return p2l_check_launch();
@@ -1076,7 +1101,7 @@ extern "C" int p2l_arb_finish(const float* partial, float* ds, float* dt, int Bn
     g.e[g.n++] = ArbFin{partial, ds, dt, nblk, C, out_bstride, 0};
     return P2L_OK;
   }
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream),
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(ARB_SEGS * 16), 0, ST(stream),
                      partial, ds, dt, Bn, nblk, C, out_bstride);
   return p2l_check_launch();
 }
@@ -1095,7 +1120,7 @@ extern "C" int p2l_scale_bwd(const float* da, int da_ld, const float* x, int x_l
   k.Bn = Bn; k.P = H * W; k.C = C; k.H = H; k.W = W; k.nomask = 1;
   k.nblk = cdiv(k.P, ARB_SLAB);
   hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, cdiv(C, 64), Bn), dim3(256), 0, ST(stream), k);
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(256), 0, ST(stream), partial, ds,
+  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(ARB_SEGS * 16), 0, ST(stream), partial, ds,
                      dt_scratch, Bn, k.nblk, C, dsdt_bstride);
   return p2l_check_launch();
 }

@@ -602,12 +602,14 @@ def test_winograd_block_shapes_bit_identical(dev, O, arb):
         assert (h - a).abs().max().item() <= 2e-5 * a.abs().max().item()
 
 
-def test_arb_finish_deferred_group(dev, O):
+@pytest.mark.parametrize('H', [16, 128])
+def test_arb_finish_deferred_group(dev, O, H):
     """p2l_arb_defer_begin/flush: the second reduction stage of several activation-backwards
-    in ONE launch gives exactly what the per-layer launches give."""
+    in ONE launch gives exactly what the per-layer launches give (H = 128: more partial rows than
+    segments, both chains of a segment in use)."""
     from pix2latent_amd import _native as N
     g = torch.Generator().manual_seed(21)
-    B, H = 2, 16
+    B = 2
     cases = []
     for C, Co, taps in ((64, 128, 9), (128, 64, 1), (96, 64, 1)):
         k = 3 if taps == 9 else 1
@@ -699,7 +701,7 @@ def test_gemm_splitk(dev, O, akm, bkm):
     assert relerr(C2.cpu().double(), 2 * ref) < 2e-5
 
 
-@pytest.mark.parametrize('Bn', [1, 9, 18])
+@pytest.mark.parametrize('Bn', [1, 9, 18, 24, 40])
 def test_linear_fwd_bwd(dev, O, Bn):
     g = torch.Generator().manual_seed(4)
     K, Nn = 256, 1000  # Nn % 4 == 0
@@ -713,6 +715,10 @@ def test_linear_fwd_bwd(dev, O, Bn):
     assert relerr(dx.cpu(), dy @ W.t()) < 1e-5
     dx2 = O.linear_bwd(dy.to(dev), W.to(dev), dx=dx.clone())
     assert relerr(dx2.cpu(), 2 * (dy @ W.t())) < 1e-5
+    # a row's bits do not depend on the rows it shares a pass over W with (groups of 16 | 24 rows)
+    r = Bn - 1
+    assert torch.equal(O.linear_fwd(x[r:].to(dev), W.to(dev), b.to(dev))[0], y[r])
+    assert torch.equal(O.linear_bwd(dy[r:].to(dev), W.to(dev))[0], dx[r])
 
 
 @pytest.mark.parametrize('skip', [None, 'same', 'ups'])
