@@ -137,14 +137,14 @@ def cpu_baseline(problem, chunk=MAX_BATCH):
 
 class _GpuTelemetry(object):
     """socket power and shader clock of the bench GPU while the timed steps run, read from the
-    amdgpu hwmon files at ~20 Hz on a side thread (no rocm-smi process; null when the files are
+    amdgpu hwmon files at ~4 Hz on a side thread (20 Hz cost the timed steps 0.4 %: every read is an SMU query) (no rocm-smi process; null when the files are
     not there).  The kernels of this step are power-limited: the clock a number was
     measured at belongs next to the number."""
 
-    def __init__(self, index=0):
+    def __init__(self, index=0, enabled=True):
         import glob
         self.paths = None
-        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'))
+        cards = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')) if enabled else []
         cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
         # the box shows every GPU of the node in sysfs; the one this process runs on is found by
         # its PCI address
@@ -177,7 +177,7 @@ class _GpuTelemetry(object):
                 self.power.append(pw * 1e-6)
             if fq is not None:
                 self.sclk.append(fq * 1e-6)
-            time.sleep(0.05)
+            time.sleep(0.25)
 
     def __enter__(self):
         if self.paths is not None:
@@ -436,9 +436,11 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--prof-period', type=int, default=10,
+    ap.add_argument('--prof-period', type=int, default=20,
                     help='time every N-th conv launch with hipEvents inside the timed steps '
                          '(1 = every launch; costs ~5 %% of the step)')
+    ap.add_argument('--no-telemetry', action='store_true',
+                    help='do not sample socket power / shader clock while the timed steps run')
     ap.add_argument('--no-fp32-leg', action='store_true',
                     help='skip the extra exact-fp32-MFMA measurement reported in config')
     ap.add_argument('--no-extra', action='store_true',
@@ -504,7 +506,7 @@ def main():
     # step); time every PERIOD-th launch, rotating the phase with the step, so that each
     # launch of the step is timed once per PERIOD steps
     period = max(1, min(args.prof_period, args.steps))
-    with _GpuTelemetry(local_rank) as telemetry:
+    with _GpuTelemetry(local_rank, enabled=not args.no_telemetry) as telemetry:
         t0 = time.perf_counter()
         for i in range(args.steps):
             lib.p2l_prof_step(i, period)
