@@ -344,7 +344,7 @@ def full_schedule_and_default_loss(dev, ms_per_step):
     out = {}
     with contextlib.redirect_stdout(sys.stderr):
         torch.manual_seed(0)
-        opt, vm, _ = build_problem(dev, exec_batch_size=POP)
+        opt, vm, _ = build_problem(dev, exec_batch_size=MAX_BATCH)
         opt.show_iter = 10 ** 9
         told = []
         score = opt.losses_for_tell
@@ -390,7 +390,7 @@ def full_schedule_and_default_loss(dev, ms_per_step):
         del opt, vm
         torch.cuda.empty_cache()
         torch.manual_seed(0)
-        opt, vm, _ = build_problem(dev, exec_batch_size=POP, lpips_net='alex')
+        opt, vm, _ = build_problem(dev, exec_batch_size=MAX_BATCH, lpips_net='alex')
         opt.setup_cma(vm)
         variables = opt.cma_init(vm)
         dt = _time_steps(lambda first: opt.step(variables, optimize=True, transform=first), 3, 5)
@@ -401,6 +401,36 @@ def full_schedule_and_default_loss(dev, ms_per_step):
                     '(reference loss_functions.py:89): L1 + 10*LPIPS-AlexNet',
             'evals_per_s': round(POP / dt, 1), 'ms_per_step': round(1e3 * dt, 2), 'candidates': POP}
     return out
+
+
+def alone_leg(opt, variables, lib, bf3, steps=4):
+    """the 3x3 launches of the step with nothing beside them: one pass of the whole population on one stream
+    (exec_batch_size = population), every launch of `steps` steps timed once"""
+    from pix2latent_amd import _native as N
+    saved = opt.exec_batch_size
+    opt.exec_batch_size = POP
+    try:
+        opt.step(variables, optimize=True)               # (workspaces of the 18-candidate pass)
+        torch.cuda.synchronize()
+        N.check(lib.p2l_prof_begin(4096), 'p2l_prof_begin')
+        t0 = time.perf_counter()
+        for i in range(steps):
+            lib.p2l_prof_step(i, steps)
+            opt.step(variables, optimize=True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        T = N.prof_end()
+    finally:
+        opt.exec_batch_size = saved
+    ms, cnt = T.ms[0], max(T.count[0], 1)
+    peak = BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS
+    ach = (T.mfma_flops[0] if bf3 else T.exec_flops[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'what': 'one pass of %d candidates on one stream (exec_batch_size = population), %d steps after the '
+                    'timed region, every 3x3 launch timed once' % (POP, steps),
+            'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'algorithmic_tflops': round(T.flops[0] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+            'avg_launch_ms': round(ms / cnt, 4), 'sampled_launches': int(T.count[0]),
+            'ms_per_step': round(1e3 * el / steps, 3)}
 
 
 def exact_fp32_leg(dev, args):
@@ -450,10 +480,11 @@ def main():
                          "reference's ProjectionLoss() default, reported as a side configuration")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) or "
                     "'gloo' (test only: lets several ranks share one GPU)")
-    ap.add_argument('--exec-batch', type=int, default=POP,
-                    help='candidates pushed through the device per pass (semantic chunk '
-                         'size stays max_batch_size=9); 9 = execute chunk by chunk like '
-                         'the reference')
+    ap.add_argument('--exec-batch', type=int, default=MAX_BATCH,
+                    help='candidates pushed through the device per pass (semantic chunk size stays '
+                         'max_batch_size=9).  9 (default) = the reference chunks, which the fused step runs '
+                         'as two lanes on two HIP streams (pix2latent_amd/lanes.py; P2L_STREAMS=1: one '
+                         'after the other); 18 = one pass of the whole population on one stream')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -499,6 +530,7 @@ def main():
     for i in range(args.warmup):
         opt.step(variables, optimize=True, transform=(i == 0))
     sync()
+    lanes_used = max(1, len(getattr(opt.model, '_lanes', {})))    # (sets of workspaces the model was asked for)
     lib = N.lib()
     n_prof = 4096
     N.check(lib.p2l_prof_begin(n_prof), 'p2l_prof_begin')
@@ -594,6 +626,8 @@ def main():
                 'population': POP,
                 'max_batch_size': MAX_BATCH,
                 'exec_batch_size': args.exec_batch,
+                'lanes': lanes_used,
+                'lanes_note': 'reference chunks of 9 on %d HIP streams, one set of workspaces each; same bits as one stream (tests/test_shard_bits_gpu.py)' % lanes_used if lanes_used > 1 else 'one stream',
                 'conv3x3_arithmetic': 'fp16x2 (16x16 Winograd kernel >= 128 channels; direct / sub-pixel kernel for 64-channel, up-sampling and small layers; 1x1 kernels; fused attention) + bf16x3 (3-channel image convs)' if bf3 else 'f32',
                 'lpips_net': args.lpips_net,
                 'parallelism': 'population sharded over %d rank(s)' % world,
@@ -671,6 +705,15 @@ def main():
             },
             'telemetry': telemetry.summary(),
         }
+        if lanes_used > 1:
+            # two streams: a launch's hipEvent duration includes the time it shares the GPU with the other
+            # lane's launches, so `achieved` above is what a launch gets WHILE OVERLAPPED (the step is faster,
+            # each launch slower).  The same launches ALONE -- one pass of 18 on one stream, a few more steps
+            # outside the timed region -- say what the kernel itself does:
+            rec['roofline']['concurrency'] = ('%d lanes: durations are measured while the other lane runs; '
+                                              'time_share_of_step sums overlapping intervals' % lanes_used)
+            if world == 1:
+                rec['roofline']['alone'] = alone_leg(opt, variables, lib, bf3)
         if world == 1 and bf3 and not args.no_fp32_leg:
             # the same steps with every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
             # reported beside `value` so the arithmetic choice is visible in one line

@@ -1,0 +1,66 @@
+"""Execution lanes: the reference chunks of one step on separate HIP streams.
+
+The reference evaluates a population chunk by chunk (`max_batch_size` = 9 of 18; reference
+pix2latent/optimizer/closure.py:23-27), each chunk forward -> loss -> backward -> Adam on its own rows:
+the chunks are independent.  On an MI355X one chunk of 9 leaves the 4^2 ... 16^2 layers of the generator
+and the loss network latency-bound (a few dozen blocks on 256 CUs), and so does one pass of 18; two chunks
+in flight on two streams fill each other's gaps: 16.4 -> 15.2 ms per step of 18 (tools/two_stream_probe.py).
+Such a step is replayed as ONE HIP graph with two branches by default (optimizer/base_optimizer.py): 2 launches
+instead of 520 per step on the host.
+Results are the same bits as one stream (a candidate's arithmetic does not depend on what runs beside it).
+
+A lane = a stream + its own workspaces in every object that keeps device scratch (the generator's arena
+and image staging, the loss's arena); objects advertise `lanes_ok = True` and look the current lane up
+here.  Lane 0 on the caller's stream is the only one unless closure.step opens more.
+"""
+import os
+
+import torch
+
+_current = 0
+_side = {}
+
+
+def current():
+    return _current
+
+
+class use(object):
+    """`with use(k):` -- workspaces of lane k (no stream switch: see `stream`)"""
+
+    def __init__(self, lane):
+        self.lane = lane
+
+    def __enter__(self):
+        global _current
+        self.prev, _current = _current, self.lane
+        return self
+
+    def __exit__(self, *a):
+        global _current
+        _current = self.prev
+
+
+def wanted(n_chunks, *objs):
+    """number of lanes for a step of n_chunks reference chunks over objs (model, loss): $P2L_STREAMS
+    (default 2; 1 = off) when every object has per-lane workspaces.  Also while a HIP graph is being captured:
+    the side streams fork from the capturing stream and join it again, the graph gets two branches and the
+    replay runs them side by side (measured: 15.3 ms replayed, 15.5 eager, 19.6 replayed on one stream)"""
+    try:
+        want = int(os.environ.get('P2L_STREAMS', '2'))
+    except ValueError:
+        want = 2
+    if n_chunks < 2 or want < 2 or not torch.cuda.is_available():
+        return 1
+    if not all(getattr(o, 'lanes_ok', False) for o in objs):
+        return 1
+    return min(want, n_chunks)
+
+
+def side_streams(device, n):
+    """n streams of `device`, made once per process"""
+    key = str(device)
+    have = _side.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from . import _native as N
+from . import lanes
 from .utils import synthetic
 
 LPIPS_SHIFT = (-.030, -.088, -.188)
@@ -193,6 +194,18 @@ class _CacheSlot(object):
         self.B = B
 
 
+class _EngineLane(object):
+    def __init__(self):
+        self.ws, self.ws_bytes, self.shape = None, 0, None
+        self.img16 = self.dimg16 = None
+        self.fwd_ticket = 0
+
+
+def _lane_attr(name):
+    return property(lambda self: getattr(self._lane(), name),
+                    lambda self, v: setattr(self._lane(), name, v))
+
+
 class _LossEngine(object):
     """workspace + target caches for p2l_projloss_*; one per loss object.
 
@@ -217,25 +230,38 @@ class _LossEngine(object):
             self.f_ws, self.f_cache = lib.p2l_projloss_ws_bytes, lib.p2l_loss_cache_floats
             self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_projloss_prepare, lib.p2l_projloss_fwd,
                                                       lib.p2l_projloss_bwd)
-        self.shape = None
-        self.ws = None
+        self.res = None          # (H, W) the caches were made at
+        self._lanes = {}         # lane -> _EngineLane: arena + image staging of one stream (lanes.py)
         self.slots = {}          # key -> _CacheSlot (insertion order = LRU order; equal content shares a slot)
         self.keep = {}           # key -> the tensors it identifies (kept alive)
         self.cache = None        # P2LLossCache of the slot bound by the last prepare()
         self._memo = {}
-        self._fwd_ticket = 0
         self.generation = 0
+
+    # per-lane scratch (the cached target features are shared: read-only while steps run)
+    lanes_ok = True
+
+    def _lane(self):
+        k = lanes.current()
+        st = self._lanes.get(k)
+        if st is None:
+            st = self._lanes[k] = _EngineLane()
+        return st
+
+    ws, ws_bytes, shape = _lane_attr('ws'), _lane_attr('ws_bytes'), _lane_attr('shape')
+    _img16, _dimg16, _fwd_ticket = _lane_attr('img16'), _lane_attr('dimg16'), _lane_attr('fwd_ticket')
 
     def _alloc(self, B, H, W, dev):
         """workspace + image staging sized for the LARGEST chunk seen at this resolution: a
         ragged last chunk (32 samples = 9,9,9,5) alternates B every step, and re-allocating
         would also drop the cached target features of every chunk"""
-        if self.shape is not None and self.shape[1:] == (H, W) and B <= self.shape[0]:
+        if self.res != (H, W):
+            # resolution changed: caches are void, and so is every lane's scratch
+            self.slots, self.keep, self._lanes, self.res = {}, {}, {}, (H, W)
+        if self.shape is not None and B <= self.shape[0]:
             return
-        if self.shape is not None and self.shape[1:] == (H, W):
+        if self.shape is not None:
             B = max(B, self.shape[0])
-        else:
-            self.slots, self.keep = {}, {}           # resolution changed: caches are void
         nbytes = self.f_ws(B, H, W)
         if nbytes == 0:
             raise N.NativeError('loss workspace sizing rejected shape %s' % ((B, H, W),))
@@ -359,6 +385,15 @@ class _LossEngine(object):
             slot.held = (target, weight, loss_mask)
             slot.versions = tuple(None if t is None else t._version for t in slot.held)
             slot.use_lpips = use_lpips
+            # another lane (stream) may be the next reader of these features
+            capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            slot.ready = None if capturing else torch.cuda.current_stream().record_event()
+            slot.seen_by = {torch.cuda.current_stream().cuda_stream}
+        elif getattr(slot, 'ready', None) is not None and \
+                torch.cuda.current_stream().cuda_stream not in slot.seen_by and \
+                not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_event(slot.ready)     # (once per stream)
+            slot.seen_by.add(torch.cuda.current_stream().cuda_stream)
         if len(self.slots) >= 2 * self.MAX_SLOTS:                 # (keys, several may share a slot)
             lru = next(iter(self.slots))
             self.slots.pop(lru)

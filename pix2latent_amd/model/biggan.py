@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
+from .. import lanes
 from ..utils import synthetic
 
 BN_EPS = 1e-4
@@ -57,6 +58,7 @@ class _BigGANFn(torch.autograd.Function):
         c = c.contiguous().float()
         out = model._run_forward(z, c)
         ctx.model = model
+        ctx.lane = lanes.current()
         ctx.ticket = model._ticket
         ctx.save_for_backward(z, c)
         return out
@@ -65,12 +67,27 @@ class _BigGANFn(torch.autograd.Function):
     def backward(ctx, dout):
         model = ctx.model
         z, c = ctx.saved_tensors
-        if model._ticket != ctx.ticket:
-            # another forward reused the workspace: rebuild the saved activations
-            model._run_forward(z, c)
-            ctx.ticket = model._ticket
-        dz, dc = model._run_backward(z.shape[0], dout)
+        with lanes.use(ctx.lane):        # (the saved activations live in the forward's lane)
+            if model._ticket != ctx.ticket:
+                # another forward reused the workspace: rebuild the saved activations
+                model._run_forward(z, c)
+                ctx.ticket = model._ticket
+            dz, dc = model._run_backward(z.shape[0], dout)
         return dz, dc, None
+
+
+class _Lane(object):
+    """the device scratch of one execution lane (lanes.py): arena, image staging, forward ticket"""
+
+    def __init__(self):
+        self.ws, self.ws_bytes, self.ws_B = None, 0, -1
+        self.img16 = self.dimg16 = None
+        self.ticket, self.last_B = 0, 0
+
+
+def _lane_attr(name):
+    return property(lambda self: getattr(self._lane_state(), name),
+                    lambda self, v: setattr(self._lane_state(), name, v))
 
 
 class BigGAN(nn.Module):
@@ -127,11 +144,8 @@ class BigGAN(nn.Module):
                            (N.WFMT_FLAG_THIN if self._thin else 0) |
                            (N.WFMT_FLAG_ATTN_GEMM if N.default_attn_gemm() else 0) |
                            (N.WFMT_FLAG_NO_AMAX if N.default_no_amax() else 0))
-        self._ws = None
-        self._ws_B = -1
+        self._lanes = {}         # lane -> _Lane (lanes.py: one per stream that runs chunks of a step)
         self.ws_generation = 0
-        self._ticket = 0
-        self._img16 = None
         self._pack(weights)
         self._set_truncation(1.0)
 
@@ -243,6 +257,18 @@ class BigGAN(nn.Module):
         self.truncation = truncation
 
     # -------------------------------------------------------------- execution
+    lanes_ok = True              # per-lane workspaces: chunks of one step may run on several streams
+    _ws, _ws_bytes, _ws_B = _lane_attr('ws'), _lane_attr('ws_bytes'), _lane_attr('ws_B')
+    _img16, _dimg16 = _lane_attr('img16'), _lane_attr('dimg16')
+    _ticket, _last_B = _lane_attr('ticket'), _lane_attr('last_B')
+
+    def _lane_state(self):
+        k = lanes.current()
+        st = self._lanes.get(k)
+        if st is None:
+            st = self._lanes[k] = _Lane()
+        return st
+
     def _workspace(self, B):
         # sized for the largest batch seen: a ragged last chunk must not re-allocate GBs
         # twice per step (the plan lays the arena out from the B of each call)

@@ -23,10 +23,25 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
+from .. import lanes
 from ..utils import synthetic
 
 IM_DIM = {'cars': 512, 'ffhq': 1024}
 LR_MLP = 0.01
+
+
+class _Lane(object):
+    """the device scratch of one execution lane (lanes.py)"""
+
+    def __init__(self):
+        self.ws, self.ws_bytes, self.ws_B = None, 0, -1
+        self.img16 = self.dimg16 = None
+        self.ticket = 0
+
+
+def _lane_attr(name):
+    return property(lambda self: getattr(self._lane_state(), name),
+                    lambda self, v: setattr(self._lane_state(), name, v))
 
 
 class _SynthFn(torch.autograd.Function):
@@ -47,11 +62,17 @@ class _SynthFn(torch.autograd.Function):
         N.check(lib.p2l_nhwc16_to_nchw3(N.ptr(model._img16), N.ptr(out), B, S, S, N.stream()),
                 'p2l_nhwc16_to_nchw3')
         ctx.model, ctx.ticket, ctx.want_dnoise = model, model._ticket, want_dnoise
+        ctx.lane = lanes.current()
         ctx.save_for_backward(latent, noise_lm)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        with lanes.use(ctx.lane):        # (the saved activations live in the forward's lane)
+            return _SynthFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         model = ctx.model
         latent, noise_lm = ctx.saved_tensors
         if model._ticket != ctx.ticket:
@@ -119,7 +140,7 @@ class StyleGAN2(nn.Module):
         self._desc = N.P2LStyleGAN2()
         self._wfmt = N.default_wfmt() if wfmt is None else wfmt
         self._desc.wfmt = self._wfmt
-        self._ws, self._ws_B, self._ticket = None, -1, 0
+        self._lanes = {}         # lane -> _Lane: arena + image staging of one stream (lanes.py)
         self.ws_generation = 0
         self._pack(weights)
         self.search = search
@@ -202,6 +223,17 @@ class StyleGAN2(nn.Module):
             r.bias = self._t(b32)
         d.n_rgb = len(rgb_names)
         self._noise_sizes = [s[-1] * s[-2] for s in self.noise_shape]
+
+    lanes_ok = True              # per-lane workspaces: chunks of one step may run on several streams
+    _ws, _ws_bytes, _ws_B = _lane_attr('ws'), _lane_attr('ws_bytes'), _lane_attr('ws_B')
+    _img16, _dimg16, _ticket = _lane_attr('img16'), _lane_attr('dimg16'), _lane_attr('ticket')
+
+    def _lane_state(self):
+        k = lanes.current()
+        st = self._lanes.get(k)
+        if st is None:
+            st = self._lanes[k] = _Lane()
+        return st
 
     def _ensure_ws(self, B):
         # sized for the largest batch seen (32 samples = chunks of 9,9,9,5 alternate B)

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import torch
 
+from .. import lanes
 from .closure import step, apply_hooks, LazyLosses
 from .search_loop import SearchLoopMixin
 from ..parallel import PopulationShard, ShardedLosses
@@ -256,7 +257,20 @@ class _BaseOptimizer(SearchLoopMixin):
             # a hook is replayed verbatim: its strength must not be a host number that changes
             if var.hook_fn is not None and not getattr(var.hook_fn, 'graph_safe', False):
                 return False
-        return True if self.use_graph else local_n <= 6
+        return True if self.use_graph else self._graph_default(local_n)
+
+    def _graph_default(self, local_n):
+        """graph replay of the inner step unless told otherwise: where the step is launch-bound (<= 6
+        local candidates) and where it runs as lanes on several streams (two reference chunks or more:
+        520 launches per step of 18 on the host otherwise, and one graph with two branches replays
+        faster than the eager streams)"""
+        if local_n <= 6:
+            return True
+        ebs = self.exec_batch_size
+        chunked = ebs is None or (ebs != 'all' and ebs <= self.max_batch_size)
+        n_chunks = -(-local_n // self.max_batch_size) if chunked else 1
+        return (not self.shard.enabled) and lanes.wanted(
+            n_chunks, self.model, getattr(self.loss_fn, '_engine', None)) > 1
 
     def _graphed_step(self, variables, optimize, transform, lo, hi):
         """optimize steps without a transform, on variables whose device buffers were seen

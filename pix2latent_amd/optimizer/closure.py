@@ -24,6 +24,7 @@ Two execution paths:
 import numpy as np
 import torch
 
+from .. import lanes
 from ..variable_manager import split_vars, FusedAdam
 from ..utils.lazy_losses import LazyLosses  # noqa: F401  (re-exported)
 from ..utils.function_hooks import HookSpan
@@ -82,39 +83,78 @@ def apply_hooks(vars, population=None, chunk=None):
                     var.hook_fn(var.data[s - lo:e - lo])
 
 
+class _LaneCtx(object):
+    """chunk ci of a step on lane ci % n: its stream + its workspaces (lanes.py); nothing for n = 1"""
+
+    def __init__(self, n, ci, streams):
+        self.on = n > 1
+        if self.on:
+            self.ctx = (torch.cuda.stream(streams[ci % n]), lanes.use(ci % n))
+
+    def __enter__(self):
+        if self.on:
+            for c in self.ctx:
+                c.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            for c in reversed(self.ctx):
+                c.__exit__(*a)
+
+
 def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, population):
     outs, losses = [], []
-    for ci, _vars in enumerate(split_vars(vars, size=max_batch_size)):
-        b_sz = _vars.num_samples
-        gs = None if grad_scale is None else \
-            grad_scale[ci * max_batch_size: ci * max_batch_size + b_sz]
-        target_args = {k: _gather(v) for k, v in _vars.output.items()}
-        leaves, input_args = {}, {}
-        for k, var in _vars.input.items():
-            x = _gather(var)
-            if optimize and var.get('requires_grad', False):
-                x = x.detach().requires_grad_(True)
-                leaves[k] = (x, var)
-            input_args[k] = x
-        with torch.set_grad_enabled(bool(optimize)):
-            out = model(**input_args)
-            loss = loss_fn(out, **target_args).view(b_sz, -1).mean(1)
+    chunks = split_vars(vars, size=max_batch_size)
+    # the reference chunks of a step are independent (own rows, own Adam update): with more than one they
+    # run on side streams, each lane with its own workspaces in the model and the loss -- same bits, the
+    # latency-bound layers of one chunk under the busy ones of the other (lanes.py)
+    n_lanes = lanes.wanted(len(chunks), model, getattr(loss_fn, '_engine', None))
+    streams, main = None, None
+    if n_lanes > 1:
+        dev = next(iter(vars.input.values())).data[0].device
+        main = torch.cuda.current_stream(dev)
+        streams = lanes.side_streams(dev, n_lanes)
+        for s in streams:
+            s.wait_stream(main)                         # (hooks, tracking copies, the previous step)
+    for ci, _vars in enumerate(chunks):
+        with _LaneCtx(n_lanes, ci, streams):
+            b_sz = _vars.num_samples
+            gs = None if grad_scale is None else \
+                grad_scale[ci * max_batch_size: ci * max_batch_size + b_sz]
+            target_args = {k: _gather(v) for k, v in _vars.output.items()}
+            leaves, input_args = {}, {}
+            for k, var in _vars.input.items():
+                x = _gather(var)
+                if optimize and var.get('requires_grad', False):
+                    x = x.detach().requires_grad_(True)
+                    leaves[k] = (x, var)
+                input_args[k] = x
+            with torch.set_grad_enabled(bool(optimize)):
+                out = model(**input_args)
+                loss = loss_fn(out, **target_args).view(b_sz, -1).mean(1)
+                if optimize:
+                    if gs is None:
+                        loss.mean().backward()
+                    else:
+                        (loss * gs).sum().backward()
             if optimize:
-                if gs is None:
-                    loss.mean().backward()
-                else:
-                    (loss * gs).sum().backward()
-        if optimize:
-            for k, (x, var) in leaves.items():
-                if x.grad is None:
-                    continue
-                if not _in_sync(var):
-                    raise RuntimeError('variable `%s` was rebound outside its buffer; '
-                                       'fused Adam cannot update it' % k)
-                off = var.get('offset', 0)
-                _vars.opt.update(k, off, off + b_sz, x.grad)
-        outs.append(out.detach())
-        losses.append(loss.detach())
+                for k, (x, var) in leaves.items():
+                    if x.grad is None:
+                        continue
+                    if not _in_sync(var):
+                        raise RuntimeError('variable `%s` was rebound outside its buffer; '
+                                           'fused Adam cannot update it' % k)
+                    off = var.get('offset', 0)
+                    _vars.opt.update(k, off, off + b_sz, x.grad)
+            outs.append(out.detach())
+            losses.append(loss.detach())
+            if n_lanes > 1:                                # (read on the caller's stream after the join)
+                outs[-1].record_stream(main)
+                losses[-1].record_stream(main)
+    if n_lanes > 1:
+        for s_ in streams:
+            main.wait_stream(s_)
     return torch.cat(outs), LazyLosses(torch.cat(losses)), {}
 
 

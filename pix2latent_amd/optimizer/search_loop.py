@@ -184,7 +184,7 @@ class SearchLoopMixin(object):
         if getattr(self, 'use_graph', False) is not False and torch.cuda.is_available():
             lo, hi = self.shard.bounds(num_samples) if self.shard.enabled else (0, num_samples)
             if self.use_graph or os.environ.get('P2L_GRAPH') == '1' or \
-                    (os.environ.get('P2L_GRAPH') != '0' and 0 < hi - lo <= 6):
+                    (os.environ.get('P2L_GRAPH') != '0' and hi > lo and self._graph_default(hi - lo)):
                 self.var_manager.reuse_buffers = True
         try:
             for g_idx, gen in enumerate(plan):

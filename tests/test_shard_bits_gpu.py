@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, 'tools', 'shard_bits.py')
 
 
-def _run(world, extra=()):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _run(world, extra=(), **more_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **more_env)
     if world == 1:
         cmd = [sys.executable, TOOL] + list(extra)
     else:
@@ -44,7 +44,9 @@ def test_bits_do_not_depend_on_the_number_of_ranks():
         pytest.skip('needs a GPU')
     one = _run(1)
     assert len(one['rescore']) == 18 and len(one['steps']) == 3
-    runs = {'chunks 9+9': _run(1, ['--chunks']), '2 ranks': _run(2), '4 ranks': _run(4),
+    # (chunks 9+9: on two streams, one lane of workspaces each -- pix2latent_amd/lanes.py -- and on one stream)
+    runs = {'chunks 9+9': _run(1, ['--chunks']), 'chunks 9+9, one stream': _run(1, ['--chunks'], P2L_STREAMS='1'),
+            '2 ranks': _run(2), '4 ranks': _run(4),
             '4 ranks, eager': _run(4, ['--graph', '0'])}
     assert runs['4 ranks']['local_candidates'] == [5, 5, 4, 4]
     for name, rec in runs.items():

@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device('cuda:0')
-opt, vm, _ = bench.build_problem(dev, exec_batch_size=bench.POP)
+opt, vm, _ = bench.build_problem(dev, exec_batch_size=int(os.environ.get("P2L_TOOL_EXEC", bench.MAX_BATCH)))
 with contextlib.redirect_stdout(sys.stderr):
     opt.setup_cma(vm)
     opt.optimize(meta_steps=1, grad_steps=2, last_grad_steps=2)      # warm-up

@@ -22,7 +22,9 @@ for n in NS:
     vm.register('c', (128,), 'input', default=0.05 * torch.randn(128), learning_rate=0.01)
     vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=target)
     vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=weight)
-    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9, exec_batch_size=n)
+    # P2L_TOOL_EXEC=9: the reference chunks (two lanes on two streams unless P2L_STREAMS=1) instead of one pass
+    opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=9,
+                            exec_batch_size=int(os.environ.get('P2L_TOOL_EXEC', n)))
     variables = vm.initialize(num_samples=n)
     for i in range(4):       # (with HIP-graph execution the step is captured on its third call)
         opt.step(variables, optimize=True, transform=(i == 0))
