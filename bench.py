@@ -408,7 +408,7 @@ def alone_leg(opt, variables, lib, bf3, steps=4):
     (exec_batch_size = population), every launch of `steps` steps timed once"""
     from pix2latent_amd import _native as N
     saved = opt.exec_batch_size
-    opt.exec_batch_size = POP
+    opt.exec_batch_size = POP                            # (an execution pass above the reference chunk: one stream)
     try:
         opt.step(variables, optimize=True)               # (workspaces of the 18-candidate pass)
         torch.cuda.synchronize()

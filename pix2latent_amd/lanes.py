@@ -57,6 +57,22 @@ def wanted(n_chunks, *objs):
     return min(want, n_chunks)
 
 
+SUB_MIN = 7
+
+
+def sub_wanted(n, *objs):
+    """a step that is ONE chunk of n candidates -- a rank of a 2-GPU run holds 9, the GradientOptimizer example
+    8 -- cut in two for two lanes.  The gradient factor stays the one of the whole chunk (closure._step_fused
+    passes it explicitly), so the bits do not change (tests/test_sublanes_gpu.py).  Measured
+    (profiles/round5_sublanes.txt): 9 candidates 9.92 -> 9.27 ms eager, 9.07 replayed as one graph; 5: 6.57 ->
+    6.41; 3 and 2: 2 % SLOWER (there the step is one chain of tiny dependent launches, and two chains side by
+    side are as long as one) -- hence from SUB_MIN candidates up.  $P2L_SUBLANES: 0 = never, 1 = from 2 up."""
+    mode = os.environ.get('P2L_SUBLANES', '')
+    if mode == '0' or n < 2 or (mode != '1' and n < SUB_MIN):
+        return False
+    return wanted(2, *objs) == 2
+
+
 def side_streams(device, n):
     """n streams of `device`, made once per process"""
     key = str(device)

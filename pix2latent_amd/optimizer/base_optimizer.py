@@ -269,8 +269,12 @@ class _BaseOptimizer(SearchLoopMixin):
         ebs = self.exec_batch_size
         chunked = ebs is None or (ebs != 'all' and ebs <= self.max_batch_size)
         n_chunks = -(-local_n // self.max_batch_size) if chunked else 1
-        return (not self.shard.enabled) and lanes.wanted(
-            n_chunks, self.model, getattr(self.loss_fn, '_engine', None)) > 1
+        objs = (self.model, getattr(self.loss_fn, '_engine', None))
+        if n_chunks >= 2:
+            return (not self.shard.enabled) and lanes.wanted(n_chunks, *objs) > 1
+        # one chunk: two lanes inside it from lanes.SUB_MIN candidates up, unless it is an execution pass
+        # larger than the reference chunk (exec_batch_size: one stream by request)
+        return local_n <= self.max_batch_size and lanes.sub_wanted(local_n, *objs)
 
     def _graphed_step(self, variables, optimize, transform, lo, hi):
         """optimize steps without a transform, on variables whose device buffers were seen

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import lanes
-from ..variable_manager import split_vars, FusedAdam
+from ..variable_manager import split_vars, slice_vars, FusedAdam
 from ..utils.lazy_losses import LazyLosses  # noqa: F401  (re-exported)
 from ..utils.function_hooks import HookSpan
 
@@ -83,6 +83,17 @@ def apply_hooks(vars, population=None, chunk=None):
                     var.hook_fn(var.data[s - lo:e - lo])
 
 
+_SCALES = {}
+
+
+def _const_scale(n, device):
+    """[n] tensor of 1/n on the device, made once (an H2D copy per step would drain the stream)"""
+    key = (n, str(device))
+    if key not in _SCALES:
+        _SCALES[key] = torch.full((n,), 1.0 / n, dtype=torch.float32, device=device)
+    return _SCALES[key]
+
+
 class _LaneCtx(object):
     """chunk ci of a step on lane ci % n: its stream + its workspaces (lanes.py); nothing for n = 1"""
 
@@ -106,10 +117,21 @@ class _LaneCtx(object):
 def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, population):
     outs, losses = [], []
     chunks = split_vars(vars, size=max_batch_size)
+    offsets = [ci * max_batch_size for ci in range(len(chunks))]
+    engine = getattr(loss_fn, '_engine', None)
+    one_pass = population is not None and vars.num_samples > population[2]      # (exec_batch_size: one stream by request)
+    if len(chunks) == 1 and not one_pass and lanes.sub_wanted(vars.num_samples, model, engine):
+        # one chunk, two lanes (from lanes.SUB_MIN candidates up): rows [0, h) and [h, n), each with the gradient
+        # factor of the whole chunk
+        n = vars.num_samples
+        h = (n + 1) // 2
+        if grad_scale is None:
+            grad_scale = _const_scale(n, next(iter(vars.input.values())).data[0].device)
+        chunks, offsets = [slice_vars(vars, 0, h), slice_vars(vars, h, n)], [0, h]
     # the reference chunks of a step are independent (own rows, own Adam update): with more than one they
     # run on side streams, each lane with its own workspaces in the model and the loss -- same bits, the
     # latency-bound layers of one chunk under the busy ones of the other (lanes.py)
-    n_lanes = lanes.wanted(len(chunks), model, getattr(loss_fn, '_engine', None))
+    n_lanes = lanes.wanted(len(chunks), model, engine)
     streams, main = None, None
     if n_lanes > 1:
         dev = next(iter(vars.input.values())).data[0].device
@@ -120,8 +142,7 @@ def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, popu
     for ci, _vars in enumerate(chunks):
         with _LaneCtx(n_lanes, ci, streams):
             b_sz = _vars.num_samples
-            gs = None if grad_scale is None else \
-                grad_scale[ci * max_batch_size: ci * max_batch_size + b_sz]
+            gs = None if grad_scale is None else grad_scale[offsets[ci]: offsets[ci] + b_sz]
             target_args = {k: _gather(v) for k, v in _vars.output.items()}
             leaves, input_args = {}, {}
             for k, var in _vars.input.items():
