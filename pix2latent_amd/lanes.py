@@ -14,31 +14,33 @@ and image staging, the loss's arena); objects advertise `lanes_ok = True` and lo
 here.  Lane 0 on the caller's stream is the only one unless closure.step opens more.
 """
 import os
+import threading
 
 import torch
 
-_current = 0
+_tls = threading.local()         # the current lane is per host thread: two threads may each drive an optimizer
 _side = {}
 
 
 def current():
-    return _current
+    return getattr(_tls, 'lane', 0)
 
 
 class use(object):
-    """`with use(k):` -- workspaces of lane k (no stream switch: see `stream`)"""
+    """`with use(k):` -- workspaces of lane k for this thread (no stream switch: closure._LaneCtx pairs it with
+    `torch.cuda.stream`).  autograd runs a backward on its own thread: the Functions remember the forward's
+    lane and re-enter it there (model/biggan.py `_BigGANFn.backward`)."""
 
     def __init__(self, lane):
         self.lane = lane
 
     def __enter__(self):
-        global _current
-        self.prev, _current = _current, self.lane
+        self.prev = current()
+        _tls.lane = self.lane
         return self
 
     def __exit__(self, *a):
-        global _current
-        _current = self.prev
+        _tls.lane = self.prev
 
 
 def wanted(n_chunks, *objs):

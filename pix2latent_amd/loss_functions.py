@@ -453,6 +453,7 @@ class _ProjLossFn(torch.autograd.Function):
         ctx.has_mask = loss_mask is not None
         eng._fwd_ticket += 1
         ctx.ticket = eng._fwd_ticket
+        ctx.lane = lanes.current()
         eng.last_l1, eng.last_lpips = l1, lp
         if mode == 2:
             return lp
@@ -460,6 +461,11 @@ class _ProjLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss):
+        with lanes.use(ctx.lane):        # (autograd's thread: the scratch of the forward's lane)
+            return _ProjLossFn._backward(ctx, gloss)
+
+    @staticmethod
+    def _backward(ctx, gloss):
         eng = ctx.eng
         lib = eng.lib
         out_c, target, weight, loss_mask = ctx.saved_tensors
