@@ -80,8 +80,10 @@ class PycmaSampler(PopulationSampler):
         values = PopulationSampler.draw(self, variables, shard)      # (a replica is not asked either)
         if self._replica:
             return values
-        if shard is not None and shard.enabled:
-            # every replica tells rank 0's population, so the replicas stay identical
+        if shard is not None and shard.enabled and not CMA_EXTERNAL:
+            # every replica tells rank 0's population, so the replicas stay identical.  (An EXTERNAL
+            # strategy has no told replicas: rank 0 keeps the handle and the 2-d proxy of its own ask,
+            # and must NOT enter a collective the replicas -- returned above -- never join.)
             self._handle = values.reshape(len(values), -1)
             if self.es.is_scalar:
                 # a scalar variable lives in a 2-d proxy problem whose second coordinate the

@@ -329,3 +329,45 @@ def test_scalar_variable_step_size_path_independent_of_world_size():
         p.join(60)
         assert p.exitcode == 0
     assert np.array_equal(res[0], single) and np.array_equal(res[1], single)
+
+
+def _scalar_external_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pix2latent_amd.optimizer.base_cma_optimizer as B
+        from pix2latent_amd.parallel import PopulationShard
+        B.CMA_EXTERNAL = True                 # (as if `import cma` had succeeded: only rank 0 is asked / told)
+        shard = PopulationShard()
+        path = _scalar_sigma_path(shard, seed=11 + 100 * rank, gens=3)
+        # the collectives of the three generations stayed aligned: one more, compared on both sides
+        probe = shard.broadcast_numpy(np.full(3, 7.0 + rank), src=0)
+        q.put((rank, path, probe))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_scalar_variable_with_an_external_strategy_keeps_the_collectives_symmetric():
+    """with an INSTALLED pycma a replica rank returns from draw() before the broadcast
+    of the scalar variable's 2-d proxy draw; rank 0 must not enter that broadcast alone (a hang on gloo,
+    misaligned collectives afterwards on RCCL).  Rank 0's step-size path is the single-process one, the
+    replica's strategy is never told, and a later collective still lines up."""
+    single = _scalar_sigma_path(None, seed=11, gens=3)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 1311) % 2000)
+    procs = [ctx.Process(target=_scalar_external_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        rank, path, probe = q.get(timeout=120)
+        res[rank] = (path, probe)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], single)
+    assert len(set(res[1][0].tolist())) == 1          # the replica's strategy was never told: sigma frozen
+    assert np.array_equal(res[0][1], np.full(3, 7.0)) and np.array_equal(res[1][1], np.full(3, 7.0))
