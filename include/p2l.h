@@ -92,6 +92,16 @@ typedef struct P2LConv {
   double algo_flops; /* algorithmic FLOPs of this launch for the profiler;    */
                      /* 0 = 2*B*H*W*Cin*Cout*taps (set it when Cin/Cout are   */
                      /* zero-padded, e.g. the 3-channel image convs)          */
+  int64_t w_floats;  /* length of the buffer behind `w` in floats (version 101). */
+                     /* The packed formats are not tagged on the device: a launch */
+                     /* finds the image it reads at a fixed offset that follows   */
+                     /* from (taps, ups, Cin, Cout, wfmt), so a buffer packed for */
+                     /* another format (a _subpix_bf3 buffer handed to a          */
+                     /* P2L_WFMT_BF16X3W launch) would be read past its end.      */
+                     /* > 0: the call returns P2L_EINVAL when the buffer is       */
+                     /* shorter than p2l_packed_weight_floats /                   */
+                     /* p2l_packed_subpix_weight_floats(.., wfmt) of THIS launch; */
+                     /* 0 = not stated, nothing is checked.                       */
 } P2LConv;
 
 /* Weight layout expected in `w`: [taps][Cin/KC][Cout][KC] fp32 with KC = 16 for
@@ -170,12 +180,16 @@ int p2l_arb_defer_flush(void* stream);
 void p2l_arb_defer_cancel(void);
 
 /* Per-launch timing of the conv kernel with HIP events recorded on the launch
- * stream (bench.py roofline leg).  begin() pre-creates the event pool; end()
- * synchronises and returns totals per family: [0] = 3x3, [1] = 1x1. */
+ * stream (bench.py roofline leg).  begin() pre-creates the event pool; p2l_prof_totals()
+ * synchronises, ends the session and returns totals per family: [0] = 3x3, [1] = 1x1. */
 int p2l_prof_begin(int max_launches);
 /* Totals per conv family, index 0 = 3x3 launches, 1 = 1x1 launches.  `size` is set by the CALLER to
  * sizeof(P2LProfTotals) as it was compiled; the library fills the members that fit (later versions of
- * the library only ever append members), so one entry point serves every generation of callers.      */
+ * the library only ever append members), so p2l_prof_totals serves every caller built against version
+ * >= 101.  (Version 100 exported `p2l_prof_end`, first as (double[2], double[2], int32_t[2]) and then
+ * with this struct under the SAME name: a caller of the array form would have had its doubles read as
+ * `size`.  The name is retired -- a stale binding now fails to resolve instead of corrupting memory --
+ * and p2l_version() says which side of the change a library is on.)                                 */
 typedef struct P2LProfTotals {
   uint32_t size;           /* in: sizeof(P2LProfTotals)                                             */
   int32_t count[2];        /* timed launches                                                         */
@@ -191,7 +205,7 @@ typedef struct P2LProfTotals {
   double write_bytes[2];   /* the WRITTEN share of `bytes` (y / yp): PMC FETCH_SIZE and WRITE_SIZE     *
                             * can each be set against their own algorithmic count                     */
 } P2LProfTotals;
-int p2l_prof_end(P2LProfTotals* out);
+int p2l_prof_totals(P2LProfTotals* out);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
  * `period`-th conv launch to be timed: call p2l_prof_step(i, period) at the top of step i;
@@ -199,7 +213,7 @@ int p2l_prof_end(P2LProfTotals* out);
  * steps every launch of the step has been timed once.  Without the call every launch is
  * timed. */
 int p2l_prof_step(int step, int period);
-/* p2l_prof_end also writes one line per timed launch to `path` (taps B H W Cin Cout ups pro arb
+/* p2l_prof_totals also writes one line per timed launch to `path` (taps B H W Cin Cout ups pro arb
  * splitk flops bytes ms) when a path was given; NULL switches it off.  The profiler is the one
  * process-wide object of the library (the backward pass of a torch program runs on the autograd
  * engine's thread and must be timed too): opt-in, every access under a mutex. */

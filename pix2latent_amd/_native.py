@@ -23,7 +23,8 @@ class P2LConv(C.Structure):
                 ('pool', C.c_int32), ('y_ld', C.c_int32), ('yp_ld', C.c_int32),
                 ('n_store', C.c_int32), ('res_ld', C.c_int32), ('res_ups', C.c_int32),
                 ('mask_ld', C.c_int32), ('splitk', C.c_int32), ('ext', C.c_int32),
-                ('wfmt', C.c_int32), ('form', C.c_int32), ('algo_flops', C.c_double)]
+                ('wfmt', C.c_int32), ('form', C.c_int32), ('algo_flops', C.c_double),
+                ('w_floats', C.c_int64)]
 
 
 class P2LAmax(C.Structure):
@@ -134,12 +135,16 @@ class P2LProfTotals(C.Structure):
                 ('write_bytes', C.c_double * 2)]
 
 
-def prof_end():
-    """p2l_prof_end: totals of the timed conv launches per family (index 0 = 3x3, 1 = 1x1)"""
+def prof_totals():
+    """p2l_prof_totals: ends the timing session; totals of the timed conv launches per family
+    (index 0 = 3x3, 1 = 1x1)"""
     t = P2LProfTotals()
     t.size = C.sizeof(P2LProfTotals)
-    check(lib().p2l_prof_end(C.byref(t)), 'p2l_prof_end')
+    check(lib().p2l_prof_totals(C.byref(t)), 'p2l_prof_totals')
     return t
+
+
+prof_end = prof_totals      # (the helper's name in tools/ and tests/ written before version 101)
 
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU_SQRT2 = 0, 1, 2, 3
@@ -251,7 +256,7 @@ EXPORTS = [
     'p2l_clamp', 'p2l_affine_grid_sample', 'p2l_affine_grid_sample_bwd', 'p2l_affine_grid_sample_bwd_ws_bytes', 'p2l_vec_scale_div', 'p2l_concat2', 'p2l_split2',
     'p2l_biggan_ws_bytes', 'p2l_biggan_fwd', 'p2l_biggan_bwd', 'p2l_biggan_ws_lookup',
     'p2l_loss_cache_floats', 'p2l_projloss_ws_bytes', 'p2l_projloss_ws_lookup', 'p2l_projloss_prepare',
-    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_end', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
+    'p2l_projloss_fwd', 'p2l_projloss_bwd', 'p2l_mfma_probe', 'p2l_prof_begin', 'p2l_prof_totals', 'p2l_prof_step', 'p2l_prof_dump', 'p2l_wino_split_factor', 'p2l_linear_fwd_ld', 'p2l_linear_bwd_ld', 'p2l_scale_bwd',
     'p2l_sg2_pixelnorm_fwd', 'p2l_sg2_pixelnorm_bwd', 'p2l_sg2_bias_lrelu_fwd', 'p2l_sg2_lrelu_bwd',
     'p2l_sg2_demod_fwd', 'p2l_sg2_demod_bwd', 'p2l_sg2_blur_fwd', 'p2l_sg2_act_bwd_nblk',
     'p2l_sg2_styled_act_bwd', 'p2l_sg2_blur_bwd', 'p2l_sg2_rgb_up_fwd', 'p2l_sg2_rgb_up_bwd',
@@ -267,6 +272,7 @@ EXPORTS = [
 ]
 
 _lib = None
+ABI_VERSION = 101
 
 
 class NativeError(RuntimeError):
@@ -282,6 +288,12 @@ def lib():
                 'libp2l_hip.so not found at %s: the HIP extension is required '
                 '(no CPU fallback). Run __graft_entry__.build().' % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
+        # the structs below mirror include/p2l.h of THIS version (101: P2LConv.w_floats, p2l_prof_totals);
+        # an older library would read them at other offsets
+        if _lib.p2l_version() < ABI_VERSION:
+            v, _lib = _lib.p2l_version(), None
+            raise NativeError('libp2l_hip.so at %s is version %d, this package binds version %d: rebuild it '
+                              '(__graft_entry__.build())' % (LIB_PATH, v, ABI_VERSION))
         _lib.p2l_strerror.restype = C.c_char_p
         _lib.p2l_arb_defer_begin.restype = None
         _lib.p2l_arb_defer_cancel.restype = None

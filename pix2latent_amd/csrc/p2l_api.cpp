@@ -3,7 +3,7 @@
 
 thread_local int g_p2l_last_hip_error = 0;
 
-extern "C" int p2l_version(void) { return 100; }
+extern "C" int p2l_version(void) { return 101; }
 
 extern "C" int p2l_last_hip_error(void) { return g_p2l_last_hip_error; }
 

@@ -1320,6 +1320,13 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     return P2L_EUNSUP;
   if (d->taps == 1 && d->wfmt != P2L_WFMT_F32 && d->wfmt != P2L_WFMT_PW) return P2L_EUNSUP;
   if (d->ups < 0 || d->ups > 3) return P2L_EINVAL;
+  if (d->w_floats != 0) {
+    // the packed formats carry no tag: the images a launch of (taps, ups, Cin, Cout, wfmt) may read sit
+    // at fixed offsets of a buffer of exactly this size; a shorter one was packed for something else
+    const size_t need = d->ups >= 2 ? p2l_packed_subpix_weight_floats(d->Cout, d->Cin, d->wfmt)
+                                    : p2l_packed_weight_floats(d->taps, d->Cout, d->Cin, d->wfmt);
+    if (d->w_floats < 0 || (size_t)d->w_floats < need) return P2L_EINVAL;
+  }
   if (d->n_store < 1 || d->n_store > d->Cout || d->n_store % 4) return P2L_EINVAL;
   if ((y && d->y_ld % 4) || (yp && d->yp_ld % 4) || (res && d->res_ld % 4) ||
       (mask && d->mask_ld % 4))
@@ -1831,7 +1838,7 @@ extern "C" int p2l_prof_step(int step, int period) {
   return P2L_OK;
 }
 
-extern "C" int p2l_prof_end(P2LProfTotals* out) {
+extern "C" int p2l_prof_totals(P2LProfTotals* out) {
   // the caller's struct may be older (shorter) than this library's: totals are gathered in a full one
   // and the leading out->size bytes are copied back
   if (!out || out->size < offsetof(P2LProfTotals, flops)) return P2L_EINVAL;

@@ -62,6 +62,7 @@ def conv(x, w_packed, B, H, W, Cin, Cout, taps, bias=None, pro=N.PRO_NONE, pro_s
     d.res_ups = int(res_ups)
     d.mask_ld = mask.shape[-1] if mask is not None else 0
     d.ext = int(ext)
+    d.w_floats = w_packed.numel()      # (the library refuses a buffer too short for this format: P2L_EINVAL)
     d.splitk = splitk if splitk is not None else _lib().p2l_conv_suggest_splitk(C.byref(d))
     wsb = _lib().p2l_conv_workspace_bytes(C.byref(d))
     ws = torch.empty(max(wsb // 4, 1), device=x.device)
@@ -298,6 +299,7 @@ def conv_dgrad_arb(dy, wt_packed, B, H, W, Cin, Cout, taps, x, s, t, st_bstride,
     d.pool = N.POOL_SUM if (pool_sum and not subpix) else N.POOL_NONE
     d.ups = 3 if subpix else 0
     d.y_ld = d.yp_ld = d.n_store = Cout
+    d.w_floats = wt_packed.numel()
     d.splitk = splitk
     if splitk > 1 and not _lib().p2l_conv_arb_split_fusable(C.byref(d)):
         splitk = d.splitk = 1        # (shapes that run in the Winograd form never split K)

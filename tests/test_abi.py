@@ -43,11 +43,13 @@ def test_every_declared_symbol_is_exported(lib):
     assert hooks == sorted(['p2l_selftest_amaxreg', 'p2l_biggan_ws_lookup', 'p2l_projloss_ws_lookup', 'p2l_sg2_ws_lookup',
                             'p2l_mfma_probe'])
     assert not set(hooks) & set(header_symbols(('p2l.h',)))
-    assert len([s for s in syms if s.startswith('p2l_prof_end')]) == 1       # one signature, sized struct
+    # version 101: the sized-struct totals have their OWN name; the name that had carried two signatures is gone
+    assert 'p2l_prof_totals' in syms and not [s for s in syms if s.startswith('p2l_prof_end')]
 
 
 def test_version_and_errors(lib):
-    assert lib.p2l_version() >= 100
+    from pix2latent_amd import _native as N
+    assert lib.p2l_version() == N.ABI_VERSION == 101
     assert lib.p2l_strerror(0) == b'ok'
     assert b'workspace' in lib.p2l_strerror(-3)
     assert lib.p2l_affine_relu_bwd_nblk(65536) == 256
@@ -67,7 +69,7 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
         'P2LConvExtra': ['oscale', 'oscale_bstride', 'noise', 'noise_w', 'amax'],
         'P2LArb': ['x', 'x_ld', 's', 't', 'st_bstride', 'skip', 'skip_ld', 'skip_C', 'skip_ups', 'ds', 'dt',
                    'dsdt_bstride', 'partial', 'nomask', 'amax'],
-        'P2LConv': ['wfmt', 'form', 'algo_flops'],
+        'P2LConv': ['wfmt', 'form', 'algo_flops', 'w_floats'],
         'P2LProfTotals': ['size', 'count', 'flops', 'ms', 'bytes', 'exec_flops', 'mfma_flops', 'write_bytes'],
     }
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "p2l.h"', 'int main(void) {']
@@ -90,19 +92,19 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
             assert int(got['%s.%s' % (st, m)]) == f.offset, (st, m)
 
 
-def test_prof_end_fills_what_fits(lib):
-    """one p2l_prof_end for every generation of callers: the library writes the leading `size` bytes of
+def test_prof_totals_fills_what_fits(lib):
+    """one p2l_prof_totals for every generation of callers from version 101 on: the library writes the leading `size` bytes of
     its totals and nothing behind them; a struct too short for the counts is refused"""
     from pix2latent_amd import _native as N
     t = N.P2LProfTotals()                            # (nothing was timed: no device needed)
     t.size = N.P2LProfTotals.bytes.offset            # a caller compiled before `bytes` existed
     t.bytes[0] = t.write_bytes[1] = -7.0
-    assert lib.p2l_prof_end(C.byref(t)) == 0
+    assert lib.p2l_prof_totals(C.byref(t)) == 0
     assert t.size == N.P2LProfTotals.bytes.offset and t.count[0] == 0 and t.ms[1] == 0.0
     assert t.bytes[0] == -7.0 and t.write_bytes[1] == -7.0
     t.size = 8
-    assert lib.p2l_prof_end(C.byref(t)) == -1
-    assert lib.p2l_prof_end(None) == -1
+    assert lib.p2l_prof_totals(C.byref(t)) == -1
+    assert lib.p2l_prof_totals(None) == -1
 
 
 def test_maxima_registry_rules(lib):
@@ -115,7 +117,7 @@ def test_maxima_registry_rules(lib):
 def test_struct_layouts_match_c(lib):
     """sizes implied by include/p2l.h on LP64"""
     from pix2latent_amd import _native as N
-    assert C.sizeof(N.P2LConv) == 23 * 4 + 4 + 8          # (+ form; padded to the double)
+    assert C.sizeof(N.P2LConv) == 23 * 4 + 4 + 8 + 8      # (+ form; padded to the double; + w_floats)
     assert C.sizeof(N.P2LGemm) == 7 * 4 + 4 + 3 * 8 + 4 * 4
     assert C.sizeof(N.P2LGenBlock) == 7 * 4 + 4 + 14 * 8
     assert C.sizeof(N.P2LVggLpips) == (13 * 3 + 5 + 2) * 8 + 8
@@ -166,6 +168,22 @@ def test_host_side_planning_calls(lib):
     assert n_split >= 10
     assert lib.p2l_projloss_ws_bytes(2, 256, 256) > 0
     assert lib.p2l_projloss_ws_bytes(2, 100, 100) == 0          # not a power of two
+    # P2LConv.w_floats (version 101): a sub-pixel launch of a P2L_WFMT_BF16X3W model reads
+    # the fp16 x 2 image BEHIND the bf16 x 3 one; a buffer of the bf16 x 3-only length is refused on the
+    # host, before any launch (fake non-null device pointers: nothing is dereferenced)
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.ups = 2, 64, 64, 128, 128, 9, 2
+    d.wfmt, d.x_ld, d.n_store, d.y_ld, d.yp_ld, d.alpha, d.splitk = 2, 128, 128, 128, 128, 1.0, 1
+    short = lib.p2l_packed_subpix_weight_floats(128, 128, 1)      # what p2l_pack_conv_weight_subpix_bf3 fills
+    full = lib.p2l_packed_subpix_weight_floats(128, 128, 2)
+    assert short < full
+    d.w_floats = short
+    fake = C.c_void_p(4096)
+    assert lib.p2l_conv_fwd(C.byref(d), fake, fake, None, None, None, None, None, fake, None,
+                            None, C.c_size_t(0), None) == -1
+    d.w_floats = -5
+    assert lib.p2l_conv_fwd(C.byref(d), fake, fake, None, None, None, None, None, fake, None,
+                            None, C.c_size_t(0), None) == -1
     # invalid arguments are rejected before any launch
     assert lib.p2l_conv_fwd(None, None, None, None, None, None, None, None, None, None,
                             None, C.c_size_t(0), None) == -1

@@ -216,6 +216,37 @@ def test_conv_subpixel_forward_and_dgrad(dev, O, Cin, Cout, wfmt):
     assert relerr(nchw(da), a.grad) < 2e-5
 
 
+def test_packed_weight_buffer_of_another_format_is_refused(dev, O):
+    """VERDICT r5 #7 / ADVICE r4: the packed formats are not tagged on the device.  A sub-pixel launch
+    of format P2L_WFMT_BF16X3W reads the fp16 x 2 image BEHIND the bf16 x 3 one, so a buffer packed by
+    p2l_pack_conv_weight_subpix_bf3 (bf16 x 3 only) would be read past its end.  With the buffer length
+    stated in P2LConv.w_floats (the wrappers always state it) the library refuses the call (P2L_EINVAL)
+    and launches nothing; the properly packed buffer runs; w_floats = 0 keeps the unchecked contract."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(77)
+    B, h, Cin, Cout = 2, 16, 64, 64
+    x = nhwc(torch.randn(B, Cin, h, h, generator=g), dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).to(dev)
+    w_bf3 = O.pack_conv_weight_subpix(w, Cout, Cin, wfmt=N.WFMT_BF16X3)      # bf16 x 3 image only
+    w_h2 = O.pack_conv_weight_subpix(w, Cout, Cin, wfmt=N.WFMT_BF16X3W)      # + fp16 x 2 image
+    assert w_bf3.numel() < w_h2.numel() == N.lib().p2l_packed_subpix_weight_floats(Cout, Cin, N.WFMT_BF16X3W)
+    with pytest.raises(N.NativeError, match='rc=-1'):
+        O.conv(x, w_bf3, B, 2 * h, 2 * h, Cin, Cout, 9, ups=2, wfmt=N.WFMT_BF16X3W)
+    y_ok, _ = O.conv(x, w_h2, B, 2 * h, 2 * h, Cin, Cout, 9, ups=2, wfmt=N.WFMT_BF16X3W)
+    y_bf3, _ = O.conv(x, w_bf3, B, 2 * h, 2 * h, Cin, Cout, 9, ups=2, wfmt=N.WFMT_BF16X3)
+    torch.cuda.synchronize()
+    assert relerr(y_ok, y_bf3) < 2e-5
+    # plain 3x3: a P2L_WFMT_BF16X3 buffer (no Winograd / fp16 x 2 images behind it) handed to a BF16X3W launch
+    w3_bf3 = O.pack_conv_weight(w, 9, Cout, Cin, wfmt=N.WFMT_BF16X3)
+    with pytest.raises(N.NativeError, match='rc=-1'):
+        O.conv(x, w3_bf3, B, h, h, Cin, Cout, 9, wfmt=N.WFMT_BF16X3W)
+    # and the input-gradient wrapper states the length too
+    xs = nhwc(torch.randn(B, Cout, h, h, generator=g), dev)
+    one = torch.ones(B, Cout, device=dev)
+    with pytest.raises(N.NativeError, match='rc=-1'):
+        O.conv_dgrad_arb(x, w3_bf3, B, h, h, Cin, Cout, 9, xs, one, one, Cout, wfmt=N.WFMT_BF16X3W)
+
+
 @pytest.mark.parametrize('wfmt', WFMTS, ids=WFMT_IDS)
 def test_conv_subpixel_dgrad_fused_arb(dev, O, wfmt):
     _skip_unless_format_applies(wfmt, 9, None, True)
