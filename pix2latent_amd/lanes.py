@@ -43,6 +43,26 @@ class use(object):
         _tls.lane = self.prev
 
 
+_gave_up = []
+
+
+def give_up(reason):
+    """no more lanes in this process (the second set of workspaces did not fit: closure._step_fused)"""
+    if not _gave_up:
+        import warnings
+        warnings.warn('execution lanes switched off for this process: %s' % reason)
+    _gave_up.append(reason)
+
+
+def drop_side_scratch(*objs):
+    """free what lanes > 0 allocated in the objects that keep per-lane scratch"""
+    for o in objs:
+        held = getattr(o, '_lanes', None)
+        if isinstance(held, dict):
+            for k in [k for k in held if k != 0]:
+                del held[k]
+
+
 def wanted(n_chunks, *objs):
     """number of lanes for a step of n_chunks reference chunks over objs (model, loss): $P2L_STREAMS
     (default 2; 1 = off) when every object has per-lane workspaces.  Also while a HIP graph is being captured:
@@ -52,7 +72,7 @@ def wanted(n_chunks, *objs):
         want = int(os.environ.get('P2L_STREAMS', '2'))
     except ValueError:
         want = 2
-    if n_chunks < 2 or want < 2 or not torch.cuda.is_available():
+    if n_chunks < 2 or want < 2 or _gave_up or not torch.cuda.is_available():
         return 1
     if not all(getattr(o, 'lanes_ok', False) for o in objs):
         return 1

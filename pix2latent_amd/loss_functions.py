@@ -192,6 +192,52 @@ class _CacheSlot(object):
         self.desc.wsum = base + 4 * wsum_off.value
         self.held = None
         self.B = B
+        self.guard = _StreamGuard()
+        self.last_use = {}           # stream -> event behind its latest forward / backward over this slot
+
+    def used(self):
+        """called behind every launch sequence that READS the slot (loss forward, loss backward)"""
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            st = torch.cuda.current_stream()
+            self.last_use[st.cuda_stream] = st.record_event()
+
+    def wait_for_readers(self):
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            st = torch.cuda.current_stream()
+            for sid, ev in self.last_use.items():
+                if sid != st.cuda_stream:
+                    st.wait_event(ev)
+        self.last_use = {}
+
+
+class _StreamGuard(object):
+    """Orders streams on a tensor that ONE stream filled and others read (lanes: the side streams of a step
+    synchronise with the caller's stream, not with each other).  `filled()` records an event on the filling
+    stream; `reader()` makes any OTHER stream wait for it once.  Inside a graph capture nothing is recorded:
+    the memo entries and slots a captured step touches were made by the eager steps before it."""
+
+    def __init__(self):
+        self.event, self.seen = None, set()
+
+    @staticmethod
+    def _capturing():
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def filled(self):
+        if not torch.cuda.is_available():
+            return self
+        st = torch.cuda.current_stream()
+        self.event = None if self._capturing() else st.record_event()
+        self.seen = {st.cuda_stream}
+        return self
+
+    def reader(self):
+        if self.event is None or not torch.cuda.is_available():
+            return
+        st = torch.cuda.current_stream()
+        if st.cuda_stream not in self.seen and not self._capturing():
+            st.wait_event(self.event)
+            self.seen.add(st.cuda_stream)
 
 
 class _EngineLane(object):
@@ -314,14 +360,18 @@ class _LossEngine(object):
             key = ('ones', B, tuple(like.shape[2:]), str(like.device))
             if self._memo.get(name, (None, None))[0] != key:
                 self._memo[name] = (key, torch.ones(B, 3, like.size(2), like.size(3),
-                                                    device=like.device))
+                                                    device=like.device), _StreamGuard().filled())
+            # (filled on the stream of the lane that came first; the other lane's stream waits for it once)
+            self._memo[name][2].reader()
             return self._memo[name][1]
         if t.dim() == 4 and tuple(t.shape) == (B, 3) + tuple(like.shape[2:]) and \
                 t.is_contiguous() and t.dtype == torch.float32 and t.device == like.device:
             return t
         key = (self._ident(t), B)
         if self._memo.get(name, (None, None))[0] != key:
-            self._memo[name] = (key, self._conform(name, t.to(like.device), B, like), t)
+            self._memo[name] = (key, self._conform(name, t.to(like.device), B, like),
+                                _StreamGuard().filled(), t)
+        self._memo[name][2].reader()
         return self._memo[name][1]
 
     def _same_content(self, target, weight, loss_mask, use_lpips, B):
@@ -341,6 +391,9 @@ class _LossEngine(object):
             seen.add(id(slot))
             if getattr(slot, 'use_lpips', None) != use_lpips or slot.B != B or slot.held is None:
                 continue
+            # `held` may be conformed copies another lane's stream made in this very step: ordered by the
+            # event recorded behind that lane's prepare
+            slot.guard.reader()
             differ = None
             for new, old, ver in zip((target, weight, loss_mask), slot.held, slot.versions):
                 if (new is None) != (old is None):
@@ -375,6 +428,10 @@ class _LossEngine(object):
                 self.keep.pop(lru, None)
                 shared = any(v is old for v in self.slots.values())
                 slot = old if (old.B == B and not shared) else None   # ... and reuse its memory
+                if slot is not None:
+                    # ... once every stream that read its features is done with them (another lane may
+                    # still be inside the forward / backward that uses the evicted chunk's slot)
+                    slot.wait_for_readers()
             if slot is None:
                 slot = _CacheSlot(self.f_cache, B, H, W, out.device)
             vref = C.byref(self.vgg.desc) if use_lpips else None
@@ -386,14 +443,9 @@ class _LossEngine(object):
             slot.versions = tuple(None if t is None else t._version for t in slot.held)
             slot.use_lpips = use_lpips
             # another lane (stream) may be the next reader of these features
-            capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
-            slot.ready = None if capturing else torch.cuda.current_stream().record_event()
-            slot.seen_by = {torch.cuda.current_stream().cuda_stream}
-        elif getattr(slot, 'ready', None) is not None and \
-                torch.cuda.current_stream().cuda_stream not in slot.seen_by and \
-                not torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream().wait_event(slot.ready)     # (once per stream)
-            slot.seen_by.add(torch.cuda.current_stream().cuda_stream)
+            slot.guard.filled()
+        else:
+            slot.guard.reader()                                    # (once per stream)
         if len(self.slots) >= 2 * self.MAX_SLOTS:                 # (keys, several may share a slot)
             lru = next(iter(self.slots))
             self.slots.pop(lru)
@@ -447,6 +499,8 @@ class _ProjLossFn(torch.autograd.Function):
                           use_lpips, B, H, W, N.ptr(eng.ws),
                           C.c_size_t(eng.ws_bytes), N.ptr(loss), N.ptr(l1),
                           N.ptr(lp), N.stream()), 'p2l_%sloss_fwd' % eng.prefix)
+        if len(eng._lanes) > 1:          # (one stream: program order already protects an evicted slot)
+            slot.used()
         ctx.eng, ctx.beta, ctx.mode = eng, beta, mode
         ctx.save_for_backward(out_c, target, weight, loss_mask if loss_mask is not None
                               else torch.empty(0))
@@ -485,6 +539,8 @@ class _ProjLossFn(torch.autograd.Function):
                           use_lpips, N.ptr(g), B, H, W, N.ptr(eng.ws),
                           C.c_size_t(eng.ws_bytes), N.ptr(eng.dimg16), N.stream()),
                 'p2l_%sloss_bwd' % eng.prefix)
+        if len(eng._lanes) > 1:
+            ctx.slot.used()
         dout = torch.empty(B, 3, H, W, device=out_c.device, dtype=torch.float32)
         N.check(lib.p2l_nhwc16_to_nchw3(N.ptr(eng.dimg16), N.ptr(dout), B, H, W, N.stream()),
                 'p2l_nhwc16_to_nchw3')

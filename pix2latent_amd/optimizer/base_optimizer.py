@@ -322,12 +322,15 @@ class _BaseOptimizer(SearchLoopMixin):
             entry = self._graphs[key] = (graph, out, loss, other, variables, variables.opt)
         graph, out, loss, other = entry[:4]
         graph.replay()
-        # the captured tensors are static buffers the replay has just refilled
-        self.out = self.out_local = out
+        # The captured tensors are static buffers every replay refills.  What the step hands out are COPIES
+        # (one 14 MB device copy per step of 18 x 256^2, ~5 us; 18 floats of losses): the reference returns
+        # independent tensors per step (closure.py:68-79), and a caller -- or a LazyLosses read after a later
+        # step -- that keeps `opt.out` / `opt.loss` of step i must not see step i+1 in them.
+        self.out = self.out_local = out.clone()
         if isinstance(loss, ShardedLosses):
-            self.loss = ShardedLosses(loss.local, self.shard, variables.num_samples)
+            self.loss = ShardedLosses(loss.local.clone(), self.shard, variables.num_samples)
         else:
-            self.loss = LazyLosses(loss.tensor()) if isinstance(loss, LazyLosses) else loss
+            self.loss = LazyLosses(loss.tensor().clone()) if isinstance(loss, LazyLosses) else loss
         self.other = other
         return self.out, self.loss, self.other
 

@@ -139,7 +139,7 @@ def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, popu
         streams = lanes.side_streams(dev, n_lanes)
         for s in streams:
             s.wait_stream(main)                         # (hooks, tracking copies, the previous step)
-    for ci, _vars in enumerate(chunks):
+    def run_chunk(ci, _vars, n_lanes):
         with _LaneCtx(n_lanes, ci, streams):
             b_sz = _vars.num_samples
             gs = None if grad_scale is None else grad_scale[offsets[ci]: offsets[ci] + b_sz]
@@ -173,6 +173,26 @@ def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, popu
             if n_lanes > 1:                                # (read on the caller's stream after the join)
                 outs[-1].record_stream(main)
                 losses[-1].record_stream(main)
+
+    for ci, _vars in enumerate(chunks):
+        try:
+            run_chunk(ci, _vars, n_lanes)
+        except torch.cuda.OutOfMemoryError as e:
+            if n_lanes == 1 or ci % n_lanes == 0:
+                raise
+            # The second lane's set of workspaces (generator arena + image staging + loss arena: 5 GB for
+            # BigGAN-256 at 9 candidates, 17 GB per lane for StyleGAN2-1024) did not fit beside the first.
+            # Nothing of THIS chunk has been updated yet (its Adam update follows its backward), the chunks
+            # before it are complete: give the side lanes' memory back, and run this chunk and every later
+            # one on lane 0, behind whatever the side streams still hold.
+            lanes.give_up('%s in lane %d of %d' % (str(e).split('.')[0], ci % n_lanes, n_lanes))
+            for s_ in streams:
+                main.wait_stream(s_)
+            torch.cuda.current_stream().synchronize()
+            lanes.drop_side_scratch(model, engine)
+            torch.cuda.empty_cache()
+            n_lanes = 1
+            run_chunk(ci, _vars, 1)
     if n_lanes > 1:
         for s_ in streams:
             main.wait_stream(s_)

@@ -86,3 +86,57 @@ def test_wanted_needs_every_object():
     assert lanes.wanted(2, Ok(), Plain()) == 1
     assert lanes.wanted(1, Ok(), Ok()) == 1
     assert lanes.wanted(2, Ok(), None) == 1
+
+
+def test_second_lane_out_of_memory_falls_back_to_one_lane(monkeypatch):
+    """the two-lane default doubles the generator and loss arenas; when the SECOND set does not
+    fit (StyleGAN2-1024 at 9 candidates: 17 GB per lane) the step must not die.  The first allocation of
+    lane 1's generator arena is made to fail: the chunk is re-run on lane 0, the side scratch is freed,
+    lanes stay off for the process, and the bits are those of one stream."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import warnings
+    from pix2latent_amd import lanes
+    from pix2latent_amd.model import biggan as BG
+    dev = torch.device('cuda:0')
+    monkeypatch.setenv('P2L_STREAMS', '1')
+    _, _, l1, z1 = _run(dev, 7)
+    monkeypatch.setenv('P2L_STREAMS', '2')
+    monkeypatch.setattr(lanes, '_gave_up', [])
+    real_lane, fired = BG.BigGAN._lane, []
+
+    def failing_lane(self):
+        if lanes.current() == 1 and not fired:
+            fired.append(1)
+            raise torch.cuda.OutOfMemoryError('HIP out of memory (injected). Tried to allocate 3.4 GiB')
+        return real_lane(self)
+    monkeypatch.setattr(BG.BigGAN, '_lane', failing_lane)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        model, eng, l2, z2 = _run(dev, 7)
+    assert fired and any('lanes switched off' in str(x.message) for x in w)
+    assert lanes.wanted(2, model, eng) == 1
+    assert sorted(model._lanes) == [0] and sorted(eng._lanes) == [0]
+    assert torch.equal(l1, l2) and torch.equal(z1, z2)
+
+
+def test_replayed_step_hands_out_independent_tensors(monkeypatch):
+    """a HIP-graph replay refills static buffers; what `opt.out` / `opt.loss` hold after a step are
+    copies, so a caller that keeps step i's results does not find step i+1 in them (the reference returns
+    fresh tensors per step, closure.py:68-79)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    monkeypatch.setenv('P2L_STREAMS', '2')
+    opt, variables, model, loss_fn = _problem(dev, 6)
+    opt.use_graph = True
+    kept = []
+    for i in range(5):
+        opt.step(variables, optimize=True, transform=(i == 0))
+        kept.append((opt.out, opt.loss, opt.out.clone(), torch.as_tensor([float(x) for x in opt.loss])))
+    torch.cuda.synchronize()
+    assert any(isinstance(v, tuple) for v in opt._graphs.values()), 'the step was not replayed from a graph'
+    for out, loss, out_then, loss_then in kept:
+        assert torch.equal(out, out_then)
+        assert torch.equal(torch.as_tensor([float(x) for x in loss]), loss_then)
+    assert not torch.equal(kept[-1][0], kept[-2][0])
