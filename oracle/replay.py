@@ -72,11 +72,19 @@ def native_decisions(model, loss_fn, W, B, dev, out, target, diag=None):
         amb = tail_pre.double().abs() < 4e-7 * ((prev.double() * s.double()).abs() + t.double().abs())
         diag.append(('generator.bn', [0] * B, [0] * B, [int(v) for v in amb.flatten(1).sum(1)]))
     items.append(('generator.bn', 'relu', _nchw(tail_pre > 0).cpu()))
-    # L1 term: sign of (out - target) of the pixels the native loss saw
-    items.append(('l1', 'sign', torch.sign(out.detach() - target).cpu()))
-    # VGG of the generated image
+    return items + loss_decisions(loss_fn, B, out, target)
+
+
+def loss_decisions(loss_fn, B, out, target):
+    """the decisions of the LAST native ProjectionLoss(VGG) forward on B candidates, in oracle/lpips_ref.py's
+    order: the sign of (out - target) of the L1 term, then the 13 VGG ReLUs and 4 max-pools of the pass over
+    the generated image (read through p2l_projloss_ws_lookup at the resolution of `out`: 256^2 BigGAN,
+    512^2 / 1024^2 StyleGAN2)"""
+    from pix2latent_amd import _native as N
+    from oracle.masks import winner_mask
+    items = [('l1', 'sign', torch.sign(out.detach() - target).cpu())]
     eng = loss_fn._engine
-    H = Wd = 256
+    H, Wd = int(out.shape[2]), int(out.shape[3])
     lib = N.lib()
 
     def vgg_y(idx):
