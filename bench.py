@@ -124,7 +124,33 @@ def cpu_baseline(problem, chunk=MAX_BATCH):
             cpu_model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), None)
     except OSError:
         pass
+    # BASELINE configs[0] ("C1 ... timed for 5 steps"): examples/invert_biggan_adam.py with
+    # num_samples = 1 and the weighted L1 term alone -- fwd + loss + bwd (weight gradients on, as the reference
+    # computes them) + torch.optim.Adam on (z, c), lr 0.05 / 0.01 (variable_manager.py:231-235)
+    def config1(steps=5):
+        Wg = {k: (v.detach().clone().requires_grad_(True)
+                  if torch.is_floating_point(v) and 'running_' not in k else v) for k, v in W.items()}
+        z = torch.fmod(torch.randn(1, 128, generator=g), 2.0).requires_grad_(True)
+        c = c_default.unsqueeze(0).clone().requires_grad_(True)
+        adam = torch.optim.Adam([{'params': [z], 'lr': 0.05}, {'params': [c], 'lr': 0.01}])
+        times = []
+        for _ in range(steps + 1):
+            t0 = time.perf_counter()
+            adam.zero_grad()
+            with torch.no_grad():
+                z.clamp_(-2.0, 2.0)
+            out = R.biggan_forward(Wg, z, c)
+            loss = L.reconstruction_loss(out, target.unsqueeze(0), weight.unsqueeze(0))
+            loss.mean().backward()
+            adam.step()
+            times.append(time.perf_counter() - t0)
+        return times[1:]                                     # (the first step warms the primitives up)
+    t_c1 = config1()
     return {'value': round(chunk / t_on[1], 4), 'unit': 'evals/s',
+            'config1': {'evals_per_s': round(len(t_c1) / sum(t_c1), 4), 'ms_per_step': round(1e3 * sum(t_c1) / len(t_c1), 1),
+                        'sample': '5 steps of BASELINE config 1 (num_samples = 1, weighted L1 only, BigGAN-deep-256 fwd + '
+                                  'bwd with weight gradients + Adam), after one warm-up step',
+                        'gpu_side': 'config.extra.biggan_gradient_n1_l1'},
             'cores': torch.get_num_threads(), 'kind': 'port',
             'cpu': cpu_model, 'host_cpus': os.cpu_count(),
             'samples_evals_per_s': [round(chunk / t, 4) for t in t_on],
@@ -233,8 +259,9 @@ def extra_configs(dev, n_steps=6):
     out = {}
     Wv = S.lpips_vgg_weights(1)
 
-    def run(name, model, vm, n, size, note, profile=None, **kw):
-        loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
+    def run(name, model, vm, n, size, note, profile=None, loss_fn=None, **kw):
+        if loss_fn is None:
+            loss_fn = LF.ProjectionLoss(lpips_net='vgg', weights=Wv, device=dev)
         opt = GradientOptimizer(model, vm, loss_fn, max_batch_size=MAX_BATCH, **kw)
         variables = vm.initialize(num_samples=n)
         # (4 untimed steps: with <= 6 candidates the step is captured in a HIP graph on its third call)
@@ -258,13 +285,20 @@ def extra_configs(dev, n_steps=6):
                 opt.step(variables, optimize=True)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            T = N.prof_end()
+            T = N.prof_totals()
             f, m, c, b, x, mf = T.flops, T.ms, T.count, T.bytes, T.exec_flops, T.mfma_flops
             opt.use_graph = saved
             if m[0] > 0:
                 tf = f[0] / (m[0] * 1e-3) / 1e12
+                dom = max(FAM_3X3, key=lambda q: T.fam_ms[q])
                 out[name]['dominant_kernel'] = {
                     'family': '3x3 / sub-pixel convs (wino16s_conv_kernel + conv_h2_kernel<9|4>)',
+                    'by_time': {N.PROF_FAMILIES[q]: round(T.fam_ms[q], 3) for q in range(6) if T.fam_count[q]},
+                    'kernel': N.PROF_FAMILIES[dom],
+                    'kernel_avg_launch_ms': round(T.fam_ms[dom] / max(T.fam_count[dom], 1), 4),
+                    'kernel_frac_executed_of_bf16_peak': round(
+                        T.fam_mfma_flops[dom] / (T.fam_ms[dom] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 3)
+                    if T.fam_ms[dom] > 0 else None,
                     'time_share_of_step': round(4 * m[0] * 1e-3 / el, 3),
                     'achieved_tflops_algorithmic': round(tf, 1),
                     'frac_of_bf16x3_ceiling': round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 3),
@@ -284,8 +318,16 @@ def extra_configs(dev, n_steps=6):
                     learning_rate=0.01)
         vm.register('target', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_target(256, 1))
         vm.register('weight', (3, 256, 256), 'output', requires_grad=False, default=S.synthetic_weight_mask(256))
-        run('biggan_gradient_n8', BigGAN(weights=S.biggan_weights(0), device=dev), vm, 8, 256,
+        biggan = BigGAN(weights=S.biggan_weights(0), device=dev)
+        run('biggan_gradient_n8', biggan, vm, 8, 256,
             'BASELINE config 2: GradientOptimizer inner step, 8 samples, L1 + 10*LPIPS-VGG16')
+        # C1: examples/invert_biggan_adam.py with num_samples = 1 and the L1 term alone (BASELINE configs[0], the
+        # reference's own CPU-runnable case; its CPU timing is cpu_baseline.config1)
+        run('biggan_gradient_n1_l1', biggan, vm, 1, 256,
+            'BASELINE config 1: examples/invert_biggan_adam.py:19-31,108 with num_samples = 1, weighted L1 only '
+            '(ReconstructionLoss): one candidate per step, launch-latency bound',
+            loss_fn=LF.ReconstructionLoss())
+        del biggan
 
         # C4: StyleGAN2 cars 512^2, 32 samples, Compose(NormalPerturb, Clamp), loss mask
         gen = StyleGAN2(model='cars', search='z', device=dev)
@@ -307,7 +349,7 @@ def extra_configs(dev, n_steps=6):
         run('stylegan2_cars_512_n32', FixedNoise(), vm, 32, 512,
             'BASELINE config 4 inner step: 32 samples (reference chunks 9,9,9,5 define the '
             'gradient scale; executed in one device pass), z-space, rows 64:-64 loss mask',
-            profile='profiles/round4_sg2_512_kernel_stats.csv, round4_sg2_512_layers.txt',
+            profile='profiles/round6_sg2_512_kernel_stats.csv, round6_sg2_512_layers.txt',
             exec_batch_size='all')
         del gen, fixed
         torch.cuda.empty_cache()
@@ -325,7 +367,7 @@ def extra_configs(dev, n_steps=6):
         run('stylegan2_ffhq_1024_shard3_wplus', gen, vm, 3, 1024,
             'BASELINE config 5, one rank\'s shard: 3 candidates, W+ latents [18,512] and the '
             '2.8M-element noise vector both optimised',
-            profile='profiles/round4_sg2_1024_kernel_stats.csv, round4_sg2_1024_layers.txt')
+            profile='profiles/round6_sg2_1024_kernel_stats.csv, round6_sg2_1024_layers.txt')
     return out
 
 
@@ -403,9 +445,10 @@ def full_schedule_and_default_loss(dev, ms_per_step):
     return out
 
 
-def alone_leg(opt, variables, lib, bf3, steps=4):
-    """the 3x3 launches of the step with nothing beside them: one pass of the whole population on one stream
-    (exec_batch_size = population), every launch of `steps` steps timed once"""
+def alone_leg(opt, variables, lib, steps=8, period=4):
+    """the conv launches of the step with nothing beside them: one pass of the whole population on one stream
+    (exec_batch_size = population), `steps` more steps right after the timed region, every launch timed
+    steps / period times (hipEvent pairs on the launch stream, phase rotating with the step)"""
     from pix2latent_amd import _native as N
     saved = opt.exec_batch_size
     opt.exec_batch_size = POP                            # (an execution pass above the reference chunk: one stream)
@@ -415,22 +458,120 @@ def alone_leg(opt, variables, lib, bf3, steps=4):
         N.check(lib.p2l_prof_begin(4096), 'p2l_prof_begin')
         t0 = time.perf_counter()
         for i in range(steps):
-            lib.p2l_prof_step(i, steps)
+            lib.p2l_prof_step(i, period)
             opt.step(variables, optimize=True)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        T = N.prof_end()
+        T = N.prof_totals()
     finally:
         opt.exec_batch_size = saved
-    ms, cnt = T.ms[0], max(T.count[0], 1)
+    return T, el, steps, period
+
+
+FAM_3X3 = (1, 2, 3, 4, 0)          # P2L_PROF_FAM_*: the families a 3x3 launch can belong to
+
+
+def family_record(T, steps, elapsed, period, bf3, exec_batch, lanes):
+    """the roofline record of one measured leg from the library's per-launch totals (P2LProfTotals): the 3x3
+    family as a whole (achieved / peak / frac = what the matrix pipe EXECUTES), its DOMINANT KERNEL by time
+    (the row to hold against a rocprofv3 --kernel-trace --stats table), the 1x1 family against the memory roof"""
+    from pix2latent_amd import _native as N
+    flops, ms, cnt, abytes, xflops, mflops, wbytes = (T.flops, T.ms, T.count, T.bytes, T.exec_flops,
+                                                      T.mfma_flops, T.write_bytes)
     peak = BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS
-    ach = (T.mfma_flops[0] if bf3 else T.exec_flops[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {'what': 'one pass of %d candidates on one stream (exec_batch_size = population), %d steps after the '
-                    'timed region, every 3x3 launch timed once' % (POP, steps),
-            'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'algorithmic_tflops': round(T.flops[0] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
-            'avg_launch_ms': round(ms / cnt, 4), 'sampled_launches': int(T.count[0]),
-            'ms_per_step': round(1e3 * el / steps, 3)}
+    sec = ms[0] * 1e-3
+    conv_tflops = flops[0] / sec / 1e12 if sec > 0 else 0.0
+    exec_tflops = xflops[0] / sec / 1e12 if sec > 0 else 0.0
+    mfma_tflops = mflops[0] / sec / 1e12 if sec > 0 else 0.0
+    prod_mix = mflops[0] / xflops[0] if xflops[0] > 0 else 6.0
+    conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
+    ach = mfma_tflops if bf3 else exec_tflops
+    dom = max(FAM_3X3, key=lambda f: T.fam_ms[f])
+    dsec = T.fam_ms[dom] * 1e-3
+    dn = max(T.fam_count[dom], 1)
+    dom_ach = T.fam_mfma_flops[dom] / dsec / 1e12 if dsec > 0 else 0.0
+    rec = {
+        'exec_batch_size': exec_batch, 'lanes': lanes,
+        'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+        'frac_is': 'executed 16-bit MFMA FLOP/s / dense 16-bit MFMA peak' if bf3
+                   else 'executed fp32 MFMA FLOP/s / fp32 MFMA peak',
+        'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
+        'sampled_launches': int(cnt[0]),
+        'launches_per_step': round(cnt[0] * period / steps, 1),
+        'time_share_of_step': round(period * ms[0] * 1e-3 / elapsed, 4),
+        'ms_per_step_of_this_leg': round(1e3 * elapsed / steps, 3),
+        'algo_bytes_per_launch': round(abytes[0] / max(cnt[0], 1)),
+        'dominant_kernel': {
+            'name': N.PROF_FAMILIES[dom],
+            'launches_per_step': round(T.fam_count[dom] * period / steps, 1),
+            'avg_launch_ms': round(T.fam_ms[dom] / dn, 4),
+            'time_share_of_step': round(period * dsec / elapsed, 4),
+            'achieved': round(dom_ach, 1), 'frac': round(dom_ach / peak, 4),
+            'algorithmic_tflops': round(T.fam_flops[dom] / dsec / 1e12, 1) if dsec > 0 else None,
+            'gflop_per_launch': round(T.fam_flops[dom] / dn / 1e9, 2),
+            'algo_bytes_per_launch': round(T.fam_bytes[dom] / dn),
+            'check': 'avg_launch_ms x launches = the Calls x AverageNs row of this kernel in the rocprofv3 '
+                     '--kernel-trace --stats table of the same configuration (profiles/round6_kernel_stats_*.csv)'},
+        'families_ms_per_step': {N.PROF_FAMILIES[f]: round(T.fam_ms[f] * period / steps, 3)
+                                 for f in range(6) if T.fam_count[f]},
+        # the algorithmic (fp32-equivalent, 9 taps on the output grid, 3 real image channels) rate of the
+        # same launches and its ratios
+        'algorithmic': {
+            'tflops': round(conv_tflops, 2),
+            'gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),
+            'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+            'mfma_products_per_fp32_product': round(prod_mix, 3),
+            'vs_mix_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix), 4) if bf3 else None,
+            'ceiling_of_that_ratio': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
+            'vs_bf16x3_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6), 4) if bf3 else None,
+            'executed_fp32_equiv_tflops': round(exec_tflops, 2)},
+        # the 1x1 family is output-dominated: its roof is memory, and the WRITE rate of the part (4.4-4.9
+        # TB/s, tools/micro/mem_rate.hip) rather than the 8 TB/s headline
+        'conv1x1': {'achieved': round(conv1_tflops, 2), 'unit': 'TFLOP/s',
+                    'mfma_products_per_fp32_product': round(mflops[1] / xflops[1], 2) if xflops[1] > 0 else None,
+                    'sampled_launches': int(cnt[1]),
+                    'launches_per_step': round(cnt[1] * period / steps, 1),
+                    'time_share_of_step': round(period * ms[1] * 1e-3 / elapsed, 4),
+                    'bound': 'hbm',
+                    'achieved_tb_per_s': round(abytes[1] / (ms[1] * 1e-3) / 1e12, 3) if ms[1] > 0 else None,
+                    'peak_tb_per_s': HBM_PEAK_TBS,
+                    'measured_stream_tb_per_s': {'write': 4.5, 'read': 6.5, 'copy': 5.0},
+                    'frac': round(abytes[1] / (ms[1] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if ms[1] > 0 else None,
+                    'per_layer_table': 'profiles/round6_conv1x1_roofline.txt'},
+    }
+    # PMC counters cannot be read from inside the timed process: `traffic` is the committed result of the
+    # separate rocprofv3 --pmc passes over `bench.py --pmc-run --exec-batch <this leg's>` (tools/gpu_round6.sh
+    # -> tools/traffic_json.py), taken at THIS leg's execution batch -- a file from another batch is refused
+    traffic, src, rw = None, None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'round6_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        run = next((r for r in tj.get('runs', []) if r.get('exec_batch_size') == exec_batch), None)
+        if run is None:
+            src = {'file': 'profiles/round6_traffic.json',
+                   'refused': 'no PMC pass at exec_batch_size %s (have %s)'
+                              % (exec_batch, [r.get('exec_batch_size') for r in tj.get('runs', [])])}
+        elif cnt[0] > 0:
+            a_wr = wbytes[0] / cnt[0]
+            a_rd = abytes[0] / cnt[0] - a_wr
+            traffic = run['hbm_bytes_per_launch']
+            rw = {'fetch_bytes_per_launch': run['fetch_bytes_per_launch'],
+                  'write_bytes_per_launch': run['write_bytes_per_launch'],
+                  'algo_read_bytes_per_launch': round(a_rd), 'algo_write_bytes_per_launch': round(a_wr),
+                  'fetch_over_algorithmic': round(run['fetch_bytes_per_launch'] / a_rd, 3) if a_rd > 0 else None,
+                  'write_over_algorithmic': round(run['write_bytes_per_launch'] / a_wr, 3) if a_wr > 0 else None,
+                  'traffic_over_algorithmic': round(traffic / (a_rd + a_wr), 3) if a_rd + a_wr > 0 else None}
+            src = {'file': 'profiles/round6_traffic.json', 'commit': tj.get('commit'), 'box': tj.get('box'),
+                   'command': run.get('command'), 'exec_batch_size': run.get('exec_batch_size'),
+                   'launches_counted': run.get('fetch_launches'),
+                   'note': 'separate rocprofv3 --pmc passes (FETCH_SIZE x 2 per the guide, WRITE_SIZE) over the '
+                           'bench command at this execution batch'}
+    rec['traffic'] = traffic
+    rec['traffic_unit'] = 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)'
+    rec['traffic_source'] = src
+    rec['traffic_read_write'] = rw
+    return rec
 
 
 def exact_fp32_leg(dev, args):
@@ -473,6 +614,12 @@ def main():
                     help='do not sample socket power / shader clock while the timed steps run')
     ap.add_argument('--no-fp32-leg', action='store_true',
                     help='skip the extra exact-fp32-MFMA measurement reported in config')
+    ap.add_argument('--no-alone', action='store_true',
+                    help='skip the one-pass-of-18 leg that measures the kernels without the other lane beside them')
+    ap.add_argument('--pmc-run', action='store_true',
+                    help='profiling runs (rocprofv3 --pmc / --kernel-trace): warm-up + timed steps ONLY -- no re-score, '
+                         'no alone leg, no side configurations -- so that every dispatch the tool sees belongs to '
+                         'the configuration named on the command line')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the additional configurations reported under config.extra')
     ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex'],
@@ -486,6 +633,8 @@ def main():
                          'as two lanes on two HIP streams (pix2latent_amd/lanes.py; P2L_STREAMS=1: one '
                          'after the other); 18 = one pass of the whole population on one stream')
     args = ap.parse_args()
+    if args.pmc_run:
+        args.no_alone = args.no_fp32_leg = args.no_extra = args.no_cpu_baseline = True
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -545,18 +694,18 @@ def main():
             opt.step(variables, optimize=True)
         sync()
         elapsed = time.perf_counter() - t0
-    T = N.prof_end()
+    T = N.prof_totals()
     flops, ms, cnt, abytes, xflops, mflops, wbytes = (T.flops, T.ms, T.count, T.bytes, T.exec_flops,
                                                       T.mfma_flops, T.write_bytes)
     last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()
     t1 = time.perf_counter()
-    n_rescore = 3
+    n_rescore = 0 if args.pmc_run else 3
     for _ in range(n_rescore):
         opt.step(variables, optimize=False)
     sync()
-    rescore_rate = POP * n_rescore / (time.perf_counter() - t1)
+    rescore_rate = POP * n_rescore / (time.perf_counter() - t1) if n_rescore else 0.0
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -567,38 +716,55 @@ def main():
         evals = POP * args.steps
         # generator fwd+dgrad 58.80 GMAC + LPIPS net fwd+dgrad (VGG16 40.08 | AlexNet 1.74 GMAC)
         gflop_eval = GFLOP_PER_EVAL if args.lpips_net == 'vgg' else 2 * (58.80 + 1.737)
-        conv_tflops = flops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
-        exec_tflops = xflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
-        # 16-bit MFMA FLOP/s issued, and the MFMA products per fp32 product of the launch mix
-        # (6 = bf16 x 3, 3 = fp16 x 2 launches; weighted by executed FLOPs)
-        mfma_tflops = mflops[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
-        prod_mix = mflops[0] / xflops[0] if xflops[0] > 0 else 6.0
-        conv1_tflops = flops[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0
         bf3 = N.default_wfmt() != N.WFMT_F32
-        # PMC counters cannot be read from inside the timed process: `traffic` is the
-        # committed result of the separate rocprofv3 --pmc passes over this same command
-        # (tools/gpu_profile.sh -> tools/traffic_json.py), or null when absent
-        traffic, traffic_src, traffic_rw = None, None, None
-        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-        for name in ('round5_traffic.json', 'round4_traffic.json', 'round3_traffic.json', 'round2_traffic.json', 'round1_traffic.json'):
-            tpath = os.path.join(prof_dir, name)
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic = tj.get('hbm_bytes_per_launch')
-                if tj.get('fetch_bytes_per_launch') and cnt[0] > 0:
-                    a_wr = wbytes[0] / cnt[0]
-                    a_rd = abytes[0] / cnt[0] - a_wr
-                    traffic_rw = {'fetch_bytes_per_launch': tj['fetch_bytes_per_launch'],
-                                  'write_bytes_per_launch': tj['write_bytes_per_launch'],
-                                  'algo_read_bytes_per_launch': round(a_rd), 'algo_write_bytes_per_launch': round(a_wr),
-                                  'fetch_over_algorithmic': round(tj['fetch_bytes_per_launch'] / a_rd, 3) if a_rd > 0 else None,
-                                  'write_over_algorithmic': round(tj['write_bytes_per_launch'] / a_wr, 3) if a_wr > 0 else None}
-                traffic_src = {'file': 'profiles/' + name, 'commit': tj.get('commit'),
-                               'box': tj.get('box'), 'command': tj.get('command'),
-                               'note': 'separate rocprofv3 --pmc passes over this bench command '
-                                       '(PMC cannot be read inside the timed process)'}
-                break
+        # what the timed steps measured.  With two lanes a launch's hipEvent pair also spans the time it
+        # shares the GPU with the OTHER lane's launches: the step is faster, every launch looks slower, and
+        # the durations sum to more than the step -- reported, but not as the kernel's figure
+        timed = family_record(T, args.steps, elapsed, period, bf3, args.exec_batch, lanes_used)
+        kernel_text = (
+            'every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
+            '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
+            'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product; per-image maxima handed '
+            'over by the launch that wrote the input, wino_amax_kernel where none did), '
+            'conv_h2_kernel<TAPS=9|4> (direct | sub-pixel, the same fp16 x 2 arithmetic) and '
+            'conv_thinin/thinout_kernel (3-channel image convs) in the bf16 x 3 arithmetic (6 x '
+            'v_mfma_f32_32x32x16_bf16 per product on 3-way split fp32 operands); `dominant_kernel` names the one '
+            'that takes the most time' if bf3 else
+            'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)')
+        # achieved / peak / frac are what the matrix pipe EXECUTES -- 16-bit MFMA
+        # FLOP/s issued by these launches (3 products per fp32 product for the fp16 x 2 launches, 6 for bf16
+        # x 3; Winograd launches 16 instead of 36 products per output quad, sub-pixel launches 4
+        # phase-taps, image convs their padded channels) over the dense 16-bit MFMA peak.
+        roof = {'kernel': kernel_text, 'bound': 'mfma'}
+        if lanes_used > 1 and world == 1 and not args.no_alone:
+            # the TOP-LEVEL figures are the kernels' own -- the same build, the same
+            # launches with nothing beside them: one pass of the 18 candidates on one stream, 8 more steps
+            # right after the timed region, every launch timed twice.  What the launches get while the two
+            # lanes overlap is under `concurrent`.
+            Ta, el_a, st_a, per_a = alone_leg(opt, variables, lib)
+            roof.update(family_record(Ta, st_a, el_a, per_a, bf3, POP, 1))
+            roof['measured'] = ('one pass of %d candidates on one stream (exec_batch_size = population), %d steps '
+                                'right after the timed region, hipEvent pairs on the launch stream around every '
+                                '%d-th conv launch, phase rotating with the step: NON-overlapped launch durations. '
+                                'The timed steps themselves run the reference chunks on %d lanes: see `concurrent`'
+                                % (POP, st_a, per_a, lanes_used))
+            conc = {k: timed[k] for k in ('exec_batch_size', 'lanes', 'achieved', 'frac', 'avg_launch_ms',
+                                          'sampled_launches', 'launches_per_step', 'time_share_of_step',
+                                          'algo_bytes_per_launch', 'traffic', 'traffic_source', 'traffic_read_write')}
+            conc['dominant_kernel'] = timed['dominant_kernel']
+            conc['conv1x1'] = timed['conv1x1']
+            conc['what'] = ('the launches of the TIMED steps (reference chunks of %d on %d HIP streams): a hipEvent '
+                            'pair spans the time a launch shares the GPU with the other lane, so these durations '
+                            'overlap -- time_share_of_step sums overlapping intervals and may exceed 1 -- and '
+                            '`achieved` is what a launch gets while overlapped, not what the kernel does'
+                            % (args.exec_batch, lanes_used))
+            roof['concurrent'] = conc
+        else:
+            roof.update(timed)
+            roof['measured'] = ('the timed steps: hipEvent pairs on the launch stream around every %d-th conv '
+                                'launch, phase rotating with the step' % period) + (
+                '; %d lanes: durations overlap (see DESIGN section 6)' % lanes_used if lanes_used > 1 else '')
+        roof['launch_sampling'] = 'every %d-th conv launch of the timed steps timed (hipEvent pairs)' % period
         rec = {
             'metric': 'candidate-latent evals/sec (fwd+loss+bwd), BigGAN-256 pop=18',
             'value': round(evals / elapsed, 3),
@@ -641,79 +807,9 @@ def main():
                 'last_losses_min_max': [round(min(last_loss), 5), round(max(last_loss), 5)],
                 'last_losses': [round(x, 6) for x in last_loss],
             },
-            'roofline': {
-                'kernel': ('every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
-                           '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
-                           'in two fp16 pieces, 3 x v_mfma_f32_32x32x16_f16 per product; per-image maxima handed '
-                           'over by the launch that wrote the input, wino_amax_kernel where none did), '
-                           'conv_h2_kernel<TAPS=9|4> (direct | sub-pixel, the same fp16 x 2 arithmetic) and '
-                           'conv_thinin/thinout_kernel (3-channel image convs) in the bf16 x 3 arithmetic (6 x '
-                           'v_mfma_f32_32x32x16_bf16 per product on 3-way split fp32 operands)'
-                           if bf3 else
-                           'conv_mfma_kernel<TAPS=9> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)'),
-                'bound': 'mfma',
-                # achieved / peak / frac are what the matrix pipe EXECUTES --
-                # 16-bit MFMA FLOP/s issued by these launches (3 products per fp32 product for the
-                # fp16 x 2 launches, 6 for bf16 x 3; Winograd launches 16 instead of 36 products per
-                # output quad, sub-pixel launches 4 phase-taps, image convs their padded channels)
-                # over the dense 16-bit MFMA peak.  The algorithmic (fp32-equivalent, 9 taps on the
-                # output grid, 3 real image channels) rate of the same launches and its ratios are
-                # under `algorithmic`.
-                'achieved': round(mfma_tflops if bf3 else exec_tflops, 1),
-                'peak': BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': round((mfma_tflops if bf3 else exec_tflops) /
-                              (BF16_MFMA_PEAK_TFLOPS if bf3 else FP32_MFMA_PEAK_TFLOPS), 4),
-                'frac_is': 'executed 16-bit MFMA FLOP/s / dense 16-bit MFMA peak' if bf3
-                           else 'executed fp32 MFMA FLOP/s / fp32 MFMA peak',
-                'algorithmic': {
-                    'tflops': round(conv_tflops, 2),
-                    'gflop_per_launch': round(flops[0] / max(cnt[0], 1) / 1e9, 3),
-                    'vs_fp32_mfma_peak': round(conv_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-                    'mfma_products_per_fp32_product': round(prod_mix, 3),
-                    # algorithmic FLOP/s against (dense 16-bit peak / products per fp32 product of the
-                    # launch mix): a MIXED scale whose top is `ceiling_of_that_ratio`, not 1
-                    'vs_mix_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / prod_mix), 4) if bf3 else None,
-                    'ceiling_of_that_ratio': round(flops[0] / xflops[0], 3) if xflops[0] > 0 else None,
-                    'vs_bf16x3_ceiling': round(conv_tflops / (BF16_MFMA_PEAK_TFLOPS / 6), 4) if bf3 else None,
-                    'executed_fp32_equiv_tflops': round(exec_tflops, 2),
-                },
-                'traffic': traffic,
-                'traffic_unit': 'HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
-                'traffic_source': traffic_src,
-                'traffic_read_write': traffic_rw,
-                'algo_bytes_per_launch': round(abytes[0] / max(cnt[0], 1)),
-                'sampled_launches': int(cnt[0]),
-                'launches_per_step': round(cnt[0] * period / args.steps, 1),
-                'launch_sampling': 'every %d-th conv launch timed (hipEvent pairs), phase rotating '
-                                   'with the step' % period,
-                'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
-                'time_share_of_step': round(period * ms[0] * 1e-3 / elapsed, 4),
-                # the 1x1 family is output-dominated: its roof is memory, and the WRITE rate of the
-                # part (4.4-4.9 TB/s, tools/micro/mem_rate.hip) rather than the 8 TB/s headline
-                'conv1x1': {'achieved': round(conv1_tflops, 2), 'unit': 'TFLOP/s',
-                            'mfma_products_per_fp32_product': round(mflops[1] / xflops[1], 2) if xflops[1] > 0 else None,
-                            'sampled_launches': int(cnt[1]),
-                            'launches_per_step': round(cnt[1] * period / args.steps, 1),
-                            'time_share_of_step': round(period * ms[1] * 1e-3 / elapsed, 4),
-                            'bound': 'hbm',
-                            'achieved_tb_per_s': round(abytes[1] / (ms[1] * 1e-3) / 1e12, 3) if ms[1] > 0 else None,
-                            'peak_tb_per_s': HBM_PEAK_TBS,
-                            'measured_stream_tb_per_s': {'write': 4.5, 'read': 6.5, 'copy': 5.0},
-                            'frac': round(abytes[1] / (ms[1] * 1e-3) / 1e12 / HBM_PEAK_TBS, 4) if ms[1] > 0 else None,
-                            'per_layer_table': 'profiles/round5_conv1x1_roofline.txt'},
-            },
+            'roofline': roof,
             'telemetry': telemetry.summary(),
         }
-        if lanes_used > 1:
-            # two streams: a launch's hipEvent duration includes the time it shares the GPU with the other
-            # lane's launches, so `achieved` above is what a launch gets WHILE OVERLAPPED (the step is faster,
-            # each launch slower).  The same launches ALONE -- one pass of 18 on one stream, a few more steps
-            # outside the timed region -- say what the kernel itself does:
-            rec['roofline']['concurrency'] = ('%d lanes: durations are measured while the other lane runs; '
-                                              'time_share_of_step sums overlapping intervals' % lanes_used)
-            if world == 1:
-                rec['roofline']['alone'] = alone_leg(opt, variables, lib, bf3)
         if world == 1 and bf3 and not args.no_fp32_leg:
             # the same steps with every conv on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32),
             # reported beside `value` so the arithmetic choice is visible in one line

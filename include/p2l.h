@@ -204,7 +204,17 @@ typedef struct P2LProfTotals {
                             * in 16-bit-MFMA time): / time / dense 16-bit peak = matrix-pipe busy      */
   double write_bytes[2];   /* the WRITTEN share of `bytes` (y / yp): PMC FETCH_SIZE and WRITE_SIZE     *
                             * can each be set against their own algorithmic count                     */
+  /* version 101: the same totals per KERNEL family (P2L_PROF_FAM_*), so that a bench line can name its *
+   * dominant kernel and be checked against that kernel's row of a rocprofv3 --kernel-trace --stats table */
+  int32_t fam_count[8];
+  double fam_ms[8], fam_flops[8], fam_mfma_flops[8], fam_bytes[8];
 } P2LProfTotals;
+enum { P2L_PROF_FAM_OTHER = 0,       /* exact-fp32 / bf16 x 3 direct kernels, 8x16 Winograd ...            */
+       P2L_PROF_FAM_WINO_H2 = 1,     /* wino16s_conv_kernel<.., H2 = true, ..> (+ its split-K finish)        */
+       P2L_PROF_FAM_DIRECT_H2 = 2,   /* conv_h2_kernel<9, ..> (+ split-K finish)                            */
+       P2L_PROF_FAM_SUBPIX_H2 = 3,   /* conv_h2_kernel<4, ..>: sub-pixel forward / input gradient           */
+       P2L_PROF_FAM_THIN = 4,        /* conv_thinin_kernel / conv_thinout_kernel (3-channel image convs)    */
+       P2L_PROF_FAM_PW = 5 };        /* pw_h2_kernel / pw_conv_kernel (1x1)                                  */
 int p2l_prof_totals(P2LProfTotals* out);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every

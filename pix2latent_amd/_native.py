@@ -132,7 +132,15 @@ class P2LProfTotals(C.Structure):
     _fields_ = [('size', C.c_uint32), ('count', C.c_int32 * 2), ('reserved0', C.c_int32),
                 ('flops', C.c_double * 2), ('ms', C.c_double * 2), ('bytes', C.c_double * 2),
                 ('exec_flops', C.c_double * 2), ('mfma_flops', C.c_double * 2),
-                ('write_bytes', C.c_double * 2)]
+                ('write_bytes', C.c_double * 2),
+                ('fam_count', C.c_int32 * 8), ('fam_ms', C.c_double * 8), ('fam_flops', C.c_double * 8),
+                ('fam_mfma_flops', C.c_double * 8), ('fam_bytes', C.c_double * 8)]
+
+
+# P2LProfTotals.fam_* index -> the kernel a rocprofv3 kernel table lists (include/p2l.h P2L_PROF_FAM_*)
+PROF_FAMILIES = {0: 'other (exact-fp32 / bf16x3 direct, 8x16 Winograd)', 1: 'wino16s_conv_kernel<.., H2>',
+                 2: 'conv_h2_kernel<9, ..>', 3: 'conv_h2_kernel<4, ..>', 4: 'conv_thinin/thinout_kernel',
+                 5: 'pw_h2_kernel / pw_conv_kernel'}
 
 
 def prof_totals():

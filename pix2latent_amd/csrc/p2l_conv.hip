@@ -68,6 +68,7 @@ struct ConvProf {
   std::vector<double> bytes;    // algorithmic bytes: every operand once + the packed weights
   std::vector<double> wbytes;   // ... of which written (y, yp)
   std::vector<int> kind;
+  std::vector<int> fam;         // P2L_PROF_FAM_*: which kernel took the launch
   std::vector<std::array<int, 10>> shape;   // taps B H W Cin Cout ups pro arb splitk
   std::string dump_path;                    // p2l_prof_dump
   int seq = 0, period = 1, phase = 0;       // sampling (p2l_prof_step)
@@ -1437,6 +1438,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     g_prof.xflops[prof_slot] =
         2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * (d->ups >= 2 ? 4 : d->taps);
     g_prof.kind[prof_slot] = d->taps == 9 ? 0 : 1;
+    g_prof.fam[prof_slot] = P2L_PROF_FAM_OTHER;
     g_prof.nprod[prof_slot] = (d->wfmt == P2L_WFMT_F32 || (d->taps == 1 && !pw_shape(d))) ? 16 : 6;
     g_prof.shape[prof_slot] = {d->taps, d->B, d->H, d->W, d->Cin, d->Cout, d->ups, d->pro,
                                arb ? (arb->skip ? 2 : 1) : 0, d->splitk};
@@ -1486,6 +1488,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     if (prof_slot >= 0) {
       g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * (double)d->Cin * d->Cout * 4;   // 16 per quad
       if (use_h2) g_prof.nprod[prof_slot] = 3;
+      g_prof.fam[prof_slot] = use_h2 ? P2L_PROF_FAM_WINO_H2 : P2L_PROF_FAM_OTHER;
       (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     }
     return rc;
@@ -1504,6 +1507,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     rc = p2l_pw_launch(kp, d->pro, st);
     if (prof_slot >= 0) {
       if (k.amax_in != nullptr) g_prof.nprod[prof_slot] = 3;
+      g_prof.fam[prof_slot] = P2L_PROF_FAM_PW;
       (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
     }
     return rc;
@@ -1519,6 +1523,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       rc = p2l_thinin_launch(kt, d->pro, st);
       if (prof_slot >= 0) {
         g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * 32.0 * d->Cout;    // K = 27 -> 32
+        g_prof.fam[prof_slot] = P2L_PROF_FAM_THIN;
         (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
       }
       return rc;
@@ -1532,6 +1537,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       if (prof_slot >= 0) {
         // pointwise product onto 32 columns for the 8x16 pixels + halo (192 rows per 128)
         g_prof.xflops[prof_slot] = 2.0 * d->B * d->H * d->W * 1.5 * d->Cin * 32.0;
+        g_prof.fam[prof_slot] = P2L_PROF_FAM_THIN;
         (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
       }
       return rc;
@@ -1579,6 +1585,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       rc = p2l_h2_launch(kh, d->pro, 4, bn, small_sp, st);
       if (prof_slot >= 0) {
         g_prof.nprod[prof_slot] = 3;
+        g_prof.fam[prof_slot] = P2L_PROF_FAM_SUBPIX_H2;
         (void)hipEventRecord(g_prof.ev[2 * prof_slot + 1], st);
       }
       return rc;
@@ -1645,7 +1652,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     }
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
     rc = p2l_h2_launch(kh, d->pro, 9, bn, small, st);
-    if (prof_slot >= 0) g_prof.nprod[prof_slot] = 3;
+    if (prof_slot >= 0) { g_prof.nprod[prof_slot] = 3; g_prof.fam[prof_slot] = P2L_PROF_FAM_DIRECT_H2; }
   } else
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
@@ -1671,7 +1678,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       if (rc) return rc;
     }
     rc = p2l_pw_launch(kp, d->pro, st);
-    if (prof_slot >= 0) g_prof.nprod[prof_slot] = 3;
+    if (prof_slot >= 0) { g_prof.nprod[prof_slot] = 3; g_prof.fam[prof_slot] = P2L_PROF_FAM_PW; }
   } else if (kc == 32) {
     if (bn == 64) rc = launch_conv<1, 64, 32, 4>(k, d->pro, 0, lds, st);
     else          rc = launch_conv<1, 32, 32, 4>(k, d->pro, 0, lds, st);
@@ -1816,6 +1823,7 @@ extern "C" int p2l_prof_begin(int max_launches) {
   g_prof.bytes.assign(max_launches, 0.0);
   g_prof.wbytes.assign(max_launches, 0.0);
   g_prof.kind.assign(max_launches, 0);
+  g_prof.fam.assign(max_launches, P2L_PROF_FAM_OTHER);
   g_prof.shape.assign(max_launches, {});
   g_prof.n = 0;
   g_prof.seq = 0; g_prof.period = 1; g_prof.phase = 0;
@@ -1866,6 +1874,14 @@ extern "C" int p2l_prof_totals(P2LProfTotals* out) {
     if (write_bytes) write_bytes[k] += g_prof.wbytes[i];
     ms[k] += t;
     count[k] += 1;
+    {
+      const int fm = g_prof.fam[i];
+      T.fam_count[fm] += 1;
+      T.fam_ms[fm] += t;
+      T.fam_flops[fm] += g_prof.flops[i];
+      T.fam_mfma_flops[fm] += g_prof.xflops[i] * g_prof.nprod[i];
+      T.fam_bytes[fm] += g_prof.bytes[i];
+    }
     if (dump) {
       const auto& sh = g_prof.shape[i];
       fprintf(dump, "%d %d %d %d %d %d %d %d %d %d %.6e %.6e %.6f %d\n", sh[0], sh[1], sh[2], sh[3],

@@ -70,7 +70,8 @@ def test_struct_layouts_match_the_compiled_header(tmp_path):
         'P2LArb': ['x', 'x_ld', 's', 't', 'st_bstride', 'skip', 'skip_ld', 'skip_C', 'skip_ups', 'ds', 'dt',
                    'dsdt_bstride', 'partial', 'nomask', 'amax'],
         'P2LConv': ['wfmt', 'form', 'algo_flops', 'w_floats'],
-        'P2LProfTotals': ['size', 'count', 'flops', 'ms', 'bytes', 'exec_flops', 'mfma_flops', 'write_bytes'],
+        'P2LProfTotals': ['size', 'count', 'flops', 'ms', 'bytes', 'exec_flops', 'mfma_flops', 'write_bytes',
+                          'fam_count', 'fam_ms', 'fam_flops', 'fam_mfma_flops', 'fam_bytes'],
     }
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "p2l.h"', 'int main(void) {']
     for st, ms in members.items():

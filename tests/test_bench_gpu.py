@@ -39,6 +39,19 @@ def test_bench_single_gpu_line():
     assert roof['conv1x1']['bound'] == 'hbm' and 'telemetry' in rec
     assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
     assert len(rec['config']['last_losses']) == 18
+    # the top-level figures are the kernels' own (one pass of 18, nothing beside the launches):
+    # they fit inside their step; what the launches get while the two lanes overlap sits under `concurrent`
+    assert rec['config']['lanes'] == 2 and roof['exec_batch_size'] == 18 and roof['lanes'] == 1
+    assert 0 < roof['time_share_of_step'] <= 1.0
+    dom = roof['dominant_kernel']
+    assert dom['name'].startswith('wino16s_conv_kernel') and 0 < dom['frac'] < 1 and dom['avg_launch_ms'] > 0
+    assert dom['time_share_of_step'] <= roof['time_share_of_step']
+    conc = roof['concurrent']
+    assert conc['exec_batch_size'] == 9 and conc['lanes'] == 2 and conc['frac'] < roof['frac']
+    # a traffic record belongs to the execution batch of its leg, or is absent with the reason
+    for leg in (roof, conc):
+        src = leg['traffic_source']
+        assert leg['traffic'] is None or src['exec_batch_size'] == leg['exec_batch_size']
 
 
 @pytest.mark.parametrize('world', [2, 4])

@@ -103,14 +103,14 @@ def test_second_lane_out_of_memory_falls_back_to_one_lane(monkeypatch):
     _, _, l1, z1 = _run(dev, 7)
     monkeypatch.setenv('P2L_STREAMS', '2')
     monkeypatch.setattr(lanes, '_gave_up', [])
-    real_lane, fired = BG.BigGAN._lane, []
+    real_ws, fired = BG.BigGAN._workspace, []
 
-    def failing_lane(self):
+    def failing_workspace(self, B):
         if lanes.current() == 1 and not fired:
             fired.append(1)
             raise torch.cuda.OutOfMemoryError('HIP out of memory (injected). Tried to allocate 3.4 GiB')
-        return real_lane(self)
-    monkeypatch.setattr(BG.BigGAN, '_lane', failing_lane)
+        return real_ws(self, B)
+    monkeypatch.setattr(BG.BigGAN, '_workspace', failing_workspace)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         model, eng, l2, z2 = _run(dev, 7)

@@ -203,8 +203,8 @@ def test_c5_ffhq_1024_wplus_and_noise_replayed_gradients_vs_oracle(ffhq):
 
     def oracle(dt, rows, replayed=True):
         n = rows.stop - rows.start
-        wr = wplus[rows].to(dt).requires_grad_(True)
-        nr = flat[rows].to(dt).requires_grad_(True)
+        wr = wplus[rows].detach().clone().to(dt).requires_grad_(True)
+        nr = flat[rows].detach().clone().to(dt).requires_grad_(True)
         s_t = [mk[rows] for mk in sg2]
         v_t = [(a, k, mk[rows]) for a, k, mk in vgg]
         if replayed:

@@ -33,25 +33,37 @@ def per_launch(path, counter):
     return calls, (total / calls if calls else 0.0)
 
 
-nf, f = per_launch(sys.argv[1], 'FETCH_SIZE')
-nw, w = per_launch(sys.argv[2], 'WRITE_SIZE')
+def one_run(fetch_csv, write_csv, bench_json):
+    nf, f = per_launch(fetch_csv, 'FETCH_SIZE')
+    nw, w = per_launch(write_csv, 'WRITE_SIZE')
+    b = json.load(open(bench_json))
+    return {
+        # the configuration the passes ran at, as the bench line of the FETCH pass reports it: bench.py
+        # looks a run up by exec_batch_size and refuses a file that has none for its leg
+        'exec_batch_size': b['config']['exec_batch_size'], 'lanes': b['config']['lanes'],
+        'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --pmc-run --steps %d --warmup %d '
+                   '--exec-batch %d' % (b['steps'], b['warmup'], b['config']['exec_batch_size']),
+        'fetch_launches': nf, 'write_launches': nw,
+        'fetch_size_raw_bytes_per_launch': round(f * 1024),
+        'fetch_bytes_per_launch': round(f * 1024 * 2),
+        'write_bytes_per_launch': round(w * 1024),
+        'hbm_bytes_per_launch': round(f * 1024 * 2 + w * 1024),
+        'algo_bytes_per_launch_of_that_run': b['roofline'].get('algo_bytes_per_launch'),
+    }
+
+
+# usage (round 6): traffic_json.py <out.json> <commit> <box> (<fetch_summary.csv> <write_summary.csv> <bench.json>)...
+out_path, commit, box = sys.argv[1:4]
+runs = [one_run(*sys.argv[i:i + 3]) for i in range(4, len(sys.argv) - 2, 3)]
 out = {
     'kernel': '3x3 conv launches: conv_h2_kernel<TAPS=9|4,...> / conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
               'wino16s_conv_kernel + conv_thinin/thinout_kernel; the bytes of wino_amax_kernel (max-|x| pass of '
               'the fp16 x 2 Winograd launches) and conv_splitk_finish* are included, per conv launch',
-    'commit': sys.argv[4] if len(sys.argv) > 4 else None,
-    'box': sys.argv[5] if len(sys.argv) > 5 else None,
-    'command': sys.argv[6] if len(sys.argv) > 6 else None,
-    'fetch_launches': nf, 'write_launches': nw,
-    'fetch_size_raw_bytes_per_launch': round(f * 1024),
-    'fetch_bytes_per_launch': round(f * 1024 * 2),
-    'write_bytes_per_launch': round(w * 1024),
-    'hbm_bytes_per_launch': round(f * 1024 * 2 + w * 1024),
-    'fetch_launches_note': 'FETCH and WRITE are reported separately so that their ratios to the algorithmic '
-                           'read / write bytes can be formed (bench.py roofline.traffic_*)',
-    'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over '
-              '`bench.py --steps 2 --warmup 1`; KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read '
-              'under-count); WRITE_SIZE uncalibrated',
+    'commit': commit, 'box': box,
+    'runs': runs,
+    'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --pmc-run` (warm-up + '
+              'timed steps only: every dispatch belongs to the named execution batch); KiB -> bytes; FETCH_SIZE x2 '
+              '(gfx950 wide-read under-count, MI355X_MICROARCH.md "HBM"); WRITE_SIZE as reported (uncalibrated)',
 }
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
+json.dump(out, open(out_path, 'w'), indent=1)
 print(json.dumps(out))
