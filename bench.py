@@ -293,7 +293,7 @@ def extra_configs(dev, n_steps=6):
                 dom = max(FAM_3X3, key=lambda q: T.fam_ms[q])
                 out[name]['dominant_kernel'] = {
                     'family': '3x3 / sub-pixel convs (wino16s_conv_kernel + conv_h2_kernel<9|4>)',
-                    'by_time': {N.PROF_FAMILIES[q]: round(T.fam_ms[q], 3) for q in range(6) if T.fam_count[q]},
+                    'by_time': {N.PROF_FAMILIES[q]: round(T.fam_ms[q], 3) for q in range(7) if T.fam_count[q]},
                     'kernel': N.PROF_FAMILIES[dom],
                     'kernel_avg_launch_ms': round(T.fam_ms[dom] / max(T.fam_count[dom], 1), 4),
                     'kernel_frac_executed_of_bf16_peak': round(
@@ -468,7 +468,7 @@ def alone_leg(opt, variables, lib, steps=8, period=4):
     return T, el, steps, period
 
 
-FAM_3X3 = (1, 2, 3, 4, 0)          # P2L_PROF_FAM_*: the families a 3x3 launch can belong to
+FAM_3X3 = (1, 2, 6, 3, 4, 0)          # P2L_PROF_FAM_*: the families a 3x3 launch can belong to
 
 
 def family_record(T, steps, elapsed, period, bf3, exec_batch, lanes):
@@ -513,7 +513,7 @@ def family_record(T, steps, elapsed, period, bf3, exec_batch, lanes):
             'check': 'avg_launch_ms x launches = the Calls x AverageNs row of this kernel in the rocprofv3 '
                      '--kernel-trace --stats table of the same configuration (profiles/round6_kernel_stats_*.csv)'},
         'families_ms_per_step': {N.PROF_FAMILIES[f]: round(T.fam_ms[f] * period / steps, 3)
-                                 for f in range(6) if T.fam_count[f]},
+                                 for f in range(7) if T.fam_count[f]},
         # the algorithmic (fp32-equivalent, 9 taps on the output grid, 3 real image channels) rate of the
         # same launches and its ratios
         'algorithmic': {

@@ -214,7 +214,8 @@ enum { P2L_PROF_FAM_OTHER = 0,       /* exact-fp32 / bf16 x 3 direct kernels, 8x
        P2L_PROF_FAM_DIRECT_H2 = 2,   /* conv_h2_kernel<9, ..> (+ split-K finish)                            */
        P2L_PROF_FAM_SUBPIX_H2 = 3,   /* conv_h2_kernel<4, ..>: sub-pixel forward / input gradient           */
        P2L_PROF_FAM_THIN = 4,        /* conv_thinin_kernel / conv_thinout_kernel (3-channel image convs)    */
-       P2L_PROF_FAM_PW = 5 };        /* pw_h2_kernel / pw_conv_kernel (1x1)                                  */
+       P2L_PROF_FAM_PW = 5,          /* pw_h2_kernel / pw_conv_kernel (1x1)                                  */
+       P2L_PROF_FAM_DIRECT_H2R = 6 };/* conv_h2r_kernel: 64 -> 64 channels, weights resident in registers    */
 int p2l_prof_totals(P2LProfTotals* out);
 /* Sampling: every hipEventRecord pair costs the stream a ~5 us bubble (500 of them are 5 %
  * of a 26 ms step), so a caller that times a whole step loop can ask for only every
@@ -333,7 +334,11 @@ enum {
    * blocks (4 waves) while the launch has <= 128 blocks of 16x16 -- chosen from the grid, i.e. from the
    * batch, which is allowed because the two shapes give bit-identical results and maxima slots.     */
   P2L_FORM_WINO_H2_8X16 = 64,   /* always the 4-wave block (tests)                                   */
-  P2L_FORM_WINO_H2_16X16 = 128  /* always the 8-wave block (tests, A/B)                              */
+  P2L_FORM_WINO_H2_16X16 = 128, /* always the 8-wave block (tests, A/B)                              */
+  /* 64 -> 64 channel 3x3 layers of whole 8x16-pixel tiles run with their weights resident in registers  *
+   * (csrc/p2l_h2r.hip: persistent blocks, one per CU); the results are bit-identical to the chunked      *
+   * direct kernel, which this bit keeps (tests, A/B)                                                     */
+  P2L_FORM_NO_H2R = 256
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

@@ -1214,6 +1214,15 @@ static int direct_split(const P2LConv* d) {
   return s <= 2 ? 1 : s;
 }
 
+// ... with the weights resident in registers (p2l_h2r.hip: persistent blocks, bit-identical results): the
+// 64 -> 64 channel layers of whole 8x16-pixel tiles that never split K.  Shape and format only.
+static bool direct_h2r(const P2LConv* d) {
+  if ((d->form & P2L_FORM_NO_H2R) || !direct_h2(d)) return false;
+  if (!p2l_h2r_shape(d->taps, d->ups, d->H, d->W, d->Cin, d->Cout, d->x_ld)) return false;
+  return d->H * d->W >= 128 && direct_split(d) <= 1;
+}
+
+
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
   if (!d || d->ups >= 2) return 1;       // sub-pixel modes never split K
@@ -1280,7 +1289,8 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
 #ifdef P2L_AB_PW_SLOTS_R4             // (A/B build: the round-4 count, for the test that has to fail on it)
   const int nnt = pw_shape(d) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
 #else
-  const int nnt = (pw_shape(d) || pw_small_h2(d)) ? d->Cout / 64 : d->Cout / choose_bn(d, k.n_mtiles);
+  // (the register-resident 64-channel kernel writes all 64 channels of a tile from one block)
+  const int nnt = (pw_shape(d) || pw_small_h2(d)) ? d->Cout / 64 : direct_h2r(d) ? 1 : d->Cout / choose_bn(d, k.n_mtiles);
 #endif
   return k.tiles_x * k.tiles_y * nnt * (d->ups == 2 ? 4 : 1) * 4;
 }
@@ -1405,6 +1415,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     if (thin_shape(d) >= 0 && ex && (ex->oscale || ex->noise)) nslots = 0;   // (generic kernel then)
     // (the slot count was promised for the fp16 x 2 small-grid pointwise kernel: 64-channel tiles)
     if (nslots > 0 && h2_pw_small && !use_h2 && effective_splitk(d) <= 1) return P2L_EWS;
+    if (nslots > 0 && direct_h2r(d) && !use_h2) return P2L_EWS;   // (... for the register-resident kernel: one block per tile)
     if (nslots > 0) { k.amax_out = am->out; k.amax_outp = am->outp; k.amax_out_n = nslots; }
     if (nslots > 0 && am->out && am->next_s && am->next_t && !arb) {
       k.amax_ps = am->next_s; k.amax_pt = am->next_t; k.amax_pbstride = am->next_bstride;
@@ -1651,8 +1662,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       if (rc) return rc;
     }
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
-    rc = p2l_h2_launch(kh, d->pro, 9, bn, small, st);
-    if (prof_slot >= 0) { g_prof.nprod[prof_slot] = 3; g_prof.fam[prof_slot] = P2L_PROF_FAM_DIRECT_H2; }
+    const bool h2r = direct_h2r(d) && k.splitk == 1 && !k.partial && TB == 1;
+    rc = h2r ? p2l_h2r_launch(kh, d->pro, st) : p2l_h2_launch(kh, d->pro, 9, bn, small, st);
+    if (prof_slot >= 0) { g_prof.nprod[prof_slot] = 3; g_prof.fam[prof_slot] = h2r ? P2L_PROF_FAM_DIRECT_H2R : P2L_PROF_FAM_DIRECT_H2; }
   } else
   if (d->taps == 9) {
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;

@@ -392,12 +392,19 @@ __device__ __forceinline__ void epi_arb_reduce(const ConvK& k, EpiSums& S, float
 //   v = alpha*acc + bias + residual ; act ; mask ; store ; 2x2 max/sum pool, or
 //   ARB (input-gradient convs): g = (x*s+t>0) ? da : 0 ; dx = g*s + shortcut ;
 //   partial sums of g*x and g per (tile, channel)  [da 2x2-summed first if pool==SUM].
+// The second half of epilogue_vec: the dumps [4 pixel groups of 32][COLS + 4] are in `smem` and visible; wave w
+// works through pixel group w.  (Separate so that a kernel with another wave -> accumulator mapping --
+// p2l_h2r.hip: a wave owns 64 pixels x 32 channels -- can fill the same dumps and share everything behind.)
+template <int NT>
+__device__ __forceinline__ void epilogue_vec_items(const ConvK& k, float* smem, int wave, int lane, int b0,
+                                                   int y0, int x0, int n0, int tile_in_image, int osh,
+                                                   int ph_y, int ph_x);
 template <int NT>
 __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)[NT],
                                              float* smem, int wave, int lane, int b0, int y0,
                                              int x0, int n0, int tile_in_image, int osh,
                                              int ph_y, int ph_x) {
-  constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
+  constexpr int COLS = NT * 32, EP = COLS + 4;
   const int l31 = lane & 31, lhi = lane >> 5;
   float* tb = smem + wave * 32 * EP;
 #pragma unroll
@@ -406,6 +413,14 @@ __device__ __forceinline__ void epilogue_vec(const ConvK& k, const f32x16 (&acc)
     for (int r = 0; r < 16; ++r)
       tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP + j * 32 + l31] = acc[j][r];
   __syncthreads();
+  epilogue_vec_items<NT>(k, smem, wave, lane, b0, y0, x0, n0, tile_in_image, osh, ph_y, ph_x);
+}
+template <int NT>
+__device__ __forceinline__ void epilogue_vec_items(const ConvK& k, float* smem, int wave, int lane, int b0,
+                                                   int y0, int x0, int n0, int tile_in_image, int osh,
+                                                   int ph_y, int ph_x) {
+  constexpr int COLS = NT * 32, EP = COLS + 4, C4 = COLS / 4, ITEMS = 8 * C4;
+  float* tb = smem + wave * 32 * EP;
 
   const int TWh = (1 << k.tw_log) >> 1, THh = (1 << k.th_log) >> 1;
   EpiSums S, S2;                           // S2: the second quad of a lane (64-channel tiles), see epi_arb_reduce
@@ -480,3 +495,8 @@ size_t p2l_h2_weight_floats(int N_pad, int K_pad, int subpix);
 int p2l_h2_pack(const float* w_oihw, int O, int I, int N_pad, int K_pad, int flip, int mode, float* dst,
                 hipStream_t st);
 int p2l_h2_launch(const p2lconv::ConvK& k, int pro, int taps, int bn, bool small, hipStream_t st);
+
+// ... with the weights of a 64 -> 64 channel layer RESIDENT IN REGISTERS (p2l_h2r.hip): persistent blocks,
+// one per CU, that walk over 128-pixel tiles; bit-identical to conv_h2_kernel<9, ..>
+bool p2l_h2r_shape(int taps, int ups, int H, int W, int Cin, int Cout, int x_ld);
+int p2l_h2r_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

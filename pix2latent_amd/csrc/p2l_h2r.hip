@@ -1,0 +1,351 @@
+// Direct 3x3 convolution, 64 -> 64 channels, fp16 x 2 arithmetic, WEIGHTS RESIDENT IN REGISTERS (round 6).
+//
+// The 64-channel 3x3 layers of the path -- VGG conv1_2 and the last BigGAN GenBlock at 256^2, their input
+// gradients, the 128^2 64 -> 64 layers, VGG at 512^2 / 1024^2 behind StyleGAN2 (reached from
+// pix2latent/loss_functions.py:142 and pix2latent/model/biggan.py:58 in the reference) -- ran in
+// conv_h2_kernel<9, ..> (p2l_h2.hip) at ~3 x both of their floors: with K = 576 a block of
+// that kernel is four 16-channel chunks, each with its own 36 KB weight tile through LDS (147 KB of weights per
+// 32 KB of output), three barriers and one LDS fragment read per MFMA group.
+//
+// Here the whole layer's weights never leave the register file.  One 4-wave block per CU (one wave per SIMD,
+// 512 registers each) is PERSISTENT: it loads its B fragments once -- wave (mh, nt) keeps the 36 (chunk, tap)
+// fragments x 2 fp16 pieces of output channels nt*32 .. nt*32+31: 288 VGPRs -- and then walks over a contiguous
+// range of 8x16-pixel tiles:
+//   * the tile's 10x18-pixel patch is staged ONCE for all 64 channels (16 lanes = one pixel's 256 bytes: fully
+//     coalesced; the chunked kernel fetched every line in four 64-byte passes), split into the two fp16 pieces
+//     and written to the other half of a double-buffered LDS patch while the current tile is multiplied;
+//   * a wave multiplies 64 pixels x 32 channels: per (chunk, tap) 4 ds_read_b128 of activations feed 6 MFMAs
+//     (the chunked kernel: 6 reads, 2 of them weights), no weight DMA, no barrier inside a tile;
+//   * the accumulators are dumped in the layout of epilogue_vec and everything behind the dump is SHARED with
+//     the other conv kernels (p2l_conv_k.h epilogue_vec_items: bias / residual / activation / mask / pool /
+//     fused activation backward with its partial sums / partial maxima).
+// The per-output summation order is the chunked kernel's -- chunk, tap, (m h, h m, h h) -- on the same operand
+// pieces, so the results are BIT-IDENTICAL to conv_h2_kernel<9, 64 | 32, ..> (tests/test_kernels_gpu.py
+// test_register_resident_64ch_kernel_bit_identical); which of the two runs is a function of the layer shape only.
+#include "p2l_conv_k.h"
+
+#include <atomic>
+#include <type_traits>
+
+using namespace p2lconv;
+
+namespace {
+
+// (A/B builds, tools/ab_build.sh p2l_h2r -DP2L_H2R_ABL=n -mllvm -pragma-unroll-threshold=400000: timing ablations,
+//  results are wrong when set: 1 no staging of the next tile (loads, split, LDS writes), 2 no MFMAs, 4 no
+//  epilogue items (loads / stores behind the dump), 8 no accumulator dump, 16 no fragment reads)
+#ifndef P2L_H2R_ABL
+#define P2L_H2R_ABL 0
+#endif
+
+__device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3) ^ (((row >> 1) & 1) << 1); }
+
+constexpr int HP = 24, HH = 10, HW = 18;              // patch: 10 lines of 18 pixels, 24 LDS rows per line
+constexpr int ROWS = HH * HP;                          // 240 rows of 64 B per 16-channel plane
+constexpr int PLANE = ROWS * 64;                       // 15 360 B
+constexpr int BUF = 4 * PLANE;                         // one patch, 64 channels: 61 440 B
+constexpr int EP = 68;                                 // dump row pitch (epilogue_vec<2>: COLS + 4)
+constexpr int DUMP_FLOATS = 4 * 32 * EP;
+constexpr size_t LDS_BYTES = 2 * (size_t)BUF + (DUMP_FLOATS + 32) * sizeof(float);
+
+template <int PRO>
+__global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = reinterpret_cast<char*>(smem);
+  float* dump = smem + 2 * BUF / 4;
+  float* red = dump + DUMP_FLOATS;                     // 32 floats: block reductions of the scales
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int mh = wave >> 1, nt = wave & 1;
+
+  // ---- weights: the fp16 x 2 image [chunk][32-channel tile][tap][32 rows][64 B] (p2l_h2.hip h2_pack_kernel),
+  //      this wave's 36 fragments of both pieces, once
+  h16x8 bh[36], bm[36];
+  {
+    const char* wb = reinterpret_cast<const char*>(k.w) + l31 * 64;
+    const int oh = h2c(lhi, l31) * 16, om = h2c(2 + lhi, l31) * 16;
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      const int c = s / 9, tap = s - c * 9;
+      const char* slab = wb + (size_t)(((c * 2 + nt) * 9 + tap) * 32) * 64;
+      bh[s] = *reinterpret_cast<const h16x8*>(slab + oh);
+      bm[s] = *reinterpret_cast<const h16x8*>(slab + om);
+    }
+  }
+
+  // ---- my tiles: a contiguous range; the blocks of one XCD (dispatch order: block b -> XCD b % 8) take
+  //      neighbouring ranges, so that the halos two tiles share are met in one L2
+  const int G = gridDim.x;
+  const int v = xcd_remap(blockIdx.x, G);
+  const int t_begin = (int)(((long)v * n_tiles) / G), t_end = (int)(((long)(v + 1) * n_tiles) / G);
+  const int tiles_per_image = k.tiles_x * k.tiles_y;
+
+  // ---- staging descriptors (the same for every tile).  Items 0 .. 9: patch line `it`, pixel hx = tid >> 4
+  //      (0 .. 15) of it, channel quad cq = tid & 15 (16 lanes = one pixel's 256 bytes, 256 threads = 4 KB of one
+  //      image row); items 10, 11: the two right-hand halo pixels (hx = 16, 17) of every line.  LDS: plane
+  //      cq >> 2, row = line * 24 + hx of 64 bytes [h k0-7 | h k8-15 | m k0-7 | m k8-15], the 16-byte chunk
+  //      swizzled by the row (h2c).  24 lines apart the swizzle toggles bit 1 of the chunk: offset ^ 32, which is
+  //      also where the m piece of a value sits -- odd lines swap the two pieces' places.
+  const int cq = tid & 15, p0 = tid >> 4;
+  const int goff0 = (-k.W + (p0 - 1)) * k.x_ld + cq * 4;                 // line 0 (image row y0 - 1)
+  const int loff0 = (cq >> 2) * PLANE + p0 * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, p0) * 16;
+  int e_line[2], e_hx[2], e_goff[2], e_loff[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 256 * e;
+    e_line[e] = idx < 320 ? (idx >> 5) : -1;
+    e_hx[e] = 16 + ((idx >> 4) & 1);
+    const int row = (idx >> 5) * HP + e_hx[e];
+    e_goff[e] = (((idx >> 5) - 1) * k.W + (e_hx[e] - 1)) * k.x_ld + cq * 4;
+    e_loff[e] = (cq >> 2) * PLANE + row * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, row) * 16;
+  }
+  const int line_step = k.W * k.x_ld;
+
+  // ---- fragment addressing: wave (mh, nt), pixel sub-tile ms: MFMA row l31 = pixel (mh*2+ms)*32 + l31 of the
+  //      tile in 2x2-quad order (epilogue_vec's order).  Tap (dy, dx): row + 24 dy + dx -- per dx one offset,
+  //      dy adds 1536 bytes and (odd dy) swaps the pieces as above
+  int aoff[2][3];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    const int i = (mh * 2 + ms) * 32 + l31;
+    const int Q = i >> 2, s = i & 3;
+    const int row0 = (2 * ((Q >> 3) & 3) + (s >> 1)) * HP + 2 * (Q & 7) + (s & 1);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) aoff[ms][dx] = (row0 + dx) * 64 + h2c(lhi, row0 + dx) * 16;
+  }
+
+  float sw, inv_w;
+  h2_scales(__builtin_amdgcn_readfirstlane(k.w_tail[0]), sw, inv_w);
+
+  // scales of image b: x scale (power of two from max |x| of the image -- the maxima the producer of the tensor
+  // handed over, or the 64 partials of the pass in front of the launch) and the exact un-scale of the products
+  auto image_scales = [&](int b, float& xs, float& os) {
+    float a = 0.f, ms_ = 0.f, mt_ = 0.f;
+    if (k.amax_in != nullptr) {
+      for (int i = tid; i < k.amax_in_n; i += 256) a = fmaxf(a, k.amax_in[(size_t)b * k.amax_in_n + i]);
+      if (PRO != P2L_PRO_NONE && !k.amax_in_applied) {
+        const f32x4* ps = reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride);
+        const f32x4* pt = reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride);
+        for (int c = tid; c < (k.Cin >> 2); c += 256) {
+          const f32x4 s4 = ps[c], t4 = pt[c];
+          ms_ = fmaxf(fmaxf(ms_, fmaxf(fabsf(s4.x), fabsf(s4.y))), fmaxf(fabsf(s4.z), fabsf(s4.w)));
+          mt_ = fmaxf(fmaxf(mt_, fmaxf(fabsf(t4.x), fabsf(t4.y))), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+        }
+      }
+    } else if (tid < 64) {
+      a = k.amax[b * 64 + tid];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      a = fmaxf(a, __shfl_xor(a, o, 64));
+      if (PRO != P2L_PRO_NONE) { ms_ = fmaxf(ms_, __shfl_xor(ms_, o, 64)); mt_ = fmaxf(mt_, __shfl_xor(mt_, o, 64)); }
+    }
+    __syncthreads();                                   // (the scratch of the previous call has been read)
+    if (lane == 0) { red[wave * 4] = a; red[wave * 4 + 1] = ms_; red[wave * 4 + 2] = mt_; }
+    __syncthreads();
+    a = fmaxf(fmaxf(red[0], red[4]), fmaxf(red[8], red[12]));
+    ms_ = fmaxf(fmaxf(red[1], red[5]), fmaxf(red[9], red[13]));
+    mt_ = fmaxf(fmaxf(red[2], red[6]), fmaxf(red[10], red[14]));
+    if (PRO != P2L_PRO_NONE && k.amax_in != nullptr) a = (k.amax_in_applied ? a : ms_ * a + mt_) * 1.001f;
+    float inv_x;
+    h2_scales(__builtin_bit_cast(unsigned, a), xs, inv_x);
+    os = inv_x * inv_w;
+  };
+
+  // ---- staging of tile t into patch buffer `buf` in two halves (lines 0-5 | lines 6-9 + the edge items):
+  //      issue<half>() starts the loads, land(it) converts and writes one item
+  f32x4 xr[6];
+  f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};    // this thread's channel quad of the fused prologue
+  float st_xs = 1.f;
+  char* st_dst = As;
+  const float* st_base = k.x;
+  bool st_top = false, st_bot = false, st_left = false, st_right = false;
+  auto tile_geom = [&](int t, int& b, int& y0, int& x0, int& til) {
+    b = t / tiles_per_image;
+    til = t - b * tiles_per_image;
+    const int ty = til / k.tiles_x;
+    y0 = ty << 3; x0 = (til - ty * k.tiles_x) << 4;
+  };
+  // does item `it` of the staged tile exist in the image (else: zero padding)
+  auto item_ok = [&](int it) -> bool {
+    if (it < 10) return !((st_top && it == 0) || (st_bot && it == 9) || (st_left && p0 == 0));
+    const int e = it - 10;
+    return e_line[e] >= 0 && !((st_top && e_line[e] == 0) || (st_bot && e_line[e] == 9) || (st_right && e_hx[e] == 17));
+  };
+  auto begin_tile = [&](int t, int buf, float xs) {
+    int b, y0, x0, til;
+    tile_geom(t, b, y0, x0, til);
+    st_top = (y0 == 0); st_bot = (y0 + 8 == k.H); st_left = (x0 == 0); st_right = (x0 + 16 == k.W);
+    st_xs = xs;
+    st_dst = As + buf * BUF;
+    st_base = k.x + (size_t)((b * k.H + y0) * k.W + x0) * k.x_ld;
+    if (PRO != P2L_PRO_NONE) {
+      s4 = *reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride + cq * 4);
+      t4 = *reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride + cq * 4);
+    }
+  };
+  auto issue = [&](auto half_c) {                       // (unconditional loads from an always valid address)
+    constexpr int half = decltype(half_c)::value;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int it = half * 6 + j;
+      const int go = it < 10 ? goff0 + it * line_step : e_goff[it - 10];
+      xr[j] = *reinterpret_cast<const f32x4*>(st_base + (item_ok(it) ? go : cq * 4));
+    }
+  };
+  auto land = [&](int it) {
+    if (it >= 10 && e_line[it - 10] < 0) return;
+    f32x4 v4 = xr[it % 6];
+    if (PRO != P2L_PRO_NONE) {
+      v4 = v4 * s4 + t4;
+      if (PRO == P2L_PRO_AFFINE_RELU) {
+        v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f);
+      }
+    }
+    if (!item_ok(it)) v4 = f32x4{0.f, 0.f, 0.f, 0.f};               // zero padding (after the prologue)
+    v4 = v4 * st_xs;
+    const h16x4 h = __builtin_convertvector(v4, h16x4);
+    const f32x4 w = __builtin_convertvector(h, f32x4);
+    const h16x4 m = __builtin_convertvector(v4 - w, h16x4);
+    const int lo = it < 10 ? ((loff0 + it * (HP * 64)) ^ ((it & 1) ? 32 : 0)) : e_loff[it - 10];
+    *reinterpret_cast<h16x4*>(st_dst + lo) = h;
+    *reinterpret_cast<h16x4*>(st_dst + (lo ^ 32)) = m;
+  };
+  using Half0 = std::integral_constant<int, 0>;
+  using Half1 = std::integral_constant<int, 1>;
+
+  if (t_begin >= t_end) return;
+
+  // ---- first tile ----
+  int b_cur, y0, x0, til;
+  tile_geom(t_begin, b_cur, y0, x0, til);
+  float xs_cur, os_cur;
+  image_scales(b_cur, xs_cur, os_cur);
+  begin_tile(t_begin, 0, xs_cur);
+  issue(Half0{});
+#pragma unroll
+  for (int it = 0; it < 6; ++it) land(it);
+  issue(Half1{});
+#pragma unroll
+  for (int it = 6; it < 12; ++it) land(it);
+  __syncthreads();
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    tile_geom(t, b_cur, y0, x0, til);
+    // the NEXT tile (the last iteration re-stages its own tile: no branch in the stream below); its image may
+    // be another one, with another scale
+    const int tn = (t + 1 < t_end) ? t + 1 : t;
+    const int b_next = tn / tiles_per_image;
+    float xs_next = xs_cur, os_next = os_cur;
+    if (b_next != b_cur) image_scales(b_next, xs_next, os_next);
+    begin_tile(tn, cur ^ 1, xs_next);
+    if (!(P2L_H2R_ABL & 1)) issue(Half0{});
+
+    const char* Ab = As + cur * BUF;
+    f32x16 acc[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][r] = 0.f;
+
+    h16x8 af[2][2][2];                                  // [double buffer][ms][h | m]
+    auto lda = [&](int s, h16x8 (&a)[2][2]) {
+      const int c = s / 9, tap = s - c * 9;
+      const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        // (the m piece: 16-byte chunk index ^ 2 = offset ^ 32; an odd dy swaps the pieces' places)
+        const int oh = aoff[ms][dx] ^ ((dy & 1) ? 32 : 0);
+        a[ms][0] = *reinterpret_cast<const h16x8*>(Ab + c * PLANE + dy * (HP * 64) + oh);
+        a[ms][1] = *reinterpret_cast<const h16x8*>(Ab + c * PLANE + dy * (HP * 64) + (oh ^ 32));
+      }
+    };
+    lda(0, af[0]);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      if (s + 1 < 36 && !(P2L_H2R_ABL & 16)) lda(s + 1, af[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const h16x8 (&a)[2][2] = af[s & 1];
+      // per accumulator: m h, h m, h h (smallest terms first) -- the order of conv_h2_kernel; the two
+      // accumulators alternate so that no MFMA waits for the one in front of it
+      if (!(P2L_H2R_ABL & 2)) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], bh[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], bh[s], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], bm[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], bm[s], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][0], bh[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][0], bh[s], acc[1], 0, 0, 0);
+      } else { acc[0][s & 15] += (float)a[0][0][0] * (float)bh[s][0] + (float)a[1][1][1] * (float)bm[s][1]; }
+      // the next tile's patch lands under the stream: lines 0-5 (requested in front of it) at steps 10 .. 15, the
+      // second half is requested behind them and lands at steps 28 .. 33
+      if (!(P2L_H2R_ABL & 1)) {
+        if (s >= 10 && s < 16) land(s - 10);
+        if (s == 15) issue(Half1{});
+        if (s >= 28 && s < 34) land(s - 28 + 6);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- un-scale (exact: a power of two), dump in epilogue_vec's layout: pixel group mh*2+ms, columns nt*32.. ----
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ms][r] *= os_cur;
+    __syncthreads();                                    // the items of the previous tile have been read
+    if (!(P2L_H2R_ABL & 8) || acc[0][0] == 12345.678f)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      float* tb = dump + (mh * 2 + ms) * 32 * EP + nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP] = acc[ms][r];
+    }
+    __syncthreads();                                    // dumps visible; the next patch is complete
+    if (!(P2L_H2R_ABL & 4) || acc[0][0] == 12345.678f)
+    epilogue_vec_items<2>(k, dump, wave, lane, b_cur, y0, x0, 0, til, 0, 0, 0);
+    xs_cur = xs_next; os_cur = os_next;
+  }
+}
+
+}  // namespace
+
+// which launches: plain stride-1 3x3, 64 -> 64 channels, whole 8x16-pixel tiles of one image
+bool p2l_h2r_shape(int taps, int ups, int H, int W, int Cin, int Cout, int x_ld) {
+#ifdef P2L_AB_NO_H2R               // (A/B builds: the chunked kernel for these layers)
+  return false;
+#endif
+  return taps == 9 && ups == 0 && Cin == 64 && Cout == 64 && H % 8 == 0 && W % 16 == 0 && x_ld % 4 == 0;
+}
+
+// k: the ConvK of the direct fp16 x 2 launch (k.w = the fp16 x 2 direct image, k.w_tail, k.amax | k.amax_in).
+int p2l_h2r_launch(const ConvK& k_in, int pro, hipStream_t st) {
+  ConvK k = k_in;
+  k.n_ntiles = 1;                                       // a block writes all 64 channels (maxima slots, sums)
+  const int n_tiles = k.B * k.tiles_x * k.tiles_y;
+  static std::atomic<int> n_cu{0};
+  if (n_cu == 0) {
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    n_cu = cus;
+  }
+  const int grid = n_tiles < n_cu ? n_tiles : (int)n_cu;
+#define P2L_H2RL(PROV)                                                                        \
+  do {                                                                                        \
+    auto kfn = conv_h2r_kernel<PROV>;                                                         \
+    static std::atomic<bool> attr_set{false};                                                 \
+    if (!attr_set) {                                                                          \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                  \
+      attr_set = true;                                                                        \
+    }                                                                                         \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), LDS_BYTES, st, k, n_tiles);                \
+  } while (0)
+  if (pro == P2L_PRO_NONE) P2L_H2RL(P2L_PRO_NONE);
+  else if (pro == P2L_PRO_AFFINE_RELU) P2L_H2RL(P2L_PRO_AFFINE_RELU);
+  else P2L_H2RL(P2L_PRO_AFFINE);
+#undef P2L_H2RL
+  return p2l_check_launch();
+}

@@ -1232,6 +1232,111 @@ def test_direct_kernel_fp16x2(dev, O, case):
     assert torch.equal(y1[0], ya[1]), 'result depends on the batch composition'
 
 
+# (the last two have more tiles than CUs: persistent blocks walk over 4-5 tiles each, ranges straddle images)
+H2R_CASES = [(3, 32, 32), (2, 24, 48), (5, 16, 16), (9, 128, 128), (2, 256, 256)]
+
+
+@pytest.mark.parametrize('mode', ['plain', 'pro-relu-maxima', 'pool-max-res', 'mask', 'own-amax-pass',
+                                  'dgrad-fused-arb', 'dgrad-fused-arb-skip-pool-sum'])
+@pytest.mark.parametrize('case', H2R_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_register_resident_64ch_kernel_bit_identical(dev, O, case, mode):
+    """conv_h2r_kernel (csrc/p2l_h2r.hip, round 6): the 64 -> 64 channel 3x3 layers with their weights resident
+    in registers, persistent blocks walking over tiles.  Same operand pieces, same per-output summation order as
+    the chunked direct kernel (P2L_FORM_NO_H2R keeps that one): outputs, pooled outputs, handed-over maxima and
+    the partial sums of the fused activation backward are EQUAL bit for bit, for images of very different
+    magnitude in one launch, tiles on every border, blocks that change image mid-range, non-power-of-two grids;
+    and the result agrees with torch in fp64 at the tolerance of the fp32-grade kernels."""
+    from pix2latent_amd import _native as N
+    B, H, W = case
+    Cin = Cout = 64
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0] *= 1e-5
+    if B > 2:
+        x[2] *= 3e3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = 0.1 * torch.randn(Cout, generator=g)
+    s = 0.5 + torch.rand(B, Cin, generator=g)
+    t = 0.3 * torch.randn(B, Cin, generator=g) * x.abs().amax(dim=(1, 2, 3)).view(B, 1)
+    xs = nhwc(x, dev)
+    forms = (N.FORM_NO_WINO, N.FORM_NO_WINO | N.FORM_NO_H2R)
+    fam_new, fam_old = 6, 2                  # P2L_PROF_FAM_DIRECT_H2R / _DIRECT_H2
+
+    def family(fn):
+        N.check(N.lib().p2l_prof_begin(64), 'p2l_prof_begin')
+        out = fn()
+        torch.cuda.synchronize()
+        T = N.prof_totals()
+        return out, [i for i in range(8) if T.fam_count[i]]
+
+    if mode.startswith('dgrad'):
+        wt = O.pack_conv_weight(w.to(dev), 9, Cin, Cout, flip=True, wfmt=2)
+        dy = nhwc(torch.randn(B, Cout, H, W, generator=g), dev)
+        skip = pool = None
+        Hx, Wx = H, W
+        if 'pool-sum' in mode:
+            Hx, Wx, pool = H // 2, W // 2, True
+        xa = nhwc(torch.randn(B, Cin, Hx, Wx, generator=g), dev)
+        kw = dict(wfmt=2)
+        if 'skip' in mode:
+            kw.update(skip=nhwc(torch.randn(B, 32, Hx, Wx, generator=g), dev), skip_C=32)
+        res = []
+        for form, fam in zip(forms, (fam_new, fam_old)):
+            out, fams = family(lambda: O.conv_dgrad_arb(dy, wt, B, H, W, Cout, Cin, 9, xa, s.to(dev), t.to(dev), Cin,
+                                                        pool_sum=bool(pool), form=form, **kw))
+            assert fams == [fam], (fams, fam)
+            res.append(out)
+        for a, b_, what in zip(res[0], res[1], ('dx', 'ds', 'dt')):
+            assert torch.equal(a, b_), what
+        return
+    kw = dict(wfmt=2, bias=bias.to(dev))
+    a = x.double()
+    ref_act = None
+    if mode == 'plain':
+        kw['amax_in'] = xs.abs().reshape(B, -1, 64).amax(dim=2).contiguous()
+    if mode == 'pro-relu-maxima':
+        a = F.relu(a * s.double().view(B, Cin, 1, 1) + t.double().view(B, Cin, 1, 1))
+        # maxima of |x| handed in (as the producer of x would leave them: here per 64-element pieces) and out
+        am_in = xs.abs().reshape(B, -1, 64).amax(dim=2).contiguous()
+        kw.update(pro=N.PRO_AFFINE_RELU, pro_s=s.to(dev), pro_t=t.to(dev), pro_bstride=Cin, amax_in=am_in,
+                  want_amax=True, act=N.ACT_RELU, amax_next=(s.to(dev), t.to(dev), Cin))
+        ref_act = 'relu'
+    elif mode == 'pool-max-res':
+        kw.update(pool=N.POOL_MAX, res=nhwc(torch.randn(B, Cout, H, W, generator=g), dev), act=N.ACT_RELU,
+                  want_amax=True)
+    elif mode == 'mask':
+        kw.update(mask=nhwc(torch.randn(B, Cout, H, W, generator=g), dev), alpha=0.5)
+    wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
+    outs = []
+    for form, fam in zip(forms, (fam_new, fam_old)):
+        out, fams = family(lambda: O.conv(xs, wp, B, H, W, Cin, Cout, 9, form=form, **kw))
+        assert fams == [fam], (fams, fam)
+        outs.append(out)
+    y_new, y_old = outs[0][0], outs[1][0]
+    assert torch.equal(y_new, y_old), 'outputs differ: %g' % (y_new - y_old).abs().max().item()
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1]), 'pooled outputs differ'
+    if kw.get('want_amax'):
+        # the two kernels tile the channels differently (64 per block | 32 or 64): the per-image maxima agree
+        for m_new, m_old in zip(outs[0][2], outs[1][2]):
+            if m_new is not None:
+                assert torch.equal(m_new.amax(dim=1), m_old.amax(dim=1))
+                assert (m_new >= 0).all(), 'a promised maxima slot was not written'
+    if mode in ('plain', 'pro-relu-maxima', 'own-amax-pass'):
+        ref = F.conv2d(a, w.double(), bias.double(), padding=1)
+        if ref_act:
+            ref = F.relu(ref)
+        got = nchw(y_new).double()
+        for b_ in range(B):
+            sc = ref[b_].abs().max().item()
+            assert (got[b_] - ref[b_]).abs().max().item() < 2e-5 * sc, b_
+    # a candidate's bits do not depend on who shares its launch, nor on which block's range it falls into
+    if mode == 'plain' and B > 1:
+        kw['amax_in'] = kw['amax_in'][1:2].contiguous()
+        y1, _ = O.conv(xs[1:2].contiguous(), wp, 1, H, W, Cin, Cout, 9, form=forms[0], **kw)
+        assert torch.equal(y1[0], y_new[1])
+
+
 def test_direct_kernel_fp16x2_subpixel_and_maxima(dev, O):
     """the sub-pixel forms (nearest-x2 up-conv forward, its input gradient) in the fp16 x 2 arithmetic,
     and the maxima a split-K launch now leaves through its finish kernel (P2LAmax): exact per-image

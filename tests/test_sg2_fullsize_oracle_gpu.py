@@ -138,7 +138,7 @@ def test_c4_cars_512_replayed_gradients_vs_oracle(cars):
     sg2, vgg = _sg2_loss_tape(P, B, out, t_dev, with_mapping=True)
 
     def oracle(dt, replayed):
-        zr = z.to(dt).requires_grad_(True)
+        zr = z.detach().clone().to(dt).requires_grad_(True)
         nz = [n.to(dt) for n in P.noises(B)]
         if replayed:
             with R.replay(sg2):
