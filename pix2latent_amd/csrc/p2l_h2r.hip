@@ -33,7 +33,8 @@ namespace {
 
 // (A/B builds, tools/ab_build.sh p2l_h2r -DP2L_H2R_ABL=n -mllvm -pragma-unroll-threshold=400000: timing ablations,
 //  results are wrong when set: 1 no staging of the next tile (loads, split, LDS writes), 2 no MFMAs, 4 no
-//  epilogue items (loads / stores behind the dump), 8 no accumulator dump, 16 no fragment reads)
+//  epilogue items (loads / stores behind the dump), 8 no accumulator dump, 16 no fragment reads, 32 no pipelined
+//  epilogue pieces inside the stream)
 #ifndef P2L_H2R_ABL
 #define P2L_H2R_ABL 0
 #endif
@@ -42,18 +43,32 @@ __device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3)
 
 constexpr int HP = 24, HH = 10, HW = 18;              // patch: 10 lines of 18 pixels, 24 LDS rows per line
 constexpr int ROWS = HH * HP;                          // 240 rows of 64 B per 16-channel plane
-constexpr int PLANE = ROWS * 64;                       // 15 360 B
+// (+ 32: the four planes of a pixel -- written by the 16 lanes of one ds_write_b64 lane group -- start 8 banks
+//  apart; at a multiple of 128 bytes they met in the same banks: 28 % of the LDS cycles were conflicts)
+constexpr int PLANE = ROWS * 64 + 32;                  // 15 392 B
 constexpr int BUF = 4 * PLANE;                         // one patch, 64 channels: 61 440 B
 constexpr int EP = 68;                                 // dump row pitch (epilogue_vec<2>: COLS + 4)
 constexpr int DUMP_FLOATS = 4 * 32 * EP;
-constexpr size_t LDS_BYTES = 2 * (size_t)BUF + (DUMP_FLOATS + 32) * sizeof(float);
+constexpr int ETAB_FLOATS = 4 * 16 * 12;               // per wave, per channel quad: bias4 | next_s4 | next_t4
+constexpr int PTAB_FLOATS = 16 * 8;                    // per channel quad: pro_s4 | pro_t4 of the staged image
+constexpr size_t LDS_BYTES = 2 * (size_t)BUF + (DUMP_FLOATS + 32 + ETAB_FLOATS + PTAB_FLOATS) * sizeof(float);
 
-template <int PRO>
+// EPI: 0 = the shared epilogue item behind the dump (every mode: residual, StyleGAN2 terms, fused activation
+// backward ...), run between two tiles; 1 / 2 / 3 = the forward-style epilogue  y = act(acc + bias) [mask] ->
+// store [-> 2x2 max pool -> store] + partial maxima  (1 plain, 2 with a mask, 3 with the pool) of tile i written
+// out UNDER the multiply stream of tile i + 1: a lone wave per SIMD cannot hide its own stores behind another
+// wave, and the 32 KB a tile stores are issue-bound (~2.3 k cycles per CU) -- measured sequentially the
+// epilogue cost as much as the 216 MFMAs (profiles/round6_h2r_ablation.txt).  Same operations in the same
+// order as epi_item: the bits do not change.
+template <int PRO, int EPI>
 __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const int n_tiles) {
+  constexpr bool FAST = EPI != 0, MASK = EPI == 2, POOL = EPI == 3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* As = reinterpret_cast<char*>(smem);
   float* dump = smem + 2 * BUF / 4;
   float* red = dump + DUMP_FLOATS;                     // 32 floats: block reductions of the scales
+  float* etab = red + 32;                              // per-wave constants of the pipelined epilogue
+  float* ptab = etab + ETAB_FLOATS;                    // the fused prologue's affine of the image being staged
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -90,7 +105,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
   //      also where the m piece of a value sits -- odd lines swap the two pieces' places.
   const int cq = tid & 15, p0 = tid >> 4;
   const int goff0 = (-k.W + (p0 - 1)) * k.x_ld + cq * 4;                 // line 0 (image row y0 - 1)
-  const int loff0 = (cq >> 2) * PLANE + p0 * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, p0) * 16;
+  const int lplane = (cq >> 2) * PLANE;                 // (added AFTER the ^ 32: a plane offset has bit 5 set)
+  const int loff0 = p0 * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, p0) * 16;
   int e_line[2], e_hx[2], e_goff[2], e_loff[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
     e_hx[e] = 16 + ((idx >> 4) & 1);
     const int row = (idx >> 5) * HP + e_hx[e];
     e_goff[e] = (((idx >> 5) - 1) * k.W + (e_hx[e] - 1)) * k.x_ld + cq * 4;
-    e_loff[e] = (cq >> 2) * PLANE + row * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, row) * 16;
+    e_loff[e] = row * 64 + (cq & 1) * 8 + h2c((cq >> 1) & 1, row) * 16;
   }
   const int line_step = k.W * k.x_ld;
 
@@ -144,6 +160,10 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
     }
     __syncthreads();                                   // (the scratch of the previous call has been read)
     if (lane == 0) { red[wave * 4] = a; red[wave * 4 + 1] = ms_; red[wave * 4 + 2] = mt_; }
+    if (PRO != P2L_PRO_NONE && tid < 16) {             // (the tiles staged from here on belong to image b)
+      *reinterpret_cast<f32x4*>(ptab + tid * 8) = *reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride + tid * 4);
+      *reinterpret_cast<f32x4*>(ptab + tid * 8 + 4) = *reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride + tid * 4);
+    }
     __syncthreads();
     a = fmaxf(fmaxf(red[0], red[4]), fmaxf(red[8], red[12]));
     ms_ = fmaxf(fmaxf(red[1], red[5]), fmaxf(red[9], red[13]));
@@ -157,7 +177,6 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
   // ---- staging of tile t into patch buffer `buf` in two halves (lines 0-5 | lines 6-9 + the edge items):
   //      issue<half>() starts the loads, land(it) converts and writes one item
   f32x4 xr[6];
-  f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, t4 = {0.f, 0.f, 0.f, 0.f};    // this thread's channel quad of the fused prologue
   float st_xs = 1.f;
   char* st_dst = As;
   const float* st_base = k.x;
@@ -181,10 +200,6 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
     st_xs = xs;
     st_dst = As + buf * BUF;
     st_base = k.x + (size_t)((b * k.H + y0) * k.W + x0) * k.x_ld;
-    if (PRO != P2L_PRO_NONE) {
-      s4 = *reinterpret_cast<const f32x4*>(k.pro_s + (size_t)b * k.pro_bstride + cq * 4);
-      t4 = *reinterpret_cast<const f32x4*>(k.pro_t + (size_t)b * k.pro_bstride + cq * 4);
-    }
   };
   auto issue = [&](auto half_c) {                       // (unconditional loads from an always valid address)
     constexpr int half = decltype(half_c)::value;
@@ -199,22 +214,117 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
     if (it >= 10 && e_line[it - 10] < 0) return;
     f32x4 v4 = xr[it % 6];
     if (PRO != P2L_PRO_NONE) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(ptab + cq * 8), t4 = *reinterpret_cast<const f32x4*>(ptab + cq * 8 + 4);
       v4 = v4 * s4 + t4;
       if (PRO == P2L_PRO_AFFINE_RELU) {
         v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f);
       }
     }
-    if (!item_ok(it)) v4 = f32x4{0.f, 0.f, 0.f, 0.f};               // zero padding (after the prologue)
-    v4 = v4 * st_xs;
+    v4 = v4 * (item_ok(it) ? st_xs : 0.f);                          // (x 0: zero padding, after the prologue)
     const h16x4 h = __builtin_convertvector(v4, h16x4);
     const f32x4 w = __builtin_convertvector(h, f32x4);
     const h16x4 m = __builtin_convertvector(v4 - w, h16x4);
     const int lo = it < 10 ? ((loff0 + it * (HP * 64)) ^ ((it & 1) ? 32 : 0)) : e_loff[it - 10];
-    *reinterpret_cast<h16x4*>(st_dst + lo) = h;
-    *reinterpret_cast<h16x4*>(st_dst + (lo ^ 32)) = m;
+    *reinterpret_cast<h16x4*>(st_dst + lplane + lo) = h;
+    *reinterpret_cast<h16x4*>(st_dst + lplane + (lo ^ 32)) = m;
   };
   using Half0 = std::integral_constant<int, 0>;
   using Half1 = std::integral_constant<int, 1>;
+
+  // ---- the pipelined epilogue (FAST): a lane owns quads q = lane >> 4 and 4 + (lane >> 4) of its wave's 32-pixel
+  //      group and channels n = 4 (lane & 15) .. + 3 -- epilogue_vec_items' assignment --------------------------
+  const int e_c4 = lane & 15, e_n = e_c4 * 4;
+  // bias and the reader's affine (maxima) of a lane's four channels: constants per image, parked in LDS (one
+  // table per wave: written and read by the same wave, no barrier) -- 12 registers the stream cannot spare
+  float* my_etab = etab + (wave * 16 + e_c4) * 12;
+  f32x4 e_bias, e_ns, e_nt;
+  if (FAST && lane < 16) {
+    *reinterpret_cast<f32x4*>(my_etab) = k.bias ? ld4(k.bias, (unsigned)e_n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(my_etab + 4) = f32x4{1.f, 1.f, 1.f, 1.f};
+    *reinterpret_cast<f32x4*>(my_etab + 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int e_tab_b = -1;                                     // image whose next_s / next_t the table holds
+  const float e_lo = (k.act == P2L_ACT_RELU) ? 0.f : -__builtin_inff();     // act: max(t, lo)
+  int pb = 0, py0 = 0, px0 = 0, ptil = 0;                                      // the tile whose dump is in LDS
+  float e_amax = 0.f, e_amaxp = 0.f;
+  f32x4 ev, ep, em[4];                                 // (pixel in flight, running 2x2 max, the quad's mask)
+  unsigned e_pix0 = 0, e_ppix = 0;
+  auto epi_tile = [&](int b, int y0_, int x0_, int til_) {
+    pb = b; py0 = y0_; px0 = x0_; ptil = til_;
+    e_amax = 0.f; e_amaxp = 0.f;
+    if (k.amax_ps && b != e_tab_b) {
+      if (lane < 16) {
+        *reinterpret_cast<f32x4*>(my_etab + 4) = ld4(k.amax_ps, (unsigned)(b * k.amax_pbstride + e_n));
+        *reinterpret_cast<f32x4*>(my_etab + 8) = ld4(k.amax_pt, (unsigned)(b * k.amax_pbstride + e_n));
+      }
+      e_tab_b = b;
+    }
+  };
+  auto epi_addr = [&](int j) {
+    const int Q = wave * 8 + j * 4 + (lane >> 4);
+    const int oy0 = py0 + 2 * ((Q >> 3) & 3), ox0 = px0 + 2 * (Q & 7);
+    e_pix0 = (unsigned)((pb * k.H + oy0) * k.W + ox0);
+    e_ppix = (unsigned)((pb * (k.H >> 1) + (oy0 >> 1)) * (k.W >> 1) + (ox0 >> 1));
+  };
+  auto epi_mask = [&](int j) {                          // (requested a few steps ahead of its use)
+    epi_addr(j);
+    if (MASK) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        em[s] = ld4(k.mask, (e_pix0 + (unsigned)((s >> 1) * k.W + (s & 1))) * (unsigned)k.mask_ld + (unsigned)e_n);
+    }
+  };
+  auto epi_read = [&](int j, int s) {                   // (one step ahead of epi_px(s))
+    ev = *reinterpret_cast<const f32x4*>(dump + wave * 32 * EP + (4 * (j * 4 + (lane >> 4)) + s) * EP + e_c4 * 4);
+    if (s == 0) {
+      e_bias = *reinterpret_cast<const f32x4*>(my_etab);
+      e_ns = *reinterpret_cast<const f32x4*>(my_etab + 4);
+      e_nt = *reinterpret_cast<const f32x4*>(my_etab + 8);
+    }
+  };
+  auto epi_px = [&](int s) {
+    f32x4 t = ev + e_bias;
+    t.x = fmaxf(t.x, e_lo); t.y = fmaxf(t.y, e_lo); t.z = fmaxf(t.z, e_lo); t.w = fmaxf(t.w, e_lo);
+    if (MASK) {
+      t.x = em[s].x > 0.f ? t.x : 0.f; t.y = em[s].y > 0.f ? t.y : 0.f;
+      t.z = em[s].z > 0.f ? t.z : 0.f; t.w = em[s].w > 0.f ? t.w : 0.f;
+    }
+    st4(k.y, (e_pix0 + (unsigned)((s >> 1) * k.W + (s & 1))) * (unsigned)k.y_ld + (unsigned)e_n, t);
+    e_amax = absmax4(e_amax, t * e_ns + e_nt);
+    if (POOL) {                                         // (max is exact: any order of the four gives epi_item's bits)
+      if (s == 0) ep = t;
+      else { ep.x = fmaxf(ep.x, t.x); ep.y = fmaxf(ep.y, t.y); ep.z = fmaxf(ep.z, t.z); ep.w = fmaxf(ep.w, t.w); }
+    }
+  };
+  auto epi_pool = [&]() {
+    if (POOL) {
+      st4(k.yp, e_ppix * (unsigned)k.yp_ld + (unsigned)e_n, ep);
+      e_amaxp = absmax4(e_amaxp, ep);
+    }
+  };
+  auto epi_maxima = [&]() {                             // one partial per wave and tile (epilogue_vec_items' slots)
+    if (k.amax_out != nullptr || k.amax_outp != nullptr) {
+      float m = e_amax, mp = e_amaxp;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+      if (lane == 0) {
+        const size_t slot = (size_t)pb * k.amax_out_n + (size_t)ptil * 4 + wave;
+        if (k.amax_out != nullptr) k.amax_out[slot] = m;
+        if (k.amax_outp != nullptr) k.amax_outp[slot] = mp;
+      }
+    }
+  };
+  // where the pieces sit in the 36 steps of the stream (the patch of the next tile lands at 10-15 and 28-33)
+  auto epi_hook = [&](int s) {
+    if (s == 0) epi_mask(0);
+    if (s >= 5 && s < 9) epi_px(s - 5);                 // (consumes the pixel read one step earlier ...)
+    if (s >= 4 && s < 8) epi_read(0, s - 4);            // (... before the next one replaces it)
+    if (s == 9) epi_pool();
+    if (s == 16) epi_mask(1);
+    if (s >= 21 && s < 25) epi_px(s - 21);
+    if (s >= 20 && s < 24) epi_read(1, s - 20);
+    if (s == 25) epi_pool();
+  };
 
   if (t_begin >= t_end) return;
 
@@ -232,7 +342,8 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
   for (int it = 6; it < 12; ++it) land(it);
   __syncthreads();
 
-  for (int t = t_begin; t < t_end; ++t) {
+  auto run_tile = [&](int t, auto with_epi_c) {
+    constexpr bool WITH_EPI = decltype(with_epi_c)::value;       // (FAST: the previous tile's dump is written out)
     const int cur = (t - t_begin) & 1;
     tile_geom(t, b_cur, y0, x0, til);
     // the NEXT tile (the last iteration re-stages its own tile: no branch in the stream below); its image may
@@ -269,8 +380,10 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
       if (s + 1 < 36 && !(P2L_H2R_ABL & 16)) lda(s + 1, af[(s + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       const h16x8 (&a)[2][2] = af[s & 1];
-      // per accumulator: m h, h m, h h (smallest terms first) -- the order of conv_h2_kernel; the two
-      // accumulators alternate so that no MFMA waits for the one in front of it
+      // per accumulator: m h, h m, h h (smallest terms first) -- the order of conv_h2_kernel; the two accumulators
+      // alternate.  (Measured against one back-to-back chain per accumulator -- acc0 x 3, acc1 x 3 --: MFMA-busy
+      // 54 % vs 45 %, waves parked 15 % vs 27 %: the chain form needs both pieces of a sub-tile's fragment at
+      // once and waits for the LDS more often.)
       if (!(P2L_H2R_ABL & 2)) {
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][1], bh[s], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][1], bh[s], acc[1], 0, 0, 0);
@@ -286,8 +399,10 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
         if (s == 15) issue(Half1{});
         if (s >= 28 && s < 34) land(s - 28 + 6);
       }
+      if (WITH_EPI && !(P2L_H2R_ABL & 32)) epi_hook(s);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (WITH_EPI) epi_maxima();
 
     // ---- un-scale (exact: a power of two), dump in epilogue_vec's layout: pixel group mh*2+ms, columns nt*32.. ----
 #pragma unroll
@@ -303,9 +418,23 @@ __global__ __launch_bounds__(256, 1) void conv_h2r_kernel(const ConvK k, const i
       for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EP] = acc[ms][r];
     }
     __syncthreads();                                    // dumps visible; the next patch is complete
-    if (!(P2L_H2R_ABL & 4) || acc[0][0] == 12345.678f)
-    epilogue_vec_items<2>(k, dump, wave, lane, b_cur, y0, x0, 0, til, 0, 0, 0);
+    if (FAST) {
+      epi_tile(b_cur, y0, x0, til);
+    } else {
+      if (!(P2L_H2R_ABL & 4) || acc[0][0] == 12345.678f)
+      epilogue_vec_items<2>(k, dump, wave, lane, b_cur, y0, x0, 0, til, 0, 0, 0);
+    }
     xs_cur = xs_next; os_cur = os_next;
+  };
+  if (FAST) {
+    run_tile(t_begin, std::false_type{});
+    for (int t = t_begin + 1; t < t_end; ++t) run_tile(t, std::true_type{});
+    // the last tile's dump, with nothing to hide behind
+#pragma unroll
+    for (int s = 0; s < 36; ++s) epi_hook(s);
+    epi_maxima();
+  } else {
+    for (int t = t_begin; t < t_end; ++t) run_tile(t, std::false_type{});
   }
 }
 
@@ -332,9 +461,22 @@ int p2l_h2r_launch(const ConvK& k_in, int pro, hipStream_t st) {
     n_cu = cus;
   }
   const int grid = n_tiles < n_cu ? n_tiles : (int)n_cu;
+  // the pipelined forward-style epilogue where the launch asks for nothing else (the compiled-in order of
+  // operations is epi_item's: same bits), the shared item otherwise
+  int epi = 0;
+  if (!k.arb_x && !k.res && !k.oscale && !k.noise && k.alpha == 1.0f && k.y != nullptr && k.n_store == 64 &&
+      (k.act == P2L_ACT_NONE || k.act == P2L_ACT_RELU) && !(k.form & P2L_FORM_H2R_SEQ_EPI)) {
+    if (k.pool == P2L_POOL_NONE) epi = k.mask ? 2 : 1;
+    else if (k.pool == P2L_POOL_MAX && !k.mask && k.yp != nullptr) epi = 3;
+  }
 #define P2L_H2RL(PROV)                                                                        \
   do {                                                                                        \
-    auto kfn = conv_h2r_kernel<PROV>;                                                         \
+    if (epi == 1) P2L_H2RE(PROV, 1); else if (epi == 2) P2L_H2RE(PROV, 2);                    \
+    else if (epi == 3) P2L_H2RE(PROV, 3); else P2L_H2RE(PROV, 0);                             \
+  } while (0)
+#define P2L_H2RE(PROV, EPIV)                                                                  \
+  do {                                                                                        \
+    auto kfn = conv_h2r_kernel<PROV, EPIV>;                                                   \
     static std::atomic<bool> attr_set{false};                                                 \
     if (!attr_set) {                                                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -347,5 +489,6 @@ int p2l_h2r_launch(const ConvK& k_in, int pro, hipStream_t st) {
   else if (pro == P2L_PRO_AFFINE_RELU) P2L_H2RL(P2L_PRO_AFFINE_RELU);
   else P2L_H2RL(P2L_PRO_AFFINE);
 #undef P2L_H2RL
+#undef P2L_H2RE
   return p2l_check_launch();
 }
