@@ -339,8 +339,10 @@ enum {
    * (csrc/p2l_h2r.hip: persistent blocks, one per CU); the results are bit-identical to the chunked      *
    * direct kernel, which this bit keeps (tests, A/B)                                                     */
   P2L_FORM_NO_H2R = 256,
-  P2L_FORM_H2R_SEQ_EPI = 512    /* ... that kernel with the shared epilogue item between two tiles instead of the   *
-                                 * forward-style epilogue pipelined under the next tile's stream (tests, A/B)      */
+  P2L_FORM_H2R_SEQ_EPI = 512    /* ... that kernel with the shared epilogue item between two tiles: instead of the  *
+                                 * forward-style epilogue pipelined under the next tile's stream, and for the      *
+                                 * launches (fused activation backward, residual ...) that otherwise stay on the   *
+                                 * chunked kernel (tests, A/B)                                                     */
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

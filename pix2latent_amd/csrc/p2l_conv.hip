@@ -1383,7 +1383,9 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.arb_nblk = k.n_mtiles / d->B;
     k.arb_nomask = arb->nomask;
   }
-  const int bn = choose_bn(d, k.n_mtiles);
+  // (an h2r-shaped layer keeps 64-channel tiles in the chunked kernel too: its launches may take either kernel,
+  //  by their epilogue, and both must fill the same maxima slots)
+  const int bn = direct_h2r(d) ? 64 : choose_bn(d, k.n_mtiles);
   k.n_ntiles = d->Cout / bn;
   k.nchunks = d->Cin / kc;
   const bool wino_sliced = wino_shape(d) && d->splitk > 1 && wino_split(d) == d->splitk;
@@ -1662,7 +1664,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       if (rc) return rc;
     }
     const bool small = (a_rows * 4 <= 3 * 256) && TB == 1;
-    const bool h2r = direct_h2r(d) && k.splitk == 1 && !k.partial && TB == 1;
+    const bool h2r = direct_h2r(d) && k.splitk == 1 && !k.partial && TB == 1 && p2l_h2r_takes(kh);
     rc = h2r ? p2l_h2r_launch(kh, d->pro, st) : p2l_h2_launch(kh, d->pro, 9, bn, small, st);
     if (prof_slot >= 0) { g_prof.nprod[prof_slot] = 3; g_prof.fam[prof_slot] = h2r ? P2L_PROF_FAM_DIRECT_H2R : P2L_PROF_FAM_DIRECT_H2; }
   } else

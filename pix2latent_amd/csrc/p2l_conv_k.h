@@ -499,4 +499,5 @@ int p2l_h2_launch(const p2lconv::ConvK& k, int pro, int taps, int bn, bool small
 // ... with the weights of a 64 -> 64 channel layer RESIDENT IN REGISTERS (p2l_h2r.hip): persistent blocks,
 // one per CU, that walk over 128-pixel tiles; bit-identical to conv_h2_kernel<9, ..>
 bool p2l_h2r_shape(int taps, int ups, int H, int W, int Cin, int Cout, int x_ld);
+bool p2l_h2r_takes(const p2lconv::ConvK& k);
 int p2l_h2r_launch(const p2lconv::ConvK& k, int pro, hipStream_t st);

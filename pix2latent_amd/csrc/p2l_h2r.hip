@@ -448,6 +448,23 @@ bool p2l_h2r_shape(int taps, int ups, int H, int W, int Cin, int Cout, int x_ld)
   return taps == 9 && ups == 0 && Cin == 64 && Cout == 64 && H % 8 == 0 && W % 16 == 0 && x_ld % 4 == 0;
 }
 
+// which epilogue a launch gets: 1 / 2 / 3 = forward-style, pipelined under the next tile (plain | mask | 2x2 max
+// pool); 0 = the shared item between two tiles (everything else)
+static int h2r_epi(const ConvK& k) {
+  if (!k.arb_x && !k.res && !k.oscale && !k.noise && k.alpha == 1.0f && k.y != nullptr && k.n_store == 64 &&
+      (k.act == P2L_ACT_NONE || k.act == P2L_ACT_RELU) && !(k.form & P2L_FORM_H2R_SEQ_EPI)) {
+    if (k.pool == P2L_POOL_NONE) return k.mask ? 2 : 1;
+    if (k.pool == P2L_POOL_MAX && !k.mask && k.yp != nullptr) return 3;
+  }
+  return 0;
+}
+// Does this launch of an h2r-shaped layer run here?  With the pipelined epilogue, yes; with the shared item
+// between two tiles (fused activation backward, residual, StyleGAN2 terms) the lone wave per SIMD has nothing to
+// hide its stores behind and the chunked kernel -- three blocks per CU -- is the faster one (in the bench step:
+// 256^2 fused activation backward 0.455 vs 0.374 ms): only on request (P2L_FORM_H2R_SEQ_EPI: tests).  Both give
+// the same bits and the same maxima slots, so the choice may follow the epilogue.
+bool p2l_h2r_takes(const ConvK& k) { return h2r_epi(k) != 0 || (k.form & P2L_FORM_H2R_SEQ_EPI); }
+
 // k: the ConvK of the direct fp16 x 2 launch (k.w = the fp16 x 2 direct image, k.w_tail, k.amax | k.amax_in).
 int p2l_h2r_launch(const ConvK& k_in, int pro, hipStream_t st) {
   ConvK k = k_in;
@@ -463,12 +480,7 @@ int p2l_h2r_launch(const ConvK& k_in, int pro, hipStream_t st) {
   const int grid = n_tiles < n_cu ? n_tiles : (int)n_cu;
   // the pipelined forward-style epilogue where the launch asks for nothing else (the compiled-in order of
   // operations is epi_item's: same bits), the shared item otherwise
-  int epi = 0;
-  if (!k.arb_x && !k.res && !k.oscale && !k.noise && k.alpha == 1.0f && k.y != nullptr && k.n_store == 64 &&
-      (k.act == P2L_ACT_NONE || k.act == P2L_ACT_RELU) && !(k.form & P2L_FORM_H2R_SEQ_EPI)) {
-    if (k.pool == P2L_POOL_NONE) epi = k.mask ? 2 : 1;
-    else if (k.pool == P2L_POOL_MAX && !k.mask && k.yp != nullptr) epi = 3;
-  }
+  const int epi = h2r_epi(k);
 #define P2L_H2RL(PROV)                                                                        \
   do {                                                                                        \
     if (epi == 1) P2L_H2RE(PROV, 1); else if (epi == 2) P2L_H2RE(PROV, 2);                    \

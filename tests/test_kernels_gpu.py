@@ -1236,7 +1236,8 @@ def test_direct_kernel_fp16x2(dev, O, case):
 H2R_CASES = [(3, 32, 32), (2, 24, 48), (5, 16, 16), (9, 128, 128), (2, 256, 256)]
 
 
-@pytest.mark.parametrize('mode', ['plain', 'pro-relu-maxima', 'pool-max-res', 'mask', 'own-amax-pass',
+@pytest.mark.parametrize('mode', ['plain', 'pro-relu-maxima', 'pool-max-res', 'mask', 'own-amax-pass', 'fast-mask',
+                                  'fast-pool-max-maxima',
                                   'dgrad-fused-arb', 'dgrad-fused-arb-skip-pool-sum'])
 @pytest.mark.parametrize('case', H2R_CASES, ids=lambda c: 'x'.join(map(str, c)))
 def test_register_resident_64ch_kernel_bit_identical(dev, O, case, mode):
@@ -1281,7 +1282,12 @@ def test_register_resident_64ch_kernel_bit_identical(dev, O, case, mode):
         if 'skip' in mode:
             kw.update(skip=nhwc(torch.randn(B, 32, Hx, Wx, generator=g), dev), skip_C=32)
         res = []
-        for form, fam in zip(forms, (fam_new, fam_old)):
+        # (a fused activation backward stays on the chunked kernel by default -- the resident one cannot pipeline
+        #  that epilogue --: forced here, so that the shared-item form of the new kernel is held to the same bits)
+        _, fams = family(lambda: O.conv_dgrad_arb(dy, wt, B, H, W, Cout, Cin, 9, xa, s.to(dev), t.to(dev), Cin,
+                                                  pool_sum=bool(pool), form=N.FORM_NO_WINO, **kw))
+        assert fams == [fam_old]
+        for form, fam in zip((N.FORM_NO_WINO | N.FORM_H2R_SEQ_EPI, forms[1]), (fam_new, fam_old)):
             out, fams = family(lambda: O.conv_dgrad_arb(dy, wt, B, H, W, Cout, Cin, 9, xa, s.to(dev), t.to(dev), Cin,
                                                         pool_sum=bool(pool), form=form, **kw))
             assert fams == [fam], (fams, fam)
@@ -1306,12 +1312,21 @@ def test_register_resident_64ch_kernel_bit_identical(dev, O, case, mode):
                   want_amax=True)
     elif mode == 'mask':
         kw.update(mask=nhwc(torch.randn(B, Cout, H, W, generator=g), dev), alpha=0.5)
+    elif mode == 'fast-mask':                           # (the VGG input-gradient launches: pipelined epilogue 2)
+        kw.update(mask=nhwc(torch.randn(B, Cout, H, W, generator=g), dev), want_amax=True)
+        kw.pop('bias')
+    elif mode == 'fast-pool-max-maxima':                # (VGG conv1_2 forward: pipelined epilogue 3)
+        kw.update(pool=N.POOL_MAX, act=N.ACT_RELU, want_amax=True)
     wp = O.pack_conv_weight(w.to(dev), 9, Cout, Cin, wfmt=2)
     outs = []
-    for form, fam in zip(forms, (fam_new, fam_old)):
+    slow = mode in ('pool-max-res', 'mask')           # (residual / alpha: not the pipelined epilogue)
+    for form, fam in zip(((forms[0] | N.FORM_H2R_SEQ_EPI) if slow else forms[0], forms[1]), (fam_new, fam_old)):
         out, fams = family(lambda: O.conv(xs, wp, B, H, W, Cin, Cout, 9, form=form, **kw))
         assert fams == [fam], (fams, fam)
         outs.append(out)
+    if mode == 'plain':                                 # ... and the two epilogues of the new kernel against each other
+        (y_seq, _), _ = family(lambda: O.conv(xs, wp, B, H, W, Cin, Cout, 9, form=forms[0] | N.FORM_H2R_SEQ_EPI, **kw))
+        assert torch.equal(y_seq, outs[0][0])
     y_new, y_old = outs[0][0], outs[1][0]
     assert torch.equal(y_new, y_old), 'outputs differ: %g' % (y_new - y_old).abs().max().item()
     if outs[0][1] is not None:
