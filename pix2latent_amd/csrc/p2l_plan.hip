@@ -98,16 +98,30 @@ size_t conv_ws_floats(ConvCall& c) {
 // another conv writes the buffer (run_conv), when a non-conv kernel writes it (amax_drop at that
 // call site) or when its slot set comes round again in the ring.
 // ---------------------------------------------------------------------------
+// Round 6: many partials are compacted once.  Every block of a reader reduces ALL partial maxima of its image in
+// its prologue; a producer at 512^2 / 1024^2 (VGG behind StyleGAN2) leaves 8 192 ... 32 768 of them per image, and
+// thousands of reader blocks each pulled 32 - 128 KB through L2 before their first multiply (512^2 128 -> 128 at
+// 3 candidates ran at 243 TFLOP/s where the same kernel does 340 on 128^2 x 18).  The first reader of such an
+// entry now runs one tiny kernel that folds the partials to 256 per image (max is exact: same scales, same
+// bits), and every reader gets those.
+__global__ void amax_compact_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+  const float* p = in + (size_t)blockIdx.x * n;
+  float m = 0.f;                                       // (partials are maxima of |.|: >= 0)
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, p[i]);
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = m;
+}
 struct AmaxReg {
-  static constexpr int NSETS = 6, NENT = 8;
-  float* ring = nullptr; size_t set_floats = 0; int next = 0;
+  static constexpr int NSETS = 6, NENT = 8, COMPACT_FROM = 4096, COMPACT_TO = 256;
+  // a set = [B][set_floats / B] partials of one tensor + [B][COMPACT_TO] floats for their compacted form
+  float* ring = nullptr; size_t set_floats = 0, set_stride = 0; int next = 0;
   struct Ent { const float* t = nullptr; int B = 0, H = 0, W = 0, C = 0; const float* slots = nullptr; int n = 0, set = -1;
-               const float* ps = nullptr; int pbs = 0; };   // ps: recorded as max|t*ps + pt| (the reader's prologue)
+               const float* ps = nullptr; int pbs = 0;      // ps: recorded as max|t*ps + pt| (the reader's prologue)
+               bool compacted = false; };
   Ent e[NENT];
   float* take(int* set) {
     *set = next % NSETS; ++next;
     for (Ent& x : e) if (x.set == *set) x = Ent();
-    return ring + (size_t)*set * set_floats;
+    return ring + (size_t)*set * set_stride;
   }
   void drop(const float* t) { if (t) for (Ent& x : e) if (x.t == t) x = Ent(); }
   void put(const float* t, int B, int H, int W, int C, const float* slots, int n, int set,
@@ -116,15 +130,23 @@ struct AmaxReg {
     Ent* f = &e[0];
     for (Ent& x : e) if (!x.t) { f = &x; break; }
     f->t = t; f->B = B; f->H = H; f->W = W; f->C = C; f->slots = slots; f->n = n; f->set = set;
-    f->ps = ps; f->pbs = pbs;
+    f->ps = ps; f->pbs = pbs; f->compacted = false;
   }
   // ps / pbs = the prologue vector the READER fuses (NULL: none).  Maxima recorded with an affine
   // applied serve that reader only (*applied = 1); raw maxima serve every reader (bound in the kernel).
+  // st: the stream the reader will be launched on (the compaction kernel goes in front of it); NULL = host
+  // logic only (self-test): nothing is launched
   bool get(const float* t, int B, int H, int W, int C, const float** slots, int32_t* n,
-           const float* ps = nullptr, int pbs = 0, int32_t* applied = nullptr) const {
-    for (const Ent& x : e)
+           const float* ps = nullptr, int pbs = 0, int32_t* applied = nullptr, void* st = nullptr,
+           bool launch = false) {
+    for (Ent& x : e)
       if (x.t == t && t && x.B == B && x.H == H && x.W == W && x.C == C) {
         if (x.ps && (x.ps != ps || x.pbs != pbs || !applied)) return false;
+        if (launch && !x.compacted && x.n >= COMPACT_FROM && set_stride >= set_floats + (size_t)B * COMPACT_TO) {
+          float* dst = ring + (size_t)x.set * set_stride + set_floats;
+          hipLaunchKernelGGL(amax_compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)st, x.slots, x.n, dst);
+          x.slots = dst; x.n = COMPACT_TO; x.compacted = true;
+        }
         *slots = x.slots; *n = x.n;
         if (applied) *applied = x.ps ? 1 : 0;
         return true;
@@ -135,8 +157,8 @@ struct AmaxReg {
 thread_local AmaxReg* g_amax = nullptr;
 struct AmaxScope {                                     // one per plan entry point
   AmaxReg reg;
-  AmaxScope(float* ring, size_t set_floats) {
-    reg.ring = ring; reg.set_floats = set_floats;
+  AmaxScope(float* ring, size_t set_floats, size_t set_stride) {
+    reg.ring = ring; reg.set_floats = set_floats; reg.set_stride = set_stride;
 #ifdef P2L_NO_AMAX_HANDOVER                            // (A/B build: tools/ab_build.sh p2l_plan -DP2L_NO_AMAX_HANDOVER)
     set_floats = 0;
 #endif
@@ -158,7 +180,7 @@ int conv_amax_slots(ConvCall& c) {
 extern "C" int p2l_selftest_amaxreg(void) {
   static float ring[AmaxReg::NSETS * 8];
   AmaxReg R;
-  R.ring = ring; R.set_floats = 8;
+  R.ring = ring; R.set_floats = 8; R.set_stride = 8;
   const float *slots = nullptr; int32_t n = 0;
   float t1[1], t2[1], t3[1];
   int set = -1;
@@ -216,9 +238,9 @@ int run_conv(ConvCall& c, float* skws, size_t skws_floats, void* st) {
     //  input-gradient form the high-resolution one)
     const float* rps = c.d.pro != P2L_PRO_NONE ? c.ps : nullptr;
     if ((c.d.ups == 0 || c.d.ups == 3) && c.d.x_ld == c.d.Cin)
-      R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied);
+      R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied, st, true);
     else if (c.d.ups == 2 && !c.d.ext && c.d.x_ld == c.d.Cin)
-      R->get(c.x, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied);
+      R->get(c.x, c.d.B, c.d.H / 2, c.d.W / 2, c.d.Cin, &ex.amax.in, &ex.amax.in_n, rps, c.d.pro_bstride, &ex.amax.in_applied, st, true);
     R->drop(c.y); R->drop(c.yp);                       // this launch overwrites them
     ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
     if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && c.d.n_store == c.d.Cout) {
@@ -264,7 +286,7 @@ int run_dgrad_arb(ConvCall& c, const ArbArgs& a, float* dx, float* tmp, float* p
     int ns = 0, set_o = -1;
     if (R) {
       if ((c.d.ups == 0 || (c.d.ups == 3 && !c.d.ext)) && c.d.x_ld == c.d.Cin)
-        R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &arb.amax.in, &arb.amax.in_n);
+        R->get(c.x, c.d.B, c.d.H, c.d.W, c.d.Cin, &arb.amax.in, &arb.amax.in_n, nullptr, 0, nullptr, st, true);
       R->drop(dx);
       ns = c.want_amax ? p2l_conv_amax_slots(&c.d) : 0;
       if (ns > 0 && (size_t)ns * c.d.B <= R->set_floats && (c.d.ups == 0 || (c.d.ups == 3 && !c.d.ext))) {
@@ -306,7 +328,7 @@ struct BGLayout {
   size_t arb_partial, tail_pf;
   size_t d_theta, d_phi_p, d_phi, d_g_p, d_g, d_ag;
   size_t skws; size_t skws_floats;
-  size_t amax_ring, amax_set_floats;   // AmaxReg: NSETS sets of [B][max slots per image]
+  size_t amax_ring, amax_set_floats, amax_set_stride;   // AmaxReg: NSETS sets of [B][max slots per image] (+ compacted)
   size_t total;
   int out_res;
 };
@@ -444,7 +466,8 @@ int bg_layout(const P2LBigGAN* m, int B, BGLayout& L) {
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
   L.amax_set_floats = (size_t)B * max_slots;
-  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_floats + 64);
+  L.amax_set_stride = L.amax_set_floats + (size_t)B * AmaxReg::COMPACT_TO;
+  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_stride + 64);
   L.total = a.off;
   return P2L_OK;
 }
@@ -515,7 +538,7 @@ extern "C" int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int Li
   }
   if (what == 11) {  // the maxima ring: NSETS sets of [B][slots per image]
     *float_off = L.amax_ring; shape[0] = AmaxReg::NSETS; shape[1] = 1; shape[2] = 1;
-    shape[3] = (int32_t)L.amax_set_floats;
+    shape[3] = (int32_t)L.amax_set_stride;
     return P2L_OK;
   }
   if (what != 0) return P2L_EINVAL;
@@ -549,7 +572,7 @@ extern "C" int p2l_biggan_fwd(const P2LBigGAN* m, const float* z, const float* c
   float* W = (float*)ws;
   const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
   float* skws = W + L.skws;
-  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats);
+  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats, L.amax_set_stride);
 
   RET_IF(p2l_concat2(z, c, W + L.cond, B, m->z_dim, m->c_dim, st));
   RET_IF(p2l_linear_fwd(W + L.cond, m->cbn_w, nullptr, W + L.raw, B, cond, 2 * CT, st));
@@ -678,7 +701,7 @@ extern "C" int p2l_biggan_bwd(const P2LBigGAN* m, int B, void* ws, size_t ws_byt
   const int cond = m->z_dim + m->c_dim, CT = m->cbn_total;
   float* skws = W + L.skws;
   float* part = W + L.arb_partial;
-  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats);
+  AmaxScope amax_scope(W + L.amax_ring, L.amax_set_floats, L.amax_set_stride);
   // ds / dt of the ~50 activation-backwards are only needed by the conditioning gradient at
   // the very end: record their second reduction stage and run it as ONE launch
   struct ArbDefer {
@@ -874,7 +897,7 @@ struct PLLayout {
   size_t gs;           // per-sample gradient scale
   size_t ga, gb, gtap; // backward scratch
   size_t skws, skws_floats;
-  size_t amax_ring, amax_set_floats;   // AmaxReg
+  size_t amax_ring, amax_set_floats, amax_set_stride;   // AmaxReg
   size_t total;
 };
 
@@ -923,7 +946,8 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
   L.skws_floats = max_sk;
   L.skws = a.take(max_sk ? max_sk : 64);
   L.amax_set_floats = (size_t)B * max_slots;
-  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_floats + 64);
+  L.amax_set_stride = L.amax_set_floats + (size_t)B * AmaxReg::COMPACT_TO;
+  L.amax_ring = a.take(AmaxReg::NSETS * L.amax_set_stride + 64);
   L.total = a.off;
   return P2L_OK;
 }
@@ -931,7 +955,7 @@ int pl_layout(int B, int H, int W, PLLayout& L) {
 // VGG16 features forward on an NHWC16 image; y[i] = relu(conv_i), pooled copies.
 int vgg_forward(const P2LVggLpips* v, const float* img16, int B, int H, int W, float* Wk,
                 const PLLayout& L, void* st) {
-  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats);
+  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats, L.amax_set_stride);
   const float* x = img16;
   int pi = 0;
   for (int i = 0; i < 13; ++i) {
@@ -1078,7 +1102,7 @@ extern "C" int p2l_projloss_bwd(const P2LVggLpips* v, const float* img16,
   if (!v) return P2L_EINVAL;
   // gs[b] = gloss[b] * beta / wsum[b]
   RET_IF(p2l_vec_scale_div(gloss, cache->wsum, Wk + L.gs, B, beta, st));
-  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats);
+  AmaxScope amax_scope(Wk + L.amax_ring, L.amax_set_floats, L.amax_set_stride);
   float* ga = Wk + L.ga;   // gradient w.r.t. the PRE-ReLU output of conv i (masked)
   float* gb = Wk + L.gb;
   float* gtap = Wk + L.gtap;

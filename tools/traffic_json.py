@@ -10,7 +10,7 @@ import sys
 
 # every kernel a 3x3 launch of the bench step can be: direct (TAPS=9), sub-pixel (TAPS=4), Winograd
 # (8x16 and 16x16 blocks), three-channel image convs
-KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'conv_h2_kernel', 'wino_conv_kernel', 'wino16s_conv_kernel',
+KERNELS = ('conv_mfma_kernel<9,', 'conv_mfma_kernel<4,', 'conv_h2_kernel', 'conv_h2r_kernel', 'wino_conv_kernel', 'wino16s_conv_kernel',
            'conv_thinin_kernel', 'conv_thinout_kernel')
 
 
@@ -56,7 +56,7 @@ def one_run(fetch_csv, write_csv, bench_json):
 out_path, commit, box = sys.argv[1:4]
 runs = [one_run(*sys.argv[i:i + 3]) for i in range(4, len(sys.argv) - 2, 3)]
 out = {
-    'kernel': '3x3 conv launches: conv_h2_kernel<TAPS=9|4,...> / conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
+    'kernel': '3x3 conv launches: conv_h2_kernel<TAPS=9|4,...> / conv_h2r_kernel / conv_mfma_kernel<TAPS=9|4,...> (direct / sub-pixel) + wino_conv_kernel + '
               'wino16s_conv_kernel + conv_thinin/thinout_kernel; the bytes of wino_amax_kernel (max-|x| pass of '
               'the fp16 x 2 Winograd launches) and conv_splitk_finish* are included, per conv launch',
     'commit': commit, 'box': box,
