@@ -614,6 +614,10 @@ def main():
                     help='do not sample socket power / shader clock while the timed steps run')
     ap.add_argument('--no-fp32-leg', action='store_true',
                     help='skip the extra exact-fp32-MFMA measurement reported in config')
+    ap.add_argument('--eager', action='store_true',
+                    help='run the timed steps eagerly with the per-launch hipEvent pairs inside them (rounds 1-5). '
+                         'Default: the timed steps run as the optimizers run them -- for this configuration one HIP '
+                         'graph with two branches, replayed -- and the launches are timed in an eager leg behind them')
     ap.add_argument('--no-alone', action='store_true',
                     help='skip the one-pass-of-18 leg that measures the kernels without the other lane beside them')
     ap.add_argument('--pmc-run', action='store_true',
@@ -634,7 +638,7 @@ def main():
                          'after the other); 18 = one pass of the whole population on one stream')
     args = ap.parse_args()
     if args.pmc_run:
-        args.no_alone = args.no_fp32_leg = args.no_extra = args.no_cpu_baseline = True
+        args.eager = args.no_alone = args.no_fp32_leg = args.no_extra = args.no_cpu_baseline = True
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -670,33 +674,64 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # The timed steps carry per-launch HIP-event pairs (roofline.achieved is measured live), which
-    # a captured graph cannot contain: the main loop runs eagerly at every N.  (With <= 6 local
-    # candidates the optimizers replay the step as a HIP graph by default; measured, the replay
-    # and the eager queue take the same time when the GPU is the bottleneck -- DESIGN section 7,
-    # profiles/round2_step_vs_batch.txt -- and config.extra carries a replayed configuration.)
-    opt.use_graph = False
+    # The timed steps run the step as the optimizers run it (`opt.optimize()`): for 18 candidates in two reference
+    # chunks that is ONE HIP graph with two branches, replayed (base_optimizer._graph_default; with <= 6 local
+    # candidates, i.e. on the ranks of a 4- / 8-GPU job, a one-branch graph).  A captured graph cannot contain
+    # hipEvent pairs, so the per-launch figures come from legs BEHIND the timed region: an eager leg in the same
+    # two-lane configuration (`roofline.concurrent`) and the one-pass-of-18 leg (top-level `roofline`).
+    # --eager: the rounds 1-5 form, events inside the timed steps.
+    graph_timed = not args.eager
+    if not graph_timed:
+        opt.use_graph = False
     for i in range(args.warmup):
         opt.step(variables, optimize=True, transform=(i == 0))
+
+    def replaying():
+        return any(isinstance(v, tuple) for v in getattr(opt, '_graphs', {}).values())
+    if graph_timed:
+        # (a graph is captured on the second sighting of a set of buffers: with --warmup < 3 that would fall
+        #  into the timed steps; this is set-up, like allocating the workspaces)
+        extra_warm = 0
+        while not replaying() and extra_warm < 3 and opt.use_graph is not False:
+            opt.step(variables, optimize=True, transform=(args.warmup == 0 and extra_warm == 0))
+            extra_warm += 1
     sync()
     lanes_used = max(1, len(getattr(opt.model, '_lanes', {})))    # (sets of workspaces the model was asked for)
     lib = N.lib()
     n_prof = 4096
-    N.check(lib.p2l_prof_begin(n_prof), 'p2l_prof_begin')
     # hipEvents around EVERY conv launch cost the stream ~5 us each (measured: 5 % of the
     # step); time every PERIOD-th launch, rotating the phase with the step, so that each
     # launch of the step is timed once per PERIOD steps
     period = max(1, min(args.prof_period, args.steps))
+    if not graph_timed:
+        N.check(lib.p2l_prof_begin(n_prof), 'p2l_prof_begin')
     with _GpuTelemetry(local_rank, enabled=not args.no_telemetry) as telemetry:
         t0 = time.perf_counter()
         for i in range(args.steps):
-            lib.p2l_prof_step(i, period)
+            if not graph_timed:
+                lib.p2l_prof_step(i, period)
             opt.step(variables, optimize=True)
         sync()
         elapsed = time.perf_counter() - t0
+    graph_replayed = graph_timed and replaying()
+    if graph_timed:
+        # the launches of the same two-lane step, eagerly, with event pairs: the leg `roofline.concurrent` (or,
+        # without lanes, the top-level record) is built from
+        saved_graph, opt.use_graph = opt.use_graph, False
+        ev_steps = max(period, min(args.steps, 20))
+        opt.step(variables, optimize=True)
+        sync()
+        N.check(lib.p2l_prof_begin(n_prof), 'p2l_prof_begin')
+        t0e = time.perf_counter()
+        for i in range(ev_steps):
+            lib.p2l_prof_step(i, period)
+            opt.step(variables, optimize=True)
+        sync()
+        ev_elapsed = time.perf_counter() - t0e
+        opt.use_graph = saved_graph
+    else:
+        ev_steps, ev_elapsed = args.steps, elapsed
     T = N.prof_totals()
-    flops, ms, cnt, abytes, xflops, mflops, wbytes = (T.flops, T.ms, T.count, T.bytes, T.exec_flops,
-                                                      T.mfma_flops, T.write_bytes)
     last_loss = [float(x) for x in opt.loss]     # (sharded: the one all-gather, on every rank)
     # SURVEY 8(d) also asks for the fwd-only rate (the CMA re-score); outside the timed K steps
     sync()
@@ -720,7 +755,7 @@ def main():
         # what the timed steps measured.  With two lanes a launch's hipEvent pair also spans the time it
         # shares the GPU with the OTHER lane's launches: the step is faster, every launch looks slower, and
         # the durations sum to more than the step -- reported, but not as the kernel's figure
-        timed = family_record(T, args.steps, elapsed, period, bf3, args.exec_batch, lanes_used)
+        timed = family_record(T, ev_steps, ev_elapsed, period, bf3, args.exec_batch, lanes_used)
         kernel_text = (
             'every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
             '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
@@ -753,18 +788,22 @@ def main():
                                           'algo_bytes_per_launch', 'traffic', 'traffic_source', 'traffic_read_write')}
             conc['dominant_kernel'] = timed['dominant_kernel']
             conc['conv1x1'] = timed['conv1x1']
-            conc['what'] = ('the launches of the TIMED steps (reference chunks of %d on %d HIP streams): a hipEvent '
-                            'pair spans the time a launch shares the GPU with the other lane, so these durations '
-                            'overlap -- time_share_of_step sums overlapping intervals and may exceed 1 -- and '
-                            '`achieved` is what a launch gets while overlapped, not what the kernel does'
-                            % (args.exec_batch, lanes_used))
+            conc['what'] = ('the launches of the timed configuration (reference chunks of %d on %d HIP streams), %s: a '
+                            'hipEvent pair spans the time a launch shares the GPU with the other lane, so these '
+                            'durations overlap -- time_share_of_step sums overlapping intervals and may exceed 1 -- '
+                            'and `achieved` is what a launch gets while overlapped, not what the kernel does'
+                            % (args.exec_batch, lanes_used,
+                               ('%d eager steps right behind the timed region (%.3f ms per step; the timed steps '
+                                'replay a HIP graph, which cannot hold event pairs)'
+                                % (ev_steps, 1e3 * ev_elapsed / ev_steps)) if graph_timed else 'inside the timed steps'))
             roof['concurrent'] = conc
         else:
             roof.update(timed)
-            roof['measured'] = ('the timed steps: hipEvent pairs on the launch stream around every %d-th conv '
+            roof['measured'] = (('%d eager steps right behind the timed region' % ev_steps if graph_timed else
+                                 'the timed steps') + ': hipEvent pairs on the launch stream around every %d-th conv '
                                 'launch, phase rotating with the step' % period) + (
                 '; %d lanes: durations overlap (see DESIGN section 6)' % lanes_used if lanes_used > 1 else '')
-        roof['launch_sampling'] = 'every %d-th conv launch of the timed steps timed (hipEvent pairs)' % period
+        roof['launch_sampling'] = 'every %d-th conv launch of the event legs timed (hipEvent pairs)' % period
         rec = {
             'metric': 'candidate-latent evals/sec (fwd+loss+bwd), BigGAN-256 pop=18',
             'value': round(evals / elapsed, 3),
@@ -800,7 +839,10 @@ def main():
                 'rccl_ranks': dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                 'backend': (dist.get_backend() if (world > 1 and dist.is_initialized()) else None),
                 'loss_gather': 'one all-gather per generation (lazy); per step only when log=True',
-                'hip_graph_replay': False,
+                'hip_graph_replay': bool(graph_replayed),
+                'timed_steps_run_as': ('one HIP graph per step, replayed (two branches = the two lanes): the default of '
+                                       'optimize() for this configuration' if graph_replayed else
+                                       'eager launches' + (' with hipEvent pairs inside' if not graph_timed else '')),
                 'gflop_per_eval_basis': gflop_eval,
                 'end_to_end_tflops': round(gflop_eval * evals / elapsed / 1e3, 2),
                 'fwd_only_rescore_evals_per_s': round(rescore_rate, 1),

@@ -42,6 +42,8 @@ def test_bench_single_gpu_line():
     # the top-level figures are the kernels' own (one pass of 18, nothing beside the launches):
     # they fit inside their step; what the launches get while the two lanes overlap sits under `concurrent`
     assert rec['config']['lanes'] == 2 and roof['exec_batch_size'] == 18 and roof['lanes'] == 1
+    # the timed steps run as optimize() runs them: one HIP graph with two branches, replayed
+    assert rec['config']['hip_graph_replay'] is True
     assert 0 < roof['time_share_of_step'] <= 1.0
     dom = roof['dominant_kernel']
     assert dom['name'].startswith('wino16s_conv_kernel') and 0 < dom['frac'] < 1 and dom['avg_launch_ms'] > 0
