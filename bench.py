@@ -33,6 +33,10 @@ POP = 18
 MAX_BATCH = 9
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6      # dense v_mfma_f32_32x32x16_bf16 = 16 x the fp32 MFMA rate
+# what the matrix pipe SUSTAINS on random fp16 operands, every SIMD multiplying back to back for 10-20 ms: the chip
+# clocks to its power budget (tools/micro/mfma_power.hip -> profiles/round6_mfma_power.txt: 2 460 on zeros, 1 670 on
+# random operands = 1.59 GHz).  Reported beside `frac` (which stays priced against the nominal dense peak).
+MFMA_SUSTAINED_RANDOM_TFLOPS = 1670.0
 HBM_PEAK_TBS = 8.0                  # MI355X_MICROARCH.md: HBM3E peak (achievable ~6.3 read; measured write 4.4-4.9)
 GFLOP_PER_EVAL = 197.8              # BASELINE.md §2 (conv_to_rgb sliced to 3 channels)
 
@@ -495,6 +499,11 @@ def family_record(T, steps, elapsed, period, bf3, exec_batch, lanes):
         'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
         'frac_is': 'executed 16-bit MFMA FLOP/s / dense 16-bit MFMA peak' if bf3
                    else 'executed fp32 MFMA FLOP/s / fp32 MFMA peak',
+        'frac_of_sustained': ({'value': round(ach / MFMA_SUSTAINED_RANDOM_TFLOPS, 4),
+                               'sustained_tflops_random_fp16_operands': MFMA_SUSTAINED_RANDOM_TFLOPS,
+                               'source': 'profiles/round6_mfma_power.txt (tools/micro/mfma_power.hip): back-to-back '
+                                         'v_mfma_f32_32x32x16_f16 on every SIMD, power-limited clock 1.59 GHz; the '
+                                         'nominal peak is reached on zero operands only'} if bf3 else None),
         'avg_launch_ms': round(ms[0] / max(cnt[0], 1), 4),
         'sampled_launches': int(cnt[0]),
         'launches_per_step': round(cnt[0] * period / steps, 1),
