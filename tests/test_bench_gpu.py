@@ -56,6 +56,26 @@ def test_bench_single_gpu_line():
         assert leg['traffic'] is None or src['exec_batch_size'] == leg['exec_batch_size']
 
 
+@pytest.mark.timeout(600)
+def test_bench_eager_form_for_profilers():
+    """`--pmc-run` (implies --eager: events inside the timed steps, no legs behind them) is what tools/gpu_round6.sh
+    wraps in rocprofv3: warm-up + timed steps only, every dispatch at the named execution batch; the record is then
+    built from the timed steps themselves"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    for eb, lanes in ((9, 2), (18, 1)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-run', '--steps', '2', '--warmup', '1',
+                            '--exec-batch', str(eb)], cwd=ROOT, capture_output=True, text=True, timeout=550)
+        assert r.returncode == 0, r.stderr[-4000:]
+        rec = _bench_line(r.stdout)
+        assert rec['config']['hip_graph_replay'] is False and rec['config']['exec_batch_size'] == eb
+        assert rec['config']['lanes'] == lanes and 'cpu_baseline' not in rec and 'extra' not in rec['config']
+        roof = rec['roofline']
+        assert roof['exec_batch_size'] == eb and roof['sampled_launches'] > 0 and 'concurrent' not in roof
+        src = roof['traffic_source']
+        assert roof['traffic'] is None or src['exec_batch_size'] == eb
+
+
 @pytest.mark.parametrize('world', [2, 4])
 @pytest.mark.timeout(900)
 def test_bench_sharded_ranks_share_one_gpu(world):
