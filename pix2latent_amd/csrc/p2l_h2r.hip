@@ -16,9 +16,11 @@
 //     and written to the other half of a double-buffered LDS patch while the current tile is multiplied;
 //   * a wave multiplies 64 pixels x 32 channels: per (chunk, tap) 4 ds_read_b128 of activations feed 6 MFMAs
 //     (the chunked kernel: 6 reads, 2 of them weights), no weight DMA, no barrier inside a tile;
-//   * the accumulators are dumped in the layout of epilogue_vec and everything behind the dump is SHARED with
-//     the other conv kernels (p2l_conv_k.h epilogue_vec_items: bias / residual / activation / mask / pool /
-//     fused activation backward with its partial sums / partial maxima).
+//   * the accumulators are dumped in the layout of epilogue_vec; the forward-style epilogues (bias + ReLU [+ mask]
+//     [+ 2x2 max pool] + partial maxima: template parameter EPI) are then written out one pixel per step UNDER the
+//     multiply stream of the next tile, everything else goes through the item shared with the other conv kernels
+//     (p2l_conv_k.h epilogue_vec_items) between two tiles -- and, being slower that way than the chunked kernel,
+//     is left to that kernel by the launcher (p2l_h2r_takes).
 // The per-output summation order is the chunked kernel's -- chunk, tap, (m h, h m, h h) -- on the same operand
 // pieces, so the results are BIT-IDENTICAL to conv_h2_kernel<9, 64 | 32, ..> (tests/test_kernels_gpu.py
 // test_register_resident_64ch_kernel_bit_identical); which of the two runs is a function of the layer shape only.
@@ -46,7 +48,7 @@ constexpr int ROWS = HH * HP;                          // 240 rows of 64 B per 1
 // (+ 32: the four planes of a pixel -- written by the 16 lanes of one ds_write_b64 lane group -- start 8 banks
 //  apart; at a multiple of 128 bytes they met in the same banks: 28 % of the LDS cycles were conflicts)
 constexpr int PLANE = ROWS * 64 + 32;                  // 15 392 B
-constexpr int BUF = 4 * PLANE;                         // one patch, 64 channels: 61 440 B
+constexpr int BUF = 4 * PLANE;                         // one patch, 64 channels: 61 568 B
 constexpr int EP = 68;                                 // dump row pitch (epilogue_vec<2>: COLS + 4)
 constexpr int DUMP_FLOATS = 4 * 32 * EP;
 constexpr int ETAB_FLOATS = 4 * 16 * 12;               // per wave, per channel quad: bias4 | next_s4 | next_t4
