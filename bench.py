@@ -765,6 +765,13 @@ def main():
         # shares the GPU with the OTHER lane's launches: the step is faster, every launch looks slower, and
         # the durations sum to more than the step -- reported, but not as the kernel's figure
         timed = family_record(T, ev_steps, ev_elapsed, period, bf3, args.exec_batch, lanes_used)
+        if world > 1:
+            # a rank's launches hold its block of the population (2 ... 9 candidates), not an execution batch the
+            # single-GPU PMC passes were taken at: no traffic figure rather than one that belongs to other launches
+            timed['traffic'] = timed['traffic_read_write'] = None
+            timed['traffic_source'] = {'refused': 'PMC passes exist for single-GPU execution batches only; this '
+                                                  'rank launches its block of %d ranks' % world}
+            timed['exec_batch_size'] = 'rank-local block (population %d over %d ranks)' % (POP, world)
         kernel_text = (
             'every 3x3 conv launch of the step: wino16s_conv_kernel<.., H2> (Winograd F(2x2,3x3), '
             '16x16-pixel blocks, hand-scheduled; fp16 x 2 arithmetic: power-of-two scaled operands '
