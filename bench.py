@@ -50,7 +50,8 @@ def build_problem(dev, seed=0, exec_batch_size=None, lpips_net='vgg'):
     import warnings
     warnings.simplefilter('ignore')
     W = S.biggan_weights(0)
-    Wv = S.lpips_vgg_weights(1) if lpips_net == 'vgg' else S.lpips_alex_weights(2)
+    Wv = {'vgg': lambda: S.lpips_vgg_weights(1), 'alex': lambda: S.lpips_alex_weights(2),
+          'squeeze': lambda: S.lpips_squeeze_weights(3)}[lpips_net]()
     model = BigGAN(weights=W, device=dev)
     loss_fn = LF.ProjectionLoss(lpips_net=lpips_net, weights=Wv, device=dev)
     g = torch.Generator().manual_seed(2)
@@ -446,6 +447,18 @@ def full_schedule_and_default_loss(dev, ms_per_step):
             'what': 'the headline inner step with the examples\' default loss, ProjectionLoss(lpips_net=\'alex\') '
                     '(reference loss_functions.py:89): L1 + 10*LPIPS-AlexNet',
             'evals_per_s': round(POP / dt, 1), 'ms_per_step': round(1e3 * dt, 2), 'candidates': POP}
+        del opt, vm
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        opt, vm, _ = build_problem(dev, exec_batch_size=MAX_BATCH, lpips_net='squeeze')
+        opt.setup_cma(vm)
+        variables = opt.cma_init(vm)
+        dt = _time_steps(lambda first: opt.step(variables, optimize=True, transform=first), 3, 5)
+        assert all(float(l) == float(l) for l in opt.loss)
+        out['biggan_basincma_squeeze'] = {
+            'what': 'the headline inner step with ProjectionLoss(lpips_net=\'squeeze\'), the third network '
+                    'lpips.LPIPS(net=...) takes (reference loss_functions.py:131): L1 + 10*LPIPS-SqueezeNet1.1',
+            'evals_per_s': round(POP / dt, 1), 'ms_per_step': round(1e3 * dt, 2), 'candidates': POP}
     return out
 
 
@@ -635,7 +648,7 @@ def main():
                          'the configuration named on the command line')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the additional configurations reported under config.extra')
-    ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex'],
+    ap.add_argument('--lpips-net', default='vgg', choices=['vgg', 'alex', 'squeeze'],
                     help="LPIPS network: 'vgg' = BASELINE.json's metric (default); 'alex' = the "
                          "reference's ProjectionLoss() default, reported as a side configuration")
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL) or "

@@ -746,6 +746,45 @@ int p2l_alexloss_bwd(const P2LAlexLpips* v, const float* img16, const float* tar
                      float beta, int use_lpips, const float* gloss, int Bn, int H, int W,
                      void* ws, size_t ws_bytes, float* dimg16, void* stream);
 
+/* ---- LPIPS-SqueezeNet variant (round 6) ---------------------------------------------
+ * The reference hands any lpips net name through (pix2latent/loss_functions.py:128-131).
+ * torchvision squeezenet1_1.features as lpips slices it: conv(3,64,k3,s2) | pool fire fire |
+ * pool fire fire | pool fire | fire | fire | fire = 7 taps of 64,128,256,384,384,512,512
+ * channels; Fire(in, s, e): relu(conv1x1(in,s)) -> cat(relu(conv1x1(s,e)), relu(conv3x3(s,e))).
+ * The ceil-mode pools equal the floor-mode ones for the sizes taken (every window whole:
+ * powers of two >= 64; other sizes: P2L_EINVAL / ws_bytes 0).  Weights: p2l_pack_gconv_weight
+ * (16-channel K chunks for every kernel size); squeeze convs padded to 64 output channels.     */
+int p2l_pack_gconv_weight(const float* w_oihw, int O, int I, int taps, int N_pad, int K_pad,
+                          int transpose_flip, float* w_packed, void* stream);
+typedef struct P2LSqueezeLpips {
+  const float* w0; const float* b0;   /* conv0 packed (Cin padded to 16), bias [64]              */
+  const float* wt0;                   /* [9][3][64] with 1/scale folded in (p2l_conv1_dgrad)      */
+  const float* sq_w[8]; const float* sq_b[8];   /* squeeze 1x1: N_pad 64, bias padded to 64       */
+  const float* e1_w[8]; const float* e1_b[8];   /* expand 1x1                                     */
+  const float* e3_w[8]; const float* e3_b[8];   /* expand 3x3, pad 1                              */
+  const float* sq_wt[8]; const float* e1_wt[8]; const float* e3_wt[8];   /* input-gradient copies  */
+  const float* lin[7];                /* [C_k] LPIPS linear weights                               */
+  const float* in_s; const float* in_t;   /* [16] scaling layer                                   */
+} P2LSqueezeLpips;
+typedef struct P2LLossCache7 {
+  float* nft[7];                  /* normalised target features [B,P_k,C_k]   */
+  float* wt[7];                   /* adjoint-resized weight maps [B,P_k]      */
+  float* wsum;                    /* [B]                                      */
+} P2LLossCache7;
+size_t p2l_sqz_cache_floats(int Bn, int H, int W, size_t nft_off[7], size_t wt_off[7], size_t* wsum_off);
+size_t p2l_sqzloss_ws_bytes(int Bn, int H, int W);
+int p2l_sqzloss_prepare(const P2LSqueezeLpips* v, const float* target, const float* weight,
+                        const float* loss_mask, int Bn, int H, int W, const P2LLossCache7* cache, void* ws,
+                        size_t ws_bytes, void* stream);
+int p2l_sqzloss_fwd(const P2LSqueezeLpips* v, const float* img16, const float* target, const float* weight,
+                    const float* loss_mask, const P2LLossCache7* cache, float beta, int use_lpips, int Bn,
+                    int H, int W, void* ws, size_t ws_bytes, float* loss, float* loss_l1, float* loss_lpips,
+                    void* stream);
+int p2l_sqzloss_bwd(const P2LSqueezeLpips* v, const float* img16, const float* target, const float* weight,
+                    const float* loss_mask, const P2LLossCache7* cache, float beta, int use_lpips,
+                    const float* gloss, int Bn, int H, int W, void* ws, size_t ws_bytes, float* dimg16,
+                    void* stream);
+
 /* Fused F.affine_grid + F.grid_sample (bilinear, zeros, align_corners=False) on NCHW
  * images; theta is [B][6] row-major 2x3.  Replaces the warps of
  * pix2latent/transform/spatial_transform.py:69-104 (SpatialTransform.transform /

@@ -36,6 +36,10 @@ int p2l_biggan_ws_lookup(const P2LBigGAN* m, int Bn, int what, int L,
  * (0..12) inside ws after p2l_projloss_fwd */
 int p2l_projloss_ws_lookup(int Bn, int H, int W, int idx, size_t* float_off, int32_t shape[4]);
 
+/* debug/test hook: the saved activations of the LPIPS-SqueezeNet pass inside ws after p2l_sqzloss_fwd, [B,h,w,C]:
+ * idx 0 = relu(conv0), 1..8 = squeeze outputs of fires 0..7, 9..16 = outputs of fires 0..7 */
+int p2l_sqzloss_ws_lookup(int Bn, int H, int W, int idx, size_t* float_off, int32_t shape[4]);
+
 /* debug/test hook: float offset + shape [B,res,res,cout] of the post-activation output of styled conv l
  * (0 .. n_conv-1) inside ws after p2l_sg2_synthesis_fwd: the signs are the run's leaky-ReLU decisions */
 int p2l_sg2_ws_lookup(const P2LStyleGAN2* m, int Bn, int l, size_t* float_off, int32_t shape[4]);

@@ -10,7 +10,7 @@ side of the pix2latent hot path.
   torchvision VGG16 / AlexNet weights are absent here.  `lpips_spatial` restates the
   published algorithm of lpips.LPIPS(net='vgg'|'alex', version='0.1', spatial=True)
   from recall.  The network is chosen by the keys of the weight dict
-  ('vgg.conv*' or 'alex.conv*'); 'alex' is the reference default
+  ('vgg.conv*', 'alex.conv*' or 'squeeze.conv0*'); 'alex' is the reference default
   (loss_functions.py:87 `lpips_net='alex'`).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
@@ -114,6 +114,38 @@ def alex_features(Wa, x):
     return taps
 
 
+# torchvision squeezenet1_1.features sliced as lpips.pretrained_networks.squeezenet does [3P-recall]:
+# conv(3,64,k3,s2) relu | maxpool(3,2,ceil) fire(64,16,64,64) fire(128,16,64,64) | maxpool fire(128,32,128,128)
+# fire(256,32,128,128) | maxpool fire(256,48,192,192) | fire(384,48,192,192) | fire(384,64,256,256) |
+# fire(512,64,256,256); the 7 LPIPS taps are the outputs of the 7 slices.  Fire(in, s, e1, e3):
+# x -> relu(conv1x1(in,s)) -> cat(relu(conv1x1(s,e1)), relu(conv3x3(s,e3,pad 1)))
+SQZ_FIRES = [(64, 16, 64), (128, 16, 64), (128, 32, 128), (256, 32, 128), (256, 48, 192), (384, 48, 192),
+             (384, 64, 256), (512, 64, 256)]          # (in, squeeze, expand per branch)
+SQZ_POOL_BEFORE_FIRE = (0, 2, 4)                      # 3x3 stride-2 ceil-mode max-pool in front of these fires
+SQZ_TAP_AFTER_FIRE = (1, 3, 4, 5, 6, 7)               # taps 1..6 (tap 0 = relu(conv0))
+SQZ_CHNS = (64, 128, 256, 384, 384, 512, 512)
+
+
+def squeeze_features(Ws, x, tape=None):
+    """-> the 7 taps of lpips.pretrained_networks.squeezenet [3P-recall].  `tape` (oracle/masks.py): the ReLU
+    signs and the winners of the three overlapping max-pools are the discrete decisions of the pass."""
+    relu = (lambda v, n: F.relu(v)) if tape is None else tape.relu
+    pool = (lambda v, n: F.max_pool2d(v, 3, 2, ceil_mode=True)) if tape is None else tape.maxpool3s2
+    x = relu(F.conv2d(x, Ws['squeeze.conv0.weight'], Ws['squeeze.conv0.bias'], stride=2), 'squeeze.conv0')
+    taps = [x]
+    for i in range(len(SQZ_FIRES)):
+        if i in SQZ_POOL_BEFORE_FIRE:
+            x = pool(x, 'squeeze.pool%d' % i)
+        p = 'squeeze.fire%d.' % i
+        q = relu(F.conv2d(x, Ws[p + 'squeeze.weight'], Ws[p + 'squeeze.bias']), p + 'squeeze')
+        x = torch.cat([relu(F.conv2d(q, Ws[p + 'expand1x1.weight'], Ws[p + 'expand1x1.bias']), p + 'expand1x1'),
+                       relu(F.conv2d(q, Ws[p + 'expand3x3.weight'], Ws[p + 'expand3x3.bias'], padding=1),
+                            p + 'expand3x3')], 1)
+        if i in SQZ_TAP_AFTER_FIRE:
+            taps.append(x)
+    return taps
+
+
 def normalize_tensor(f, eps=1e-10):
     """lpips.normalize_tensor [3P-recall]."""
     norm = torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True))
@@ -125,7 +157,8 @@ def lpips_spatial(Wv, in0, in1, tape=None):
     `tape` applies to the features of in0 (the generated image: the differentiated pass)."""
     shift = torch.tensor(LPIPS_SHIFT, dtype=in0.dtype).view(1, 3, 1, 1)
     scale = torch.tensor(LPIPS_SCALE, dtype=in0.dtype).view(1, 3, 1, 1)
-    feats = alex_features if 'alex.conv0.weight' in Wv else vgg_features
+    feats = alex_features if 'alex.conv0.weight' in Wv else \
+        squeeze_features if 'squeeze.conv0.weight' in Wv else vgg_features
     f0 = feats(Wv, (in0 - shift) / scale, tape) if tape is not None else feats(Wv, (in0 - shift) / scale)
     f1 = feats(Wv, (in1 - shift) / scale)
     val = None

@@ -47,6 +47,22 @@ class DecisionTape(object):
         m = self._next(name, 'pool').to(x.dtype)
         return F.avg_pool2d(x * m, 2, 2) * 4.0           # the one live element of each window
 
+    def maxpool3s2(self, x, name):
+        """3x3 / stride 2, ceil_mode (lpips SqueezeNet); replay gathers the recorded winner of every window"""
+        if not self.replaying:
+            y, idx = F.max_pool2d(x, 3, 2, ceil_mode=True, return_indices=True)
+            self.items.append((name, 'pool3', idx.detach()))
+            return y
+        idx = self._next(name, 'pool3')
+        return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+
+def pool3s2_winners(x):
+    """flat indices [B,C,Ho,Wo] of the winners of a 3x3 / stride-2 max-pool over whole windows (torch's
+    first-maximum tie rule): the windows overlap, so the decision is one index per WINDOW"""
+    _, idx = F.max_pool2d(x, 3, 2, return_indices=True)
+    return idx
+
 
 def winner_mask(x, idx=None):
     """one-hot mask [B,C,H,W] of the max-pool winners of x (torch's first-maximum tie rule)"""

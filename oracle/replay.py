@@ -99,6 +99,37 @@ def loss_decisions(loss_fn, B, out, target):
     return items
 
 
+def squeeze_decisions(loss_fn, B, out, target, with_l1=True):
+    """the decisions of the LAST native ProjectionLoss / PerceptualLoss (SqueezeNet) forward on B candidates in
+    oracle/lpips_ref.py squeeze_features' order: conv0's ReLU, then per fire (the pool winners in front of fires
+    0, 2, 4, recomputed from the saved post-ReLU tensor with torch's first-maximum rule -- the rule
+    p2l_maxpool3s2_bwd applies), the squeeze ReLU and the two expand ReLUs (p2l_sqzloss_ws_lookup)"""
+    from pix2latent_amd import _native as N
+    from oracle.masks import pool3s2_winners
+    from oracle.lpips_ref import SQZ_FIRES, SQZ_POOL_BEFORE_FIRE
+    items = [('l1', 'sign', torch.sign(out.detach() - target).cpu())] if with_l1 else []
+    eng = loss_fn._engine
+    H, Wd = int(out.shape[2]), int(out.shape[3])
+    lib = N.lib()
+
+    def act(idx):
+        off, shape = C.c_size_t(0), (C.c_int32 * 4)()
+        N.check(lib.p2l_sqzloss_ws_lookup(B, H, Wd, idx, C.byref(off), shape), 'p2l_sqzloss_ws_lookup')
+        n = shape[0] * shape[1] * shape[2] * shape[3]
+        return _nchw(eng.ws[off.value:off.value + n].view(*list(shape))).cpu()
+    x = act(0)
+    items.append(('squeeze.conv0', 'relu', x > 0))
+    for i, (_, _, ex) in enumerate(SQZ_FIRES):
+        if i in SQZ_POOL_BEFORE_FIRE:
+            items.append(('squeeze.pool%d' % i, 'pool3', pool3s2_winners(x)))
+        p = 'squeeze.fire%d.' % i
+        items.append((p + 'squeeze', 'relu', act(1 + i) > 0))
+        x = act(9 + i)
+        items.append((p + 'expand1x1', 'relu', x[:, :ex] > 0))
+        items.append((p + 'expand3x3', 'relu', x[:, ex:] > 0))
+    return items
+
+
 def sg2_decisions(model, B, out, with_mapping):
     """StyleGAN2: the leaky-ReLU decisions of the LAST native forward of `model` on B candidates in the
     order oracle/stylegan2_ref.py takes them -- the 8 mapping layers (when the run went through the mapping),

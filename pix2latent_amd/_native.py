@@ -124,6 +124,18 @@ class P2LAlexLpips(C.Structure):
                 ('lin', C.c_void_p * 5), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
 
 
+class P2LSqueezeLpips(C.Structure):
+    _fields_ = [('w0', C.c_void_p), ('b0', C.c_void_p), ('wt0', C.c_void_p),
+                ('sq_w', C.c_void_p * 8), ('sq_b', C.c_void_p * 8), ('e1_w', C.c_void_p * 8), ('e1_b', C.c_void_p * 8),
+                ('e3_w', C.c_void_p * 8), ('e3_b', C.c_void_p * 8),
+                ('sq_wt', C.c_void_p * 8), ('e1_wt', C.c_void_p * 8), ('e3_wt', C.c_void_p * 8),
+                ('lin', C.c_void_p * 7), ('in_s', C.c_void_p), ('in_t', C.c_void_p)]
+
+
+class P2LLossCache7(C.Structure):
+    _fields_ = [('nft', C.c_void_p * 7), ('wt', C.c_void_p * 7), ('wsum', C.c_void_p)]
+
+
 class P2LLossCache(C.Structure):
     _fields_ = [('nft', C.c_void_p * 5), ('wt', C.c_void_p * 5), ('wsum', C.c_void_p)]
 
@@ -243,6 +255,16 @@ def pack_conv_weight(src, taps, n_pad, k_pad, flip, wfmt, subpix_mode=None):
     check(fn(ptr(src), O, I, taps, n_pad, k_pad, int(flip), ptr(dst), stream()),
           'p2l_pack_conv_weight')
     return dst
+def pack_gconv_weight(src, taps, n_pad, k_pad, flip):
+    """[O,I,kh,kw] -> the generic gather conv's layout [tap][k_pad/16][n_pad][16] (p2l_pack_gconv_weight)"""
+    L = lib()
+    src = src.detach().float().contiguous()
+    dst = torch.empty(taps * n_pad * k_pad, device=src.device, dtype=torch.float32)
+    check(L.p2l_pack_gconv_weight(ptr(src), src.shape[0], src.shape[1], taps, n_pad, k_pad, int(flip), ptr(dst),
+                                  stream()), 'p2l_pack_gconv_weight')
+    return dst
+
+
 POOL_NONE, POOL_MAX, POOL_SUM = 0, 1, 2
 PRO_NONE, PRO_AFFINE_RELU, PRO_AFFINE = 0, 1, 2
 
@@ -279,6 +301,8 @@ EXPORTS = [
     'p2l_gconv_fwd', 'p2l_maxpool3s2_fwd', 'p2l_maxpool3s2_bwd', 'p2l_conv1_dgrad',
     'p2l_alex_cache_floats', 'p2l_alexloss_ws_bytes', 'p2l_alexloss_prepare', 'p2l_alexloss_fwd',
     'p2l_alexloss_bwd',
+    'p2l_pack_gconv_weight', 'p2l_sqz_cache_floats', 'p2l_sqzloss_ws_bytes', 'p2l_sqzloss_prepare', 'p2l_sqzloss_fwd',
+    'p2l_sqzloss_bwd', 'p2l_sqzloss_ws_lookup',
 ]
 
 _lib = None
@@ -309,7 +333,7 @@ def lib():
         _lib.p2l_arb_defer_cancel.restype = None
         for name in ('p2l_conv_workspace_bytes', 'p2l_biggan_ws_bytes',
                      'p2l_projloss_ws_bytes', 'p2l_loss_cache_floats', 'p2l_sg2_ws_bytes',
-                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_gemm_ws_bytes',
+                     'p2l_alexloss_ws_bytes', 'p2l_alex_cache_floats', 'p2l_sqzloss_ws_bytes', 'p2l_sqz_cache_floats', 'p2l_gemm_ws_bytes',
                      'p2l_packed_weight_floats', 'p2l_packed_subpix_weight_floats', 'p2l_attn_fwd_ws_bytes', 'p2l_affine_grid_sample_bwd_ws_bytes',
                      'p2l_attn_bwd_dv_ws_bytes', 'p2l_attn_bwd_qk_ws_bytes'):
             getattr(_lib, name).restype = C.c_size_t

@@ -1925,6 +1925,19 @@ extern "C" int p2l_pack_conv_weight(const float* w_oihw, int O, int I, int taps,
   return p2l_check_launch();
 }
 
+// weights of the generic gather conv (p2l_gconv_fwd, p2l_alex.hip): [tap][K_pad/16][N_pad][16] for EVERY kernel
+// size -- p2l_pack_conv_weight gives 1x1 convs 32-channel chunks where K_pad allows it (conv_mfma_kernel<1, ..>)
+extern "C" int p2l_pack_gconv_weight(const float* w_oihw, int O, int I, int taps, int N_pad, int K_pad,
+                                     int transpose_flip, float* w_packed, void* stream) {
+  if (!w_oihw || !w_packed || taps < 1) return P2L_EINVAL;
+  const int N = transpose_flip ? I : O, K = transpose_flip ? O : I;
+  if (K_pad % 16 || N_pad % 32 || N_pad < N || K_pad < K) return P2L_EINVAL;
+  const size_t total = (size_t)taps * K_pad * N_pad;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     w_packed, O, I, taps, N_pad, K_pad, 16, transpose_flip, 0);
+  return p2l_check_launch();
+}
+
 // bf16x3 pre-split weights for the BF3 conv kernels: 1.5 x taps*K_pad*N_pad floats
 // P2L_WFMT_BF16X3W: the direct bf16x3 tile image followed -- for shapes the Winograd kernel
 // takes (p2l_wino_weight_ok) -- by the transform-domain image of the same weights

@@ -175,18 +175,62 @@ class _AlexLpipsParams(object):
     _pack = _VggLpipsParams._pack
 
 
+class _SqueezeLpipsParams(object):
+    """packed torchvision-SqueezeNet1.1 features + LPIPS-lin parameters (P2LSqueezeLpips, csrc/p2l_plan_squeeze.hip)."""
+    prefix = 'squeeze'
+
+    def __init__(self, weights, device):
+        self.lib = N.lib()
+        self.dev = torch.device(device)
+        self.keep = []
+        d = self.desc = N.P2LSqueezeLpips()
+        inv_scale = torch.tensor([1.0 / s for s in LPIPS_SCALE])
+        w = weights['squeeze.conv0.weight'].float()
+        d.w0 = self._gpack(w, 9, 64, 16, False)
+        d.b0 = self._t(weights['squeeze.conv0.bias'])
+        d.wt0 = self._t((w * inv_scale.view(1, 3, 1, 1)).permute(2, 3, 1, 0).reshape(9, 3, 64))
+        for i, (cin, sq, ex) in enumerate(synthetic.SQZ_FIRES):
+            g = lambda part, what: weights['squeeze.fire%d.%s.%s' % (i, part, what)].float()
+            # squeeze 1x1: output channels padded to one 64-wide tile (the launch stores `sq` of them)
+            d.sq_w[i] = self._gpack(g('squeeze', 'weight'), 1, 64, cin, False)
+            d.sq_b[i] = self._t(torch.cat([g('squeeze', 'bias').cpu(), torch.zeros(64 - sq)]))
+            d.sq_wt[i] = self._gpack(g('squeeze', 'weight'), 1, cin, sq, True)
+            d.e1_w[i] = self._gpack(g('expand1x1', 'weight'), 1, ex, sq, False)
+            d.e1_b[i] = self._t(g('expand1x1', 'bias'))
+            d.e1_wt[i] = self._gpack(g('expand1x1', 'weight'), 1, 64, ex, True)
+            d.e3_w[i] = self._gpack(g('expand3x3', 'weight'), 9, ex, sq, False)
+            d.e3_b[i] = self._t(g('expand3x3', 'bias'))
+            d.e3_wt[i] = self._gpack(g('expand3x3', 'weight'), 9, 64, ex, True)
+        for k in range(7):
+            d.lin[k] = self._t(weights['lpips.lin%d.weight' % k].reshape(-1))
+        s16, t16 = torch.zeros(16), torch.zeros(16)
+        for c in range(3):
+            s16[c] = 1.0 / LPIPS_SCALE[c]
+            t16[c] = -LPIPS_SHIFT[c] / LPIPS_SCALE[c]
+        d.in_s = self._t(s16)
+        d.in_t = self._t(t16)
+
+    _t = _VggLpipsParams._t
+
+    def _gpack(self, w, taps, n_pad, k_pad, flip):
+        dst = N.pack_gconv_weight(w.detach().to(self.dev, torch.float32), taps, n_pad, k_pad, flip)
+        torch.cuda.current_stream().synchronize()
+        self.keep.append(dst)
+        return dst.data_ptr()
+
+
 class _CacheSlot(object):
     """target-dependent state of one (target, weight, loss_mask) chunk."""
 
-    def __init__(self, cache_floats, B, H, W, dev):
-        nft_off = (C.c_size_t * 5)()
-        wt_off = (C.c_size_t * 5)()
+    def __init__(self, cache_floats, B, H, W, dev, taps=5):
+        nft_off = (C.c_size_t * taps)()
+        wt_off = (C.c_size_t * taps)()
         wsum_off = C.c_size_t(0)
         n = cache_floats(B, H, W, nft_off, wt_off, C.byref(wsum_off))
         self.buf = torch.empty(n, device=dev, dtype=torch.float32)
-        self.desc = N.P2LLossCache()
+        self.desc = N.P2LLossCache() if taps == 5 else N.P2LLossCache7()
         base = self.buf.data_ptr()
-        for k in range(5):
+        for k in range(taps):
             self.desc.nft[k] = base + 4 * nft_off[k]
             self.desc.wt[k] = base + 4 * wt_off[k]
         self.desc.wsum = base + 4 * wsum_off.value
@@ -272,6 +316,10 @@ class _LossEngine(object):
             self.f_ws, self.f_cache = lib.p2l_alexloss_ws_bytes, lib.p2l_alex_cache_floats
             self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_alexloss_prepare, lib.p2l_alexloss_fwd,
                                                       lib.p2l_alexloss_bwd)
+        elif self.prefix == 'squeeze':
+            self.f_ws, self.f_cache = lib.p2l_sqzloss_ws_bytes, lib.p2l_sqz_cache_floats
+            self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_sqzloss_prepare, lib.p2l_sqzloss_fwd,
+                                                      lib.p2l_sqzloss_bwd)
         else:
             self.f_ws, self.f_cache = lib.p2l_projloss_ws_bytes, lib.p2l_loss_cache_floats
             self.f_prepare, self.f_fwd, self.f_bwd = (lib.p2l_projloss_prepare, lib.p2l_projloss_fwd,
@@ -433,7 +481,7 @@ class _LossEngine(object):
                     # still be inside the forward / backward that uses the evicted chunk's slot)
                     slot.wait_for_readers()
             if slot is None:
-                slot = _CacheSlot(self.f_cache, B, H, W, out.device)
+                slot = _CacheSlot(self.f_cache, B, H, W, out.device, taps=7 if self.prefix == 'squeeze' else 5)
             vref = C.byref(self.vgg.desc) if use_lpips else None
             N.check(self.f_prepare(vref, N.ptr(target), N.ptr(weight), N.ptr(loss_mask), B, H, W,
                                    C.byref(slot.desc), N.ptr(self.ws), C.c_size_t(self.ws_bytes),
@@ -548,19 +596,25 @@ class _ProjLossFn(torch.autograd.Function):
 
 
 _VGG_PARAMS = {}
+# net -> (packed-parameter class, synthetic weights, loader of the upstream checkpoint pair)
+_LPIPS_NETS = {'vgg': (_VggLpipsParams, 'lpips_vgg_weights', 'load_lpips_vgg'),
+               'alex': (_AlexLpipsParams, 'lpips_alex_weights', 'load_lpips_alex'),
+               'squeeze': (_SqueezeLpipsParams, 'lpips_squeeze_weights', 'load_lpips_squeeze')}
 
 
 def _vgg_params(net, weights, device):
     """packed LPIPS network parameters: 'alex' (the reference default,
-    loss_functions.py:87) or 'vgg' (BASELINE north_star).  A weight dict keyed 'alex.conv*' /
-    'vgg.conv*' selects the network by itself."""
+    loss_functions.py:87), 'vgg' (BASELINE north_star) or 'squeeze'.  A weight dict keyed 'alex.conv*' /
+    'vgg.conv*' / 'squeeze.conv0*' selects the network by itself."""
     if weights is not None:
-        net = 'alex' if 'alex.conv0.weight' in weights else 'vgg'
+        net = ('alex' if 'alex.conv0.weight' in weights else
+               'squeeze' if 'squeeze.conv0.weight' in weights else 'vgg')
     if net in ('vgg16',):
         net = 'vgg'
-    if net not in ('vgg', 'alex'):
+    if net not in _LPIPS_NETS:
         raise NotImplementedError("lpips_net='%s': LPIPS networks with a native path are "
-                                  "'alex' and 'vgg'" % net)
+                                  "'alex', 'vgg' and 'squeeze' (all three lpips v0.1 ships)" % net)
+    params_cls, synth, loader = _LPIPS_NETS[net]
     key = (net, id(weights), str(device), N.default_wfmt(), N.default_no_amax())
     if key not in _VGG_PARAMS:
         if weights is None:
@@ -568,18 +622,18 @@ def _vgg_params(net, weights, device):
             if path and ',' in path:
                 # the two upstream files: torchvision backbone state_dict, lpips v0.1 linear layers
                 # (reference loss_functions.py:131 -> lpips.LPIPS(net=...))
-                from .utils.checkpoint import load_lpips_vgg, load_lpips_alex
+                from .utils import checkpoint
                 backbone, lin = (torch.load(f.strip(), map_location='cpu') for f in path.split(',')[:2])
-                w = (load_lpips_alex if net == 'alex' else load_lpips_vgg)(backbone, lin)
+                w = getattr(checkpoint, loader)(backbone, lin)
             elif path:
                 w = torch.load(path, map_location='cpu')
             else:
                 warnings.warn('LPIPS-%s: no pretrained weights available (no network); using '
                               'seeded random-init weights of the same architecture' % net)
-                w = synthetic.lpips_alex_weights() if net == 'alex' else synthetic.lpips_vgg_weights()
+                w = getattr(synthetic, synth)()
         else:
             w = weights
-        _VGG_PARAMS[key] = (_AlexLpipsParams if net == 'alex' else _VggLpipsParams)(w, device)
+        _VGG_PARAMS[key] = params_cls(w, device)
     return _VGG_PARAMS[key]
 
 
@@ -591,7 +645,7 @@ def _native_ok(output, target, weight):
 class ProjectionLoss(nn.Module):
     """ The default loss that is used in the paper (reference loss_functions.py:86-100).
 
-    lpips_net: 'alex' (reference default) or 'vgg'; both are native HIP plans.
+    lpips_net: 'alex' (reference default), 'vgg' or 'squeeze'; all three are native HIP plans.
     """
 
     def __init__(self, lpips_net='alex', beta=10, weights=None, device='cuda'):

@@ -131,6 +131,35 @@ def load_lpips_alex(alexnet_sd, lpips_sd):
     return out
 
 
+_SQZ_FIRE_IDX = (3, 4, 6, 7, 9, 10, 11, 12)     # torchvision squeezenet1_1.features Fire positions
+
+
+def load_lpips_squeeze(squeezenet_sd, lpips_sd):
+    """torchvision squeezenet1_1 state_dict + lpips v0.1 'squeeze' linear layers -> flat dict
+    ('squeeze.conv0.*', 'squeeze.fire{i}.{squeeze,expand1x1,expand3x3}.*', 'lpips.lin{k}.weight')."""
+    out = {}
+    w = squeezenet_sd['features.0.weight'].float()
+    if tuple(w.shape) != (64, 3, 3, 3):
+        raise ValueError('squeezenet1_1 features.0.weight has shape %s' % (tuple(w.shape),))
+    out['squeeze.conv0.weight'] = w
+    out['squeeze.conv0.bias'] = squeezenet_sd['features.0.bias'].float()
+    for i, idx in enumerate(_SQZ_FIRE_IDX):
+        cin, sq, ex = synthetic.SQZ_FIRES[i]
+        for part, shp in (('squeeze', (sq, cin, 1, 1)), ('expand1x1', (ex, sq, 1, 1)), ('expand3x3', (ex, sq, 3, 3))):
+            w = squeezenet_sd['features.%d.%s.weight' % (idx, part)].float()
+            if tuple(w.shape) != shp:
+                raise ValueError('squeezenet1_1 features.%d.%s.weight has shape %s' % (idx, part, tuple(w.shape)))
+            out['squeeze.fire%d.%s.weight' % (i, part)] = w
+            out['squeeze.fire%d.%s.bias' % (i, part)] = squeezenet_sd['features.%d.%s.bias' % (idx, part)].float()
+    for k, c in enumerate(synthetic.SQZ_CHNS):
+        key = 'lin%d.model.1.weight' % k
+        w = lpips_sd[key].float()
+        if tuple(w.shape) != (1, c, 1, 1):
+            raise ValueError('lpips %s has shape %s' % (key, tuple(w.shape)))
+        out['lpips.lin%d.weight' % k] = w
+    return out
+
+
 def load_result(path):
     """reads what `save_variables` wrote (reference pix2latent/edit/editor.py:16-22)."""
     import numpy as np

@@ -181,6 +181,31 @@ def lpips_alex_weights(seed=2):
     return Wa
 
 
+# torchvision squeezenet1_1.features as lpips slices it (oracle/lpips_ref.py SQZ_*): (in, squeeze, expand)
+SQZ_FIRES = [(64, 16, 64), (128, 16, 64), (128, 32, 128), (256, 32, 128), (256, 48, 192), (384, 48, 192),
+             (384, 64, 256), (512, 64, 256)]
+SQZ_CHNS = (64, 128, 256, 384, 384, 512, 512)
+
+
+def lpips_squeeze_weights(seed=3):
+    """seeded random-init torchvision-SqueezeNet1.1 features + lpips lin layers (keys 'squeeze.conv0.*',
+    'squeeze.fire{0..7}.{squeeze,expand1x1,expand3x3}.{weight,bias}', 'lpips.lin{0..6}.weight')."""
+    g = torch.Generator().manual_seed(seed)
+    Ws = {}
+
+    def conv(name, cout, cin, k):
+        Ws[name + '.weight'] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))
+        Ws[name + '.bias'] = torch.randn(cout, generator=g) * 0.01
+    conv('squeeze.conv0', 64, 3, 3)
+    for i, (cin, sq, ex) in enumerate(SQZ_FIRES):
+        conv('squeeze.fire%d.squeeze' % i, sq, cin, 1)
+        conv('squeeze.fire%d.expand1x1' % i, ex, sq, 1)
+        conv('squeeze.fire%d.expand3x3' % i, ex, sq, 3)
+    for k, c in enumerate(SQZ_CHNS):
+        Ws['lpips.lin%d.weight' % k] = (torch.rand(1, c, 1, 1, generator=g) / c)
+    return Ws
+
+
 def synthetic_target(size=256, seed=1):
     """smooth image in [-1,1] + a little noise, [3,size,size]."""
     g = torch.Generator().manual_seed(seed)

@@ -41,6 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
     # the test hooks live in their own header: the drop-in boundary declares none of them
     hooks = header_symbols(('p2l_test.h',))
     assert hooks == sorted(['p2l_selftest_amaxreg', 'p2l_biggan_ws_lookup', 'p2l_projloss_ws_lookup', 'p2l_sg2_ws_lookup',
+                            'p2l_sqzloss_ws_lookup',
                             'p2l_mfma_probe'])
     assert not set(hooks) & set(header_symbols(('p2l.h',)))
     # version 101: the sized-struct totals have their OWN name; the name that had carried two signatures is gone
@@ -202,7 +203,7 @@ def test_product_path_fails_loudly_without_gpu():
                         'generator.gen_z.bias': torch.zeros(8)}, device='cpu')
     import pix2latent_amd.loss_functions as LF
     with pytest.raises(NotImplementedError):
-        LF.ProjectionLoss(lpips_net='squeeze')
+        LF.ProjectionLoss(lpips_net='resnet')
     from pix2latent_amd.model.stylegan2 import StyleGAN2
     with pytest.raises(N.NativeError, match='no CPU fallback'):
         StyleGAN2(weights={}, size=64, device='cpu')

@@ -90,3 +90,27 @@ def test_save_variables_roundtrip(tmp_path):
     assert len(r['input']['z']['data']) == 3
     assert torch.equal(r['input']['z']['data'][1], v.input.z.data[1].detach())
     assert r['loss'][-1][1]['loss'][2] == 0.3
+
+
+def test_load_lpips_squeeze_maps_torchvision_and_lpips_keys():
+    """torchvision squeezenet1_1 + lpips v0.1 'squeeze' files -> the flat dict ProjectionLoss(weights=...) takes
+    (the reference downloads both inside lpips.LPIPS(net='squeeze'), loss_functions.py:131)"""
+    import torch
+    from pix2latent_amd.utils import checkpoint as CK, synthetic as S
+    Ws = S.lpips_squeeze_weights(5)
+    sd, lin = {}, {}
+    sd['features.0.weight'], sd['features.0.bias'] = Ws['squeeze.conv0.weight'], Ws['squeeze.conv0.bias']
+    for i, idx in enumerate((3, 4, 6, 7, 9, 10, 11, 12)):
+        for part in ('squeeze', 'expand1x1', 'expand3x3'):
+            for what in ('weight', 'bias'):
+                sd['features.%d.%s.%s' % (idx, part, what)] = Ws['squeeze.fire%d.%s.%s' % (i, part, what)]
+    for k in range(7):
+        lin['lin%d.model.1.weight' % k] = Ws['lpips.lin%d.weight' % k]
+    got = CK.load_lpips_squeeze(sd, lin)
+    assert sorted(got) == sorted(Ws)
+    assert all(torch.equal(got[k], Ws[k].float()) for k in Ws)
+    bad = dict(sd)
+    bad['features.6.squeeze.weight'] = torch.zeros(16, 128, 1, 1)
+    import pytest
+    with pytest.raises(ValueError, match='features.6.squeeze'):
+        CK.load_lpips_squeeze(bad, lin)
