@@ -826,6 +826,21 @@ int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const float* d, cons
                            float nw, const float* bias, float* gd, float* dd, float* dnoise,
                            float* partial, float* strips, int Bn, int P, int C, void* stream);
 int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C, void* stream);
+/* The same three kernels, leaving the per-image maxima of what they write for the fp16 x 2 conv that reads it
+ * (P2LAmax.in with in_n = P2L_SG2_AMAX_SLOTS): amax_out [Bn][P2L_SG2_AMAX_SLOTS] floats the CALLER ZEROED on the
+ * same stream; partial maxima arrive by atomic max on the bit pattern -- exact, so the reader's scale (and every
+ * bit of its output) is that of its own pass.  blur_fwd: the maxima of |y * next_s[b,c]| (next_s [Bn][C] = the
+ * style the reader fuses as its prologue -> P2LAmax.in_applied = 1; NULL: of |y|); styled_act_bwd: of |gd|;
+ * blur_bwd: of |du| over the whole (H+2)^2 frame.  amax_out NULL = the plain form. */
+#define P2L_SG2_AMAX_SLOTS 64
+int p2l_sg2_blur_fwd_amax(const float* u, const float* d, const float* noise, float nw, const float* bias,
+                          float* y, int Bn, int H, int W, int C, const float* next_s, float* amax_out,
+                          void* stream);
+int p2l_sg2_styled_act_bwd_amax(const float* dy, const float* y, const float* d, const float* noise,
+                                float nw, const float* bias, float* gd, float* dd, float* dnoise,
+                                float* partial, float* strips, int Bn, int P, int C, float* amax_out,
+                                void* stream);
+int p2l_sg2_blur_bwd_amax(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out, void* stream);
 /* RGB skip upsample (upfirdn2d up=2, [1,3,3,1]) on NHWC16 images and its transpose */
 int p2l_sg2_rgb_up_fwd(const float* skip, float* out, int Bn, int h, int w, void* stream);
 int p2l_sg2_rgb_up_bwd(const float* dout, float* dskip, int Bn, int h, int w, int accumulate,

@@ -19,6 +19,9 @@ static inline int p2l_check_launch() {
   return P2L_OK;
 }
 
+// fold n >= 256 partial maxima per image to 256 (p2l_plan.hip; max is exact): out [B][256]
+int p2l_amax_compact(const float* in, int B, int n, float* out, void* st);
+
 static inline int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;

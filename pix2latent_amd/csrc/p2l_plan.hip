@@ -175,6 +175,11 @@ int conv_amax_slots(ConvCall& c) {
 }
 
 }  // namespace
+// (library-internal, p2l_common.h: the StyleGAN2 plan folds the partials of its high-resolution producers too)
+int p2l_amax_compact(const float* in, int B, int n, float* out, void* st) {
+  hipLaunchKernelGGL(amax_compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)st, in, n, out);
+  return p2l_check_launch();
+}
 // test hook (host logic only, no GPU): the bookkeeping rules of AmaxReg; 0 = all hold, else the
 // number of the first rule that failed (tests/test_abi.py)
 extern "C" int p2l_selftest_amaxreg(void) {

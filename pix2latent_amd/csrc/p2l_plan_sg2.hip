@@ -32,8 +32,14 @@ struct SgLayout {
   size_t rs[P2L_SG2_MAX_RGBS], rds[P2L_SG2_MAX_RGBS], skip[P2L_SG2_MAX_RGBS];
   size_t x0, zeros, ubuf, upbuf, g_a, g_b, g_c, g_d, gs_a, gs_b, part, part2, strips, scratch;
   size_t cws, cws_floats;   // conv workspace: the per-image maxima of the fp16 x 2 Winograd form
+  // maxima handed from the kernel that writes a tensor to the fp16 x 2 conv that reads it (P2LAmax, round 6):
+  //   amax_f [n_conv][B][64]     y[l] x s[l+1] left by the blur kernel of an up conv (atomic slots)
+  //   amax_b [2][n_conv][B][64]  gd of styled_act_bwd | the blur transpose's frame
+  //   amax_c                     partials of a plain conv's epilogue ([B][slots]) + [B][256] for their folded form
+  size_t amax_f, amax_b, amax_c, amax_c_floats, amax_zero_floats;
   size_t total;
 };
+constexpr int kAmaxCompactFrom = 4096;
 
 int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   if (!m || B < 1 || m->n_conv < 1 || m->n_conv > P2L_SG2_MAX_CONVS || m->n_rgb > P2L_SG2_MAX_RGBS)
@@ -85,6 +91,19 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   L.scratch = a.take((size_t)B * max_c * 2);
   L.cws_floats = (size_t)B * 64;
   L.cws = a.take(L.cws_floats);
+  L.amax_zero_floats = (size_t)3 * m->n_conv * B * P2L_SG2_AMAX_SLOTS;
+  L.amax_f = a.take(L.amax_zero_floats);
+  L.amax_b = L.amax_f + (size_t)m->n_conv * B * P2L_SG2_AMAX_SLOTS;
+  size_t mc = 0;
+  for (int l = 0; l + 1 < m->n_conv; ++l) {
+    // (an upper bound of p2l_conv_amax_slots for every kernel form: one partial per wave of a 128-pixel x
+    //  32-channel tile -- the format of the run is not known when the workspace is sized)
+    const P2LSg2Conv& c = m->conv[l];
+    const size_t n = (size_t)c.res * c.res * c.cout / 1024;
+    if (!c.up && n > mc) mc = n;
+  }
+  L.amax_c_floats = (size_t)B * (mc + 256);
+  L.amax_c = a.take(L.amax_c_floats);
   L.total = a.off;
   return P2L_OK;
 }
@@ -100,18 +119,22 @@ P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
 }
 
 // input-gradient conv + modulation backward (dx = dx' * s + extra ; ds = sum_p dx' * x)
+// amax_in: [B][P2L_SG2_AMAX_SLOTS] maxima of gin left by the kernel that wrote it, or NULL
 int dgrad_scale(P2LConv& d, const float* gin, const float* w, const float* x, const float* s,
                 int C, const float* extra, float* dx, float* ds, float* tmp, float* part,
-                float* scratch, int B, int Hout, float* cws, size_t cws_floats, void* st) {
+                float* scratch, int B, int Hout, float* cws, size_t cws_floats, const float* amax_in, void* st) {
   if (p2l_conv_arb_fusable(&d)) {
     P2LArb a{};
+    a.amax.in = amax_in; a.amax.in_n = amax_in ? P2L_SG2_AMAX_SLOTS : 0;
     a.x = x; a.x_ld = C; a.s = s; a.t = s; a.st_bstride = C;
     a.skip = extra; a.skip_ld = C; a.skip_C = extra ? C : 0; a.skip_ups = 0;
     a.ds = ds; a.dt = scratch; a.dsdt_bstride = C; a.partial = part; a.nomask = 1;
     return p2l_conv_dgrad_arb_ws(&d, &a, gin, w, dx, cws, cws_floats * sizeof(float), st);
   }
-  RET_IF(p2l_conv_fwd(&d, gin, w, nullptr, nullptr, nullptr, nullptr, nullptr, tmp, nullptr,
-                      cws, cws_floats * sizeof(float), st));
+  P2LConvExtra ex{};
+  ex.amax.in = amax_in; ex.amax.in_n = amax_in ? P2L_SG2_AMAX_SLOTS : 0;
+  RET_IF(p2l_conv_fwd_ex(&d, &ex, gin, w, nullptr, nullptr, nullptr, nullptr, nullptr, tmp, nullptr,
+                         cws, cws_floats * sizeof(float), st));
   return p2l_scale_bwd(tmp, C, x, C, s, C, extra, C, extra ? C : 0, dx, C, ds, scratch, C, part, B,
                        Hout, Hout, C, st);
 }
@@ -203,25 +226,55 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
     RET_IF(p2lsg2::grouped_linear_fwd(gs, st));
     RET_IF(p2lsg2::grouped_linear_fwd(gd, st));
   }
+  // Maxima of every conv's MODULATED input (y[l-1] * s[l]), left by the kernel that wrote y[l-1]: the fp16 x 2
+  // launches then need no pass of their own over it (35 such passes were 6.6 % of the FFHQ-1024 step,
+  // profiles/round6_sg2_1024_kernel_stats.csv).  P2L_WFMT_FLAG_NO_AMAX: every launch reduces its own.
+  const bool hand = !(m->wfmt & P2L_WFMT_FLAG_NO_AMAX);
+  if (hand && hipMemsetAsync(W + L.amax_f, 0, (size_t)m->n_conv * B * P2L_SG2_AMAX_SLOTS * sizeof(float),
+                             (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
+  const float* am_in = nullptr;          // maxima of x with s[l] applied, [B][am_n]
+  int am_n = 0;
   int rj = 0;
   for (int l = 0; l < m->n_conv; ++l) {
     const P2LSg2Conv& c = m->conv[l];
     const float* nz = noise + (size_t)B * c.noise_off;
     P2LConv d = mk(B, c.res, c.cin, c.cout, 9);
     d.pro = P2L_PRO_AFFINE; d.pro_bstride = c.cin;
+    P2LConvExtra ex{};
+    ex.amax.in = am_in; ex.amax.in_n = am_n; ex.amax.in_applied = am_in ? 1 : 0;
+    am_in = nullptr; am_n = 0;
+    const bool to_next = hand && l + 1 < m->n_conv;
+    const float* next_s = to_next ? W + L.s[l + 1] : nullptr;
     if (!c.up) {
       d.act = P2L_ACT_LRELU_SQRT2;
-      P2LConvExtra ex{};
       ex.oscale = W + L.d[l]; ex.oscale_bstride = c.cout; ex.noise = nz; ex.noise_w = c.noise_w;
+      int ns = to_next ? p2l_conv_amax_slots(&d) : 0;
+      if (ns > 0 && (size_t)B * (ns + 256) <= L.amax_c_floats) {
+        ex.amax.out = W + L.amax_c;
+        ex.amax.next_s = next_s; ex.amax.next_t = W + L.zeros; ex.amax.next_bstride = m->conv[l + 1].cin;
+      } else {
+        ns = 0;
+      }
       RET_IF(p2l_conv_fwd_ex(&d, &ex, x, c.w, c.act_b, W + L.s[l], W + L.zeros, nullptr, nullptr,
                              W + L.y[l], nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
+      if (ns > 0) {
+        am_in = W + L.amax_c; am_n = ns;
+        if (ns >= kAmaxCompactFrom) {     // (every block of the reader reduces ALL partials of its image)
+          float* folded = W + L.amax_c + (size_t)B * ns;
+          RET_IF(p2l_amax_compact(am_in, B, ns, folded, st));
+          am_in = folded; am_n = 256;
+        }
+      }
     } else {
       d.ups = 2; d.ext = 1;
       // (the workspace holds the per-image maxima of the fp16 x 2 form: without it the launch is bf16 x 3)
-      RET_IF(p2l_conv_fwd(&d, x, c.w, nullptr, W + L.s[l], W + L.zeros, nullptr, nullptr,
-                          W + L.ubuf, nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
-      RET_IF(p2l_sg2_blur_fwd(W + L.ubuf, W + L.d[l], nz, c.noise_w, c.act_b, W + L.y[l], B, c.res,
-                              c.res, c.cout, st));
+      RET_IF(p2l_conv_fwd_ex(&d, &ex, x, c.w, nullptr, W + L.s[l], W + L.zeros, nullptr, nullptr,
+                             W + L.ubuf, nullptr, W + L.cws, L.cws_floats * sizeof(float), st));
+      float* slots = to_next ? W + L.amax_f + (size_t)l * B * P2L_SG2_AMAX_SLOTS : nullptr;
+      RET_IF(p2l_sg2_blur_fwd_amax(W + L.ubuf, W + L.d[l], nz, c.noise_w, c.act_b, W + L.y[l], B, c.res,
+                                   c.res, c.cout, next_s, slots, st));
+      if (slots) { am_in = slots; am_n = P2L_SG2_AMAX_SLOTS; }
     }
     x = W + L.y[l];
     while (rj < m->n_rgb && m->rgb[rj].after_conv == l) {
@@ -255,6 +308,10 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
   (void)latent;
   if (hipMemsetAsync(dlatent, 0, (size_t)B * lat_ld * sizeof(float), (hipStream_t)st) != hipSuccess)
     return P2L_ELAUNCH;
+  const bool hand = !(m->wfmt & P2L_WFMT_FLAG_NO_AMAX);
+  if (hand && hipMemsetAsync(W + L.amax_b, 0, (size_t)2 * m->n_conv * B * P2L_SG2_AMAX_SLOTS * sizeof(float),
+                             (hipStream_t)st) != hipSuccess)
+    return P2L_ELAUNCH;
   float* gs_cur = W + L.gs_a;
   float* gs_prev = W + L.gs_b;
   RET_IF(p2l_sg2_clamp16_bwd(W + L.skip[m->n_rgb - 1], dimg16, gs_cur,
@@ -279,7 +336,7 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       t.algo_flops = 2.0 * B * r.res * r.res * (double)r.cin * 3;
       RET_IF(dgrad_scale(t, gs_cur, r.wt, W + L.y[l], W + L.rs[rj], r.cin,
                          have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, part, scratch, B, r.res,
-                         W + L.cws, L.cws_floats, st));
+                         W + L.cws, L.cws_floats, nullptr, st));
       if (rj > 0) {
         RET_IF(p2l_sg2_rgb_up_bwd(gs_cur, gs_prev, B, r.res / 2, r.res / 2, 0, st));
         float* t2 = gs_cur; gs_cur = gs_prev; gs_prev = t2;
@@ -292,21 +349,26 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
     // ---- styled conv l -----------------------------------------------------
     const float* nz = noise + (size_t)B * c.noise_off;
     float* dnz = dnoise ? dnoise + (size_t)B * c.noise_off : nullptr;
-    RET_IF(p2l_sg2_styled_act_bwd(dy, W + L.y[l], W + L.d[l], nz, c.noise_w, c.act_b, gd, W + L.dd[l],
-                                  dnz, W + L.part2, W + L.strips, B, c.res * c.res, c.cout, st));
+    // the maxima of the input-gradient conv's input come from the kernel that writes it: the activation
+    // backward (plain convs) or the blur transpose (up convs)
+    float* am_gd = hand ? W + L.amax_b + (size_t)(2 * l) * B * P2L_SG2_AMAX_SLOTS : nullptr;
+    float* am_du = hand ? W + L.amax_b + (size_t)(2 * l + 1) * B * P2L_SG2_AMAX_SLOTS : nullptr;
+    RET_IF(p2l_sg2_styled_act_bwd_amax(dy, W + L.y[l], W + L.d[l], nz, c.noise_w, c.act_b, gd, W + L.dd[l],
+                                       dnz, W + L.part2, W + L.strips, B, c.res * c.res, c.cout,
+                                       c.up ? nullptr : am_gd, st));
     // gx may alias dy (when !gy_ready): the dgrad below writes gx only after gd was produced
     float* gout = (dy == gx) ? gy : gx;
     if (c.up) {
-      RET_IF(p2l_sg2_blur_bwd(gd, tmp, B, c.res, c.res, c.cout, st));
+      RET_IF(p2l_sg2_blur_bwd_amax(gd, tmp, B, c.res, c.res, c.cout, am_du, st));
       P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
       d.ups = 3; d.ext = 1;
       // unfused temp must not alias the conv input (tmp): use gd
       RET_IF(dgrad_scale(d, tmp, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], gd, part,
-                         scratch, B, res_in, W + L.cws, L.cws_floats, st));
+                         scratch, B, res_in, W + L.cws, L.cws_floats, am_du, st));
     } else {
       P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
       RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, part,
-                         scratch, B, res_in, W + L.cws, L.cws_floats, st));
+                         scratch, B, res_in, W + L.cws, L.cws_floats, am_gd, st));
     }
     if (gout != gx) { float* t2 = gy; gy = gx; gx = t2; }   // keep "gx = gradient for layer l-1"
     have_next = true;

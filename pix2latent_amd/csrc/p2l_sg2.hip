@@ -87,6 +87,28 @@ __global__ void demod_bwd_kernel(const float* s, const float* Wsq, const float* 
   ds[i] = accumulate ? ds[i] + r : r;
 }
 
+// ---- per-image maxima for the fp16 x 2 conv that READS a tensor these kernels write (P2LAmax.in) ----
+// The plan hands the reader [B][P2L_SG2_AMAX_SLOTS] partial maxima it zeroed before the producer ran.  A wave that
+// sits inside one image (all but the few at an image boundary) reduces its lanes and issues ONE atomic max on the
+// bit pattern (non-negative floats order like unsigned integers).  max is exact, so the result does not depend
+// on the order the waves arrive in: the reader's power-of-two scale -- and with it every bit of its output --
+// is what its own pass over the tensor would have given (tests/test_sg2_amax_gpu.py).
+__device__ __forceinline__ float absmax4s(float m, const f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void amax_commit(float m, int b, unsigned slot, float* amax_out) {
+  unsigned* dst = reinterpret_cast<unsigned*>(amax_out);
+  slot &= (P2L_SG2_AMAX_SLOTS - 1);
+  const int b0 = __builtin_amdgcn_readfirstlane(b);
+  // (the ballot counts ACTIVE lanes only: all 64 bits set = nobody left the kernel early and one image)
+  if (__ballot(b == b0) == ~0ull) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(dst + (size_t)b0 * P2L_SG2_AMAX_SLOTS + slot, __float_as_uint(m));
+  } else {
+    atomicMax(dst + (size_t)b * P2L_SG2_AMAX_SLOTS + slot, __float_as_uint(m));
+  }
+}
+
 // ---- FIR blur after the transposed conv ------------------------------------
 // u: [B, H+2, W+2, C] (rows/cols 0..H real, H+1 zero), y: [B, H, W, C]
 // pre = blur(u)[Y,X] * d[b,c] + nw * noise[b,Y*W+X] + bias[c] ;  y = lrelu(pre)*sqrt2
@@ -96,8 +118,12 @@ __device__ __forceinline__ float fir_a(int j) { return (j == 0 || j == 3) ? 0.25
 // A thread produces FOUR vertically adjacent outputs of one column x 4 channels: the 4-tap row
 // sums of the 7 input rows they share are formed once (28 loads per 4 outputs instead of 64:
 // round 2's one-output-per-thread form ran at 1.8 TB/s, request-bound, profiles/round3_sg2_*).
+// amax_out: the maxima of |y * next_s[b,c]| (next_s = the style the next conv fuses into its prologue; NULL: of |y|)
+// go there (amax_commit above).  ONE kernel for both forms (a run-time test, not a template parameter): the
+// arithmetic that produces y must be the same instructions with and without the hand-over.
 __global__ void blur_fwd_kernel(const float* u, const float* d, const float* noise, float nw,
-                                const float* bias, float* y, int Bn, int H, int W, int C) {
+                                const float* bias, float* y, int Bn, int H, int W, int C,
+                                const float* next_s, float* amax_out) {
   const int C4 = C >> 2, H4 = H >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Bn * H4 * W * C4) return;
@@ -125,6 +151,9 @@ __global__ void blur_fwd_kernel(const float* u, const float* d, const float* noi
   }
   const f32x4 d4 = *reinterpret_cast<const f32x4*>(d + (size_t)b * C + c);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 ns4 = {1.f, 1.f, 1.f, 1.f};
+  if (amax_out && next_s) ns4 = *reinterpret_cast<const f32x4*>(next_s + (size_t)b * C + c);
+  float m = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int Y = Y0 + k;
@@ -138,7 +167,9 @@ __global__ void blur_fwd_kernel(const float* u, const float* d, const float* noi
     v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
     v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
     *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X) * C + c) = v;
+    if (amax_out) m = absmax4s(m, next_s ? v * ns4 : v);
   }
+  if (amax_out) amax_commit(m, b, blockIdx.x * 4u + (threadIdx.x >> 6), amax_out);
 }
 
 // activation backward of a styled conv (with or without blur): given dy and the saved
@@ -150,6 +181,7 @@ struct ActBwdK {
   const float* dy; const float* y; const float* d; const float* noise; const float* bias;
   float* gd; float* partial; float* dnoise;
   float nw; int Bn, P, C, nblk;
+  float* amax_out;     // [Bn][P2L_SG2_AMAX_SLOTS] maxima of |gd| (zeroed by the caller), or NULL
 };
 constexpr int AB_SLAB = 256;
 // SW = channel strip width per block (64, or 32 for the 32-channel FFHQ 1024^2 layers)
@@ -162,6 +194,7 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
   const f32x4 d4 = *reinterpret_cast<const f32x4*>(k.d + (size_t)b * k.C + c);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(k.bias + c);
   f32x4 acc = {0, 0, 0, 0};
+  float amax = 0.f;
   const int p_end = min(k.P, (slab + 1) * AB_SLAB);
   for (int p = slab * AB_SLAB + pl; p < p_end; p += PL) {
     const size_t o = ((size_t)b * k.P + p) * k.C + c;
@@ -175,7 +208,9 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
     const float nz = k.noise ? k.nw * k.noise[(size_t)b * k.P + p] : 0.f;
     const f32x4 cval = (pre - b4 - nz) / d4;
     acc += g * cval;
-    *reinterpret_cast<f32x4*>(k.gd + o) = g * d4;
+    const f32x4 gd4 = g * d4;
+    *reinterpret_cast<f32x4*>(k.gd + o) = gd4;
+    amax = absmax4s(amax, gd4);
     if (k.dnoise) {
       // channel sum of g1 for this pixel: CL lanes x float4 of this SW-channel strip
       float sn = (g.x + g.y) + (g.z + g.w);
@@ -193,6 +228,7 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const ActBwdK k) {
     for (int j = 1; j < PL; ++j) a += red[j * CL + cl];
     *reinterpret_cast<f32x4*>(k.partial + ((size_t)b * k.nblk + slab) * k.C + c) = a;
   }
+  if (k.amax_out) amax_commit(amax, b, (slab * gridDim.y + blockIdx.y) * 4u + (tid >> 6), k.amax_out);
 }
 // grid (cdiv(C,64), B); 16 segments x 16 channel-float4 lanes: each thread adds its
 // segment's slabs in order, then the segments are combined in a fixed order
@@ -226,7 +262,7 @@ __global__ void noise_grad_finish_kernel(const float* strips, float* dnoise, flo
 // transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d).  As the forward
 // kernel: four vertically adjacent rows of du per thread (rows yy0 .. yy0+3 of the H+2; the frame
 // height is even but not always a multiple of 4: rows past the end are skipped).
-__global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C) {
+__global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out) {
   const int C4 = C >> 2, UH = H + 2, UW = W + 2, UH4 = (UH + 3) >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Bn * UH4 * UW * C4) return;
@@ -252,6 +288,7 @@ __global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W,
     }
     hrow[r] = row;
   }
+  float m = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int yy = yy0 + k;
@@ -260,7 +297,9 @@ __global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc += hrow[k + 3 - j] * fir_a(j);       // Y = yy - j + 1 = yy0 + (k + 3 - j) - 2
     *reinterpret_cast<f32x4*>(du + ((((size_t)b * UH + yy) * UW + xx) * C4) * 4 + c) = acc;
+    if (amax_out) m = absmax4s(m, acc);
   }
+  if (amax_out) amax_commit(m, b, blockIdx.x * 4u + (threadIdx.x >> 6), amax_out);
 }
 
 // RGB skip: out[B,2h,2w,16] = upfirdn2d(skip[B,h,w,16], up=2, pad=(2,1)); per dim:
@@ -388,14 +427,20 @@ extern "C" int p2l_sg2_demod_bwd(const float* s, const float* Wsq, const float* 
                      dd, ds, Bn, Cin, Cout, accumulate);
   return p2l_check_launch();
 }
+extern "C" int p2l_sg2_blur_fwd_amax(const float* u, const float* d, const float* noise, float nw,
+                                     const float* bias, float* y, int Bn, int H, int W, int C,
+                                     const float* next_s, float* amax_out, void* stream) {
+  if (C % 4) return P2L_EINVAL;
+  if (H % 4) return P2L_EINVAL;
+  const dim3 grid(cdiv((size_t)Bn * (H / 4) * W * (C / 4), 256));
+  hipLaunchKernelGGL(blur_fwd_kernel, grid, dim3(256), 0, ST(stream), u, d, noise, nw, bias, y, Bn, H, W, C,
+                     amax_out ? next_s : nullptr, amax_out);
+  return p2l_check_launch();
+}
 extern "C" int p2l_sg2_blur_fwd(const float* u, const float* d, const float* noise, float nw,
                                 const float* bias, float* y, int Bn, int H, int W, int C,
                                 void* stream) {
-  if (C % 4) return P2L_EINVAL;
-  if (H % 4) return P2L_EINVAL;
-  hipLaunchKernelGGL(blur_fwd_kernel, dim3(cdiv((size_t)Bn * (H / 4) * W * (C / 4), 256)), dim3(256), 0,
-                     ST(stream), u, d, noise, nw, bias, y, Bn, H, W, C);
-  return p2l_check_launch();
+  return p2l_sg2_blur_fwd_amax(u, d, noise, nw, bias, y, Bn, H, W, C, nullptr, nullptr, stream);
 }
 extern "C" int p2l_sg2_act_bwd_nblk(int P) { return cdiv(P, AB_SLAB); }
 // partial: Bn*nblk*C floats; strips: (C/sw)*Bn*P floats, sw = C%64 ? 32 : 64 (only when dnoise != NULL)
@@ -403,12 +448,20 @@ extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const flo
                                       const float* noise, float nw, const float* bias, float* gd,
                                       float* dd, float* dnoise, float* partial, float* strips,
                                       int Bn, int P, int C, void* stream) {
+  return p2l_sg2_styled_act_bwd_amax(dy, y, d, noise, nw, bias, gd, dd, dnoise, partial, strips, Bn, P, C, nullptr,
+                                     stream);
+}
+extern "C" int p2l_sg2_styled_act_bwd_amax(const float* dy, const float* y, const float* d,
+                                           const float* noise, float nw, const float* bias, float* gd,
+                                           float* dd, float* dnoise, float* partial, float* strips,
+                                           int Bn, int P, int C, float* amax_out, void* stream) {
   if (C % 32) return P2L_EINVAL;
   const int sw = (C % 64) ? 32 : 64;
   ActBwdK k{};
   k.dy = dy; k.y = y; k.d = d; k.noise = noise; k.bias = bias; k.gd = gd; k.partial = partial;
   k.dnoise = dnoise ? strips : nullptr;
   k.nw = nw; k.Bn = Bn; k.P = P; k.C = C; k.nblk = cdiv(P, AB_SLAB);
+  k.amax_out = amax_out;
   if (sw == 64)
     hipLaunchKernelGGL(styled_act_bwd_kernel<64>, dim3(k.nblk, C / 64, Bn), dim3(256), 0, ST(stream), k);
   else
@@ -420,12 +473,16 @@ extern "C" int p2l_sg2_styled_act_bwd(const float* dy, const float* y, const flo
                        ST(stream), strips, dnoise, nw, C / sw, (size_t)Bn * P);
   return p2l_check_launch();
 }
+extern "C" int p2l_sg2_blur_bwd_amax(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out,
+                                     void* stream) {
+  if (C % 4) return P2L_EINVAL;
+  const dim3 grid(cdiv((size_t)Bn * ((H + 5) / 4) * (W + 2) * (C / 4), 256));
+  hipLaunchKernelGGL(blur_bwd_kernel, grid, dim3(256), 0, ST(stream), g, du, Bn, H, W, C, amax_out);
+  return p2l_check_launch();
+}
 extern "C" int p2l_sg2_blur_bwd(const float* g, float* du, int Bn, int H, int W, int C,
                                 void* stream) {
-  if (C % 4) return P2L_EINVAL;
-  hipLaunchKernelGGL(blur_bwd_kernel, dim3(cdiv((size_t)Bn * ((H + 5) / 4) * (W + 2) * (C / 4), 256)),
-                     dim3(256), 0, ST(stream), g, du, Bn, H, W, C);
-  return p2l_check_launch();
+  return p2l_sg2_blur_bwd_amax(g, du, Bn, H, W, C, nullptr, stream);
 }
 extern "C" int p2l_sg2_rgb_up_fwd(const float* skip, float* out, int Bn, int h, int w, void* stream) {
   hipLaunchKernelGGL(rgb_up_fwd_kernel, dim3(cdiv((size_t)Bn * 4 * h * w, 256)), dim3(256), 0,

@@ -139,7 +139,8 @@ class StyleGAN2(nn.Module):
         self._keep = []
         self._desc = N.P2LStyleGAN2()
         self._wfmt = N.default_wfmt() if wfmt is None else wfmt
-        self._desc.wfmt = self._wfmt
+        # (P2L_AMAX=0: every fp16 x 2 launch reduces the maxima of its input itself -- model descriptor flag)
+        self._desc.wfmt = self._wfmt | (N.WFMT_FLAG_NO_AMAX if N.default_no_amax() else 0)
         self._lanes = {}         # lane -> _Lane: arena + image staging of one stream (lanes.py)
         self.ws_generation = 0
         self._pack(weights)

@@ -1,0 +1,123 @@
+"""Maxima handed between the kernels of the StyleGAN2 plan (csrc/p2l_plan_sg2.hip, round 6): the elementwise
+tails (blur + demod + noise + bias + lrelu; activation backward; blur transpose) leave the per-image max |.| of
+what they write -- with the next conv's style applied where it fuses one -- for the fp16 x 2 conv that reads it,
+which then runs no pass of its own over its input (35 passes, 6.6 % of the FFHQ-1024 step).  max is exact, so
+nothing may change: the plan with the hand-over gives the BITS of the plan without it."""
+import ctypes as ct
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SLOTS = 64
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def _lrelu(v):
+    return torch.where(v > 0, v, 0.2 * v) * 1.41421356237
+
+
+# (B, H, C): waves inside one image; waves straddling two images (3 x 2*8*8 items); 32 / 128 channels
+@pytest.mark.parametrize('B,H,C', [(2, 16, 64), (3, 8, 32), (5, 8, 32), (1, 32, 128), (3, 64, 32)])
+def test_tail_kernels_leave_exact_maxima(dev, B, H, C):
+    from pix2latent_amd import _native as N
+    lib = N.lib()
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    mag = torch.logspace(-3, 2, B).view(B, 1, 1, 1)        # every image its own magnitude
+    u = (torch.randn(B, H + 2, H + 2, C, generator=g) * mag).to(dev)
+    u[:, H + 1:, :, :] = 0
+    u[:, :, H + 1:, :] = 0
+    d = (0.5 + torch.rand(B, C, generator=g)).to(dev)
+    s_next = (torch.randn(B, C, generator=g) * 3).to(dev)
+    noise = torch.randn(B, H * H, generator=g).to(dev)
+    bias = (0.1 * torch.randn(C, generator=g)).to(dev)
+    st = N.stream()
+    # ---- blur forward: y and max |y * s_next|
+    y0 = torch.empty(B, H, H, C, device=dev)
+    y1 = torch.empty_like(y0)
+    N.check(lib.p2l_sg2_blur_fwd(N.ptr(u), N.ptr(d), N.ptr(noise), ct.c_float(0.3), N.ptr(bias), N.ptr(y0), B, H, H,
+                                 C, st), 'blur_fwd')
+    for ns in (s_next, None):
+        am = torch.zeros(B, SLOTS, device=dev)
+        N.check(lib.p2l_sg2_blur_fwd_amax(N.ptr(u), N.ptr(d), N.ptr(noise), ct.c_float(0.3), N.ptr(bias), N.ptr(y1),
+                                          B, H, H, C, N.ptr(ns) if ns is not None else None, N.ptr(am), st),
+                'blur_fwd_amax')
+        assert torch.equal(y0, y1)
+        want = (y0 * ns.view(B, 1, 1, C) if ns is not None else y0).abs().amax(dim=(1, 2, 3))
+        assert torch.equal(am.amax(dim=1), want), (am.amax(dim=1), want)
+    # ---- activation backward: gd and max |gd|
+    P = H * H
+    dy = (torch.randn(B, H, H, C, generator=g) * mag.flip(0)).to(dev)
+    nblk = lib.p2l_sg2_act_bwd_nblk(P)
+    sw = 32 if C % 64 else 64
+    outs = []
+    for with_am in (False, True):
+        gd = torch.empty(B, H, H, C, device=dev)
+        dd = torch.empty(B, C, device=dev)
+        dn = torch.empty(B, P, device=dev)
+        part = torch.empty(B * nblk * C, device=dev)
+        strips = torch.empty((C // sw) * B * P, device=dev)
+        am = torch.zeros(B, SLOTS, device=dev)
+        N.check(lib.p2l_sg2_styled_act_bwd_amax(N.ptr(dy), N.ptr(y0), N.ptr(d), N.ptr(noise), ct.c_float(0.3),
+                                                N.ptr(bias), N.ptr(gd), N.ptr(dd), N.ptr(dn), N.ptr(part),
+                                                N.ptr(strips), B, P, C, N.ptr(am) if with_am else None, st),
+                'styled_act_bwd_amax')
+        outs.append((gd, dd, dn))
+        if with_am:
+            assert torch.equal(am.amax(dim=1), gd.abs().amax(dim=(1, 2, 3)))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # ---- blur transpose: the whole (H+2)^2 frame
+    gd = outs[0][0]
+    du0 = torch.empty(B, H + 2, H + 2, C, device=dev)
+    du1 = torch.empty_like(du0)
+    am = torch.zeros(B, SLOTS, device=dev)
+    N.check(lib.p2l_sg2_blur_bwd(N.ptr(gd), N.ptr(du0), B, H, H, C, st), 'blur_bwd')
+    N.check(lib.p2l_sg2_blur_bwd_amax(N.ptr(gd), N.ptr(du1), B, H, H, C, N.ptr(am), st), 'blur_bwd_amax')
+    assert torch.equal(du0, du1)
+    assert torch.equal(am.amax(dim=1), du0.abs().amax(dim=(1, 2, 3)))
+
+
+@pytest.mark.parametrize('widths', ['wide', 'narrow'])
+@pytest.mark.parametrize('search', ['z', 'w+'])
+def test_plan_with_handover_gives_the_bits_of_the_plan_without(dev, monkeypatch, widths, search):
+    """image, d latent and d noise of a 64^2 generator (the width table of the real models | the 128 / 64 / 32
+    channel tail of FFHQ-1024): P2L_AMAX=1 (default) vs P2L_AMAX=0 (every launch reduces its own maxima)"""
+    warnings.simplefilter('ignore')
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.model.stylegan2 import StyleGAN2
+    from pix2latent_amd import _native as N
+    W = S.stylegan2_weights(64, 0, channels={'wide': None, 'narrow': {4: 128, 8: 128, 16: 64, 32: 32, 64: 32}}[widths])
+    g = torch.Generator().manual_seed(3)
+    B = 3
+
+    def run(amax):
+        monkeypatch.setenv('P2L_AMAX', amax)
+        model = StyleGAN2(model='cars', search=search, weights=W, size=64, device=dev)
+        assert bool(model._desc.wfmt & N.WFMT_FLAG_NO_AMAX) == (amax == '0')
+        n_noise = sum(s[-2] * s[-1] for s in model.noise_shape)
+        gg = torch.Generator().manual_seed(5)
+        probe = (torch.randn(B, 3, 64, 64, generator=gg) / 64).to(dev)
+        noise = torch.randn(B, n_noise, generator=gg).to(dev).requires_grad_(True)
+        if search == 'w+':
+            lat = (model.latent_mean.view(1, 1, 512) + 0.3 * torch.randn(B, model._desc.n_latent, 512,
+                                                                        generator=gg).to(dev)).requires_grad_(True)
+            out = model.forward_w(lat, noise)
+        else:
+            lat = torch.randn(B, 512, generator=gg).to(dev).requires_grad_(True)
+            out = model.forward_z(lat, noises=model.reshape_noise(noise))
+        (out * probe).sum().backward()
+        return out.detach().clone(), lat.grad.clone(), None if noise.grad is None else noise.grad.clone()
+    on = run('1')
+    off = run('0')
+    assert torch.isfinite(on[0]).all() and on[1].abs().max() > 0
+    for a, b, what in zip(on, off, ('image', 'd latent', 'd noise')):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b), (what, (a - b).abs().max().item())
