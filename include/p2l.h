@@ -882,6 +882,11 @@ typedef struct P2LStyleGAN2 {
   int32_t reserved1;
 } P2LStyleGAN2;
 size_t p2l_sg2_ws_bytes(const P2LStyleGAN2* m, int Bn);
+/* The per-layer noise between the reference's per-sample layout [Bn][noise_total] (model/stylegan2.py:128-138
+ * `reshape_noise` slices it per layer) and the layer-major one the synthesis entry points take (layer l at
+ * Bn*noise_off[l], [Bn][h*w]); to_layer_major = 0: the transpose (gradients on their way back). */
+int p2l_sg2_noise_relayout(const P2LStyleGAN2* m, const float* src, float* dst, int Bn, int to_layer_major,
+                           void* stream);
 /* latent: [B, n_latent, 512] w+ rows (broadcast w for z-mode); noise: [B, noise_total]
  * explicit per-layer noise; img16: [B,size,size,16] clamped image */
 int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent, const float* noise, int Bn,

@@ -41,11 +41,33 @@ struct SgLayout {
 };
 constexpr int kAmaxCompactFrom = 4096;
 
+thread_local int g_sg_wfmt = P2L_WFMT_F32;   // the model's weight format: set by sg_layout
+
+P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
+  P2LConv d{};
+  d.wfmt = (taps == 9) ? (g_sg_wfmt & 0xF) : P2L_WFMT_F32;
+  d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.Cout = Cout; d.taps = taps;
+  d.x_ld = Cin; d.alpha = 1.f; d.y_ld = Cout; d.yp_ld = Cout; d.n_store = Cout; d.splitk = 1;
+  return d;
+}
+// The 4^2 ... 16^2 layers of a few candidates are a handful of blocks each running the whole K loop (8^2
+// 512 -> 512 at 3 candidates: 81 - 93 us for 3 us of work): K slices as the BigGAN plan takes them, a function
+// of the layer SHAPE only (p2l_conv_suggest_splitk), the slices summed in fixed order by the finish kernel
+// that also runs the styled epilogue.  Stride-1 convs only (the sub-pixel kernels do not slice).
+void suggest_split(P2LConv& d, size_t ws_floats_have) {
+  d.splitk = 1;
+  if (d.taps != 9 || d.ups != 0) return;
+  d.splitk = p2l_conv_suggest_splitk(&d);
+  if (d.splitk > 1 && ws_floats_have && p2l_conv_workspace_bytes(&d) > ws_floats_have * sizeof(float)) d.splitk = 1;
+}
+
 int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   if (!m || B < 1 || m->n_conv < 1 || m->n_conv > P2L_SG2_MAX_CONVS || m->n_rgb > P2L_SG2_MAX_RGBS)
     return P2L_EINVAL;
+  g_sg_wfmt = m->wfmt;
   Arena a;
   size_t max_act = 0, max_u = 0, max_c = 0, max_part = 0, max_part2 = 0, max_strips = 0;
+  size_t max_cws = (size_t)B * 64;
   for (int l = 0; l < m->n_conv; ++l) {
     const P2LSg2Conv& c = m->conv[l];
     const size_t P = (size_t)c.res * c.res;
@@ -61,7 +83,22 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
       if (u > max_u) max_u = u;
     }
     if (cm > max_c) max_c = cm;
-    const size_t p1 = 2 * (size_t)B * cdiv(P, 128) * cm;            // fused arb partials
+    size_t p1 = 2 * (size_t)B * cdiv(P, 128) * cm;                  // fused arb partials
+    if (!c.up) {
+      // K-sliced forms of the stride-1 layers: slices behind the 256 B of maxima per image, one partial of the
+      // fused modulation backward per 2x2 quad
+      P2LConv f = mk(B, c.res, c.cin, c.cout, 9);
+      f.pro = P2L_PRO_AFFINE; f.pro_bstride = c.cin;
+      suggest_split(f, 0);
+      size_t w = p2l_conv_workspace_bytes(&f) / sizeof(float);
+      if (w > max_cws) max_cws = w;
+      P2LConv g = mk(B, c.res, c.cout, c.cin, 9);
+      suggest_split(g, 0);
+      w = p2l_conv_workspace_bytes(&g) / sizeof(float);
+      if (w > max_cws) max_cws = w;
+      const size_t pq = 2 * (size_t)B * p2l_conv_arb_nblk_ws(&g) * cm;
+      if (pq > p1) p1 = pq;
+    }
     if (p1 > max_part) max_part = p1;
     const size_t p2 = (size_t)B * p2l_sg2_act_bwd_nblk((int)P) * c.cout;
     if (p2 > max_part2) max_part2 = p2;
@@ -89,7 +126,7 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   L.part2 = a.take(max_part2);
   L.strips = a.take(max_strips);
   L.scratch = a.take((size_t)B * max_c * 2);
-  L.cws_floats = (size_t)B * 64;
+  L.cws_floats = max_cws;
   L.cws = a.take(L.cws_floats);
   L.amax_zero_floats = (size_t)3 * m->n_conv * B * P2L_SG2_AMAX_SLOTS;
   L.amax_f = a.take(L.amax_zero_floats);
@@ -108,22 +145,15 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   return P2L_OK;
 }
 
-thread_local int g_sg_wfmt = P2L_WFMT_F32;   // set at the synthesis entry points
-
-P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
-  P2LConv d{};
-  d.wfmt = (taps == 9) ? (g_sg_wfmt & 0xF) : P2L_WFMT_F32;
-  d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.Cout = Cout; d.taps = taps;
-  d.x_ld = Cin; d.alpha = 1.f; d.y_ld = Cout; d.yp_ld = Cout; d.n_store = Cout; d.splitk = 1;
-  return d;
-}
 
 // input-gradient conv + modulation backward (dx = dx' * s + extra ; ds = sum_p dx' * x)
 // amax_in: [B][P2L_SG2_AMAX_SLOTS] maxima of gin left by the kernel that wrote it, or NULL
 int dgrad_scale(P2LConv& d, const float* gin, const float* w, const float* x, const float* s,
                 int C, const float* extra, float* dx, float* ds, float* tmp, float* part,
                 float* scratch, int B, int Hout, float* cws, size_t cws_floats, const float* amax_in, void* st) {
-  if (p2l_conv_arb_fusable(&d)) {
+  suggest_split(d, cws_floats);
+  const bool split_fused = d.splitk > 1 && p2l_conv_arb_split_fusable(&d);
+  if (split_fused || (d.splitk == 1 && p2l_conv_arb_fusable(&d))) {
     P2LArb a{};
     a.amax.in = amax_in; a.amax.in_n = amax_in ? P2L_SG2_AMAX_SLOTS : 0;
     a.x = x; a.x_ld = C; a.s = s; a.t = s; a.st_bstride = C;
@@ -193,7 +223,6 @@ extern "C" int p2l_sg2_mapping_bwd(const P2LStyleGAN2* m, const float* z, const 
 extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
                                      const float* noise, int B, void* ws, size_t ws_bytes,
                                      float* img16, void* st) {
-  g_sg_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   SgLayout L;
   RET_IF(sg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !latent || !noise || !img16) return P2L_EWS;
@@ -248,6 +277,7 @@ extern "C" int p2l_sg2_synthesis_fwd(const P2LStyleGAN2* m, const float* latent,
     const float* next_s = to_next ? W + L.s[l + 1] : nullptr;
     if (!c.up) {
       d.act = P2L_ACT_LRELU_SQRT2;
+      suggest_split(d, L.cws_floats);
       ex.oscale = W + L.d[l]; ex.oscale_bstride = c.cout; ex.noise = nz; ex.noise_w = c.noise_w;
       int ns = to_next ? p2l_conv_amax_slots(&d) : 0;
       if (ns > 0 && (size_t)B * (ns + 256) <= L.amax_c_floats) {
@@ -299,7 +329,6 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
                                      const float* noise, int B, void* ws, size_t ws_bytes,
                                      const float* dimg16, float* dlatent, float* dnoise,
                                      void* st) {
-  g_sg_wfmt = m ? m->wfmt : P2L_WFMT_F32;
   SgLayout L;
   RET_IF(sg_layout(m, B, L));
   if (!ws || ws_bytes < L.total * sizeof(float) || !dimg16 || !dlatent) return P2L_EWS;

@@ -121,3 +121,27 @@ def test_plan_with_handover_gives_the_bits_of_the_plan_without(dev, monkeypatch,
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.equal(a, b), (what, (a - b).abs().max().item())
+
+
+def test_noise_relayout_is_the_slices_and_cat_of_the_reference(dev):
+    """forward_w's noise path in one launch each way: the same values as reshape_noise + cat (reference
+    model/stylegan2.py:128-138) and, backwards, as autograd through them"""
+    warnings.simplefilter('ignore')
+    from pix2latent_amd.utils import synthetic as S
+    from pix2latent_amd.model.stylegan2 import StyleGAN2, _NoiseLayoutFn
+    model = StyleGAN2(model='cars', search='w+', weights=S.stylegan2_weights(64, 0), size=64, device=dev)
+    total = sum(s[-2] * s[-1] for s in model.noise_shape)
+    g = torch.Generator().manual_seed(1)
+    for B in (1, 3, 5):
+        x = torch.randn(B, total, generator=g).to(dev)
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        got = _NoiseLayoutFn.apply(a, model)
+        want = torch.cat([n.reshape(B, -1).reshape(-1) for n in model.reshape_noise(b)])
+        assert torch.equal(got, want)
+        probe = torch.randn(want.shape, generator=g).to(dev)
+        (got * probe).sum().backward()
+        (want * probe).sum().backward()
+        assert torch.equal(a.grad, b.grad)
+    with pytest.raises(AssertionError):
+        _NoiseLayoutFn.apply(torch.zeros(2, total - 4, device=dev), model)
