@@ -1223,9 +1223,29 @@ static bool direct_h2r(const P2LConv* d) {
 }
 
 
+// K slices of the sub-pixel INPUT-GRADIENT form of a stride-2 transposed conv (ups 3, ext 1: StyleGAN2's up
+// convs) in the fp16 x 2 kernel, whose chunk loop walks (phase plane, channel chunk) and takes a slice like the
+// stride-1 kernel does: the 8^2 ... 32^2 layers of a few candidates were 8 - 32 blocks running 128 chunks each
+// (0.20 - 0.23 ms for 5 - 50 us of work, profiles/round6_sg2_1024_layers.txt).  Shape and format only.
+static int subpix_bwd_split(const P2LConv* d) {
+  if (d->ups != 3 || !d->ext || !direct_h2(d)) return 1;
+  ConvK k{};
+  if (choose_tile(d, k) != P2L_OK || k.partial) return 1;
+  const long hw = (long)(d->H >> 1) * (d->W >> 1);
+  int s = p2f((long)d->Cin * 16 / 128);
+  const int g = p2f(524288L / (hw * d->Cout > 0 ? hw * d->Cout : 1));
+  if (g < s) s = g;
+  const int cap = hw >= 256 ? 4 : 8;
+  if (s > cap) s = cap;
+  const int nchunks = 4 * (d->Cin / 16);
+  while (s > 1 && nchunks / s < 8) s >>= 1;
+  return s <= 2 ? 1 : s;
+}
+
 extern "C" int p2l_conv_suggest_splitk(const P2LConv* d) {
   ConvK k{};
-  if (!d || d->ups >= 2) return 1;       // sub-pixel modes never split K
+  if (d && d->ups == 3 && d->ext) return subpix_bwd_split(d);
+  if (!d || d->ups >= 2) return 1;       // the other sub-pixel modes never split K
   if (choose_tile(d, k) == P2L_OK && wino_split(d) > 1 && !(d->form & P2L_FORM_WINO_ANY) &&
       (d->H / 8) * (d->W / 16) * (d->Cout / 64) < 64)
     return wino_split(d);                // small-grid Winograd layer: a function of the shape only
@@ -1267,6 +1287,7 @@ extern "C" int p2l_conv_amax_slots(const P2LConv* d) {
     }
     return (d->H / 16) * (d->W / 16) * (d->Cout / 64) * 8;     // (one partial per wave)
   }
+  if (d->ups == 3 && effective_splitk(d) > 1) return 0;   // (the finish kernel runs on the low-res grid: no slots)
   if (effective_splitk(d) > 1) {
     // split-K launch of the direct kernels: a finish kernel writes the tensor, one partial per block of
     // 64 items -- (quad, 4 channels) for the 16-byte kernel, (quad, channel) for the scalar one -- when
@@ -1302,6 +1323,11 @@ extern "C" size_t p2l_conv_workspace_bytes(const P2LConv* d) {
 
 // the split-K factor conv_launch_impl ends up with for d->splitk
 static int effective_splitk(const P2LConv* d) {
+  if (d->splitk > 1 && d->ups == 3 && d->ext && subpix_bwd_split(d) > 1) {
+    const int nchunks = 4 * (d->Cin / 16);
+    const int sk = d->splitk > nchunks ? nchunks : d->splitk;
+    return cdiv(nchunks, cdiv(nchunks, sk));
+  }
   if (d->splitk > 1 && d->ups == 0 && wino_split(d) == d->splitk && wino_shape(d)) return d->splitk;
   if (d->splitk <= 1 || d->ups >= 2 || wino_shape(d) || pw_any(d)) return 1;
   const int kc = (d->taps == 9) ? 16 : (d->Cin % 32 == 0 ? 32 : 16);
@@ -1426,7 +1452,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   if (k.splitk > 1) {
     const size_t need = (use_h2 ? h2_bytes : 0) + (size_t)k.splitk * d->B * d->H * d->W * d->Cout * sizeof(float);
     if (!workspace || ws_bytes < need) return P2L_EWS;
-    if (arb) k.arb_nblk = (d->H >> 1) * (d->W >> 1);    // finish kernel: one partial per quad
+    if (arb) k.arb_nblk = p2l_conv_arb_nblk_ws(d);      // finish kernel: one partial per quad
   }
   hipStream_t st = (hipStream_t)stream;
 
@@ -1558,8 +1584,13 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
   }
   // ---- sub-pixel modes (ups 2 = forward, 3 = input-gradient of an upsampled conv) ----
   if (d->ups >= 2) {
-    if (d->taps != 9 || k.splitk != 1 || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
-        (arb && k.tb_log != 0) || (d->ups == 2 && (res || mask)))
+    // K slices: the input-gradient form of a transposed conv in the fp16 x 2 kernel only (subpix_bwd_split);
+    // the fused modulation / activation backward of a sliced launch runs in the finish kernel, per quad,
+    // so multi-image tiles are no obstacle there
+    const int sk3 = (d->taps == 9 && d->splitk > 1) ? ((d->ups == 3 && d->ext) ? effective_splitk(d) : 1) : 1;
+    if (sk3 > 1 && !(use_h2 && direct_h2(d))) return P2L_EWS;
+    if (d->taps != 9 || (k.splitk != 1 && sk3 == 1) || d->Cin % 16 || d->pool != P2L_POOL_NONE ||
+        (arb && k.tb_log != 0 && sk3 == 1) || (d->ups == 2 && (res || mask)))
       return P2L_EUNSUP;
     {
       int gH, gW;
@@ -1578,7 +1609,8 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
     k.sp_mode = d->ups - 1;
     k.sp_ncc = d->Cin / 16;
     k.nchunks = (d->ups == 3) ? 4 * k.sp_ncc : k.sp_ncc;
-    k.chunks_per_split = k.nchunks;
+    k.chunks_per_split = cdiv(k.nchunks, sk3);
+    k.splitk = sk3;
     k.ups = 0;
     const int a_rows_sp = (1 << k.tb_log) * ((1 << k.th_log) + 2) * ((1 << k.tw_log) + 2);
     const bool small_sp = (a_rows_sp * 4 <= 3 * 256) && k.tb_log == 0;
@@ -1596,6 +1628,18 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
         if (rc) return rc;
       }
       rc = p2l_h2_launch(kh, d->pro, 4, bn, small_sp, st);
+      if (rc == P2L_OK && k.splitk > 1) {
+        // the slices meet in the finish kernel of the direct path, on the low-res grid this launch tiled
+        const bool arb_al = !arb || (k.arb_x_ld % 4 == 0 && (!k.arb_skip || k.arb_skip_ld % 4 == 0));
+        if (finish_v4_ok(d) && arb_al) {
+          const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * (k.n_store >> 2);
+          hipLaunchKernelGGL(conv_splitk_finish_v4, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+        } else {
+          const size_t total = (size_t)k.B * (k.H >> 1) * (k.W >> 1) * k.n_store;
+          hipLaunchKernelGGL(conv_splitk_finish, dim3(cdiv(total, 64)), dim3(256), 0, st, k);
+        }
+        rc = p2l_check_launch();
+      }
       if (prof_slot >= 0) {
         g_prof.nprod[prof_slot] = 3;
         g_prof.fam[prof_slot] = P2L_PROF_FAM_SUBPIX_H2;
@@ -1755,7 +1799,8 @@ extern "C" int p2l_conv_arb_split_fusable(const P2LConv* d) {
 
 extern "C" int p2l_conv_arb_nblk_ws(const P2LConv* d) {
   if (!d) return 0;
-  return effective_splitk(d) > 1 ? (d->H >> 1) * (d->W >> 1) : p2l_conv_arb_nblk(d);
+  const int sh = d->ups == 3 ? 2 : 1;       // (quads of the grid the finish kernel walks: low-res for ups 3)
+  return effective_splitk(d) > 1 ? (d->H >> sh) * (d->W >> sh) : p2l_conv_arb_nblk(d);
 }
 
 static int dgrad_arb_unsplit(const P2LConv* d, const P2LArb* arb, const float* dy, const float* w,

@@ -53,10 +53,11 @@ P2LConv mk(int B, int H, int Cin, int Cout, int taps) {
 // The 4^2 ... 16^2 layers of a few candidates are a handful of blocks each running the whole K loop (8^2
 // 512 -> 512 at 3 candidates: 81 - 93 us for 3 us of work): K slices as the BigGAN plan takes them, a function
 // of the layer SHAPE only (p2l_conv_suggest_splitk), the slices summed in fixed order by the finish kernel
-// that also runs the styled epilogue.  Stride-1 convs only (the sub-pixel kernels do not slice).
+// that also runs the styled epilogue.  Stride-1 convs and the input-gradient form of the up convs (the forward
+// sub-pixel kernel does not slice: its blockIdx.y is the output phase).
 void suggest_split(P2LConv& d, size_t ws_floats_have) {
   d.splitk = 1;
-  if (d.taps != 9 || d.ups != 0) return;
+  if (d.taps != 9 || !(d.ups == 0 || (d.ups == 3 && d.ext))) return;
   d.splitk = p2l_conv_suggest_splitk(&d);
   if (d.splitk > 1 && ws_floats_have && p2l_conv_workspace_bytes(&d) > ws_floats_have * sizeof(float)) d.splitk = 1;
 }
@@ -95,6 +96,14 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
       P2LConv g = mk(B, c.res, c.cout, c.cin, 9);
       suggest_split(g, 0);
       w = p2l_conv_workspace_bytes(&g) / sizeof(float);
+      if (w > max_cws) max_cws = w;
+      const size_t pq = 2 * (size_t)B * p2l_conv_arb_nblk_ws(&g) * cm;
+      if (pq > p1) p1 = pq;
+    } else {
+      P2LConv g = mk(B, c.res, c.cout, c.cin, 9);
+      g.ups = 3; g.ext = 1;
+      suggest_split(g, 0);
+      const size_t w = p2l_conv_workspace_bytes(&g) / sizeof(float);
       if (w > max_cws) max_cws = w;
       const size_t pq = 2 * (size_t)B * p2l_conv_arb_nblk_ws(&g) * cm;
       if (pq > p1) p1 = pq;
