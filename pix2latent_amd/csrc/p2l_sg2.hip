@@ -115,39 +115,58 @@ __device__ __forceinline__ void amax_commit(float m, int b, unsigned slot, float
 // blur(u)[Y,X] = sum_{j,i} a_j a_i u[Y+j-1, X+i-1],  a = [.25 .75 .75 .25]
 __device__ __forceinline__ float fir_a(int j) { return (j == 0 || j == 3) ? 0.25f : 0.75f; }
 
-// A thread produces FOUR vertically adjacent outputs of one column x 4 channels: the 4-tap row
-// sums of the 7 input rows they share are formed once (28 loads per 4 outputs instead of 64:
-// round 2's one-output-per-thread form ran at 1.8 TB/s, request-bound, profiles/round3_sg2_*).
+// A thread produces a 4 x 4 patch of outputs x 4 channels from the 7 x 7 inputs under it: 49 loads per 16
+// outputs.  (Round 2: one output per thread, 16 loads each, 1.8 TB/s; round 3: four vertically adjacent outputs,
+// 7 loads each, 2.3 TB/s -- 512^2 x 64 x 32 candidates, request-bound: every input element was fetched by four
+// threads through L2.)  The sums keep the order of those forms: horizontal taps i = 0..3 into a row sum,
+// vertical taps j = 0..3 over the row sums -- the same bits.
 // amax_out: the maxima of |y * next_s[b,c]| (next_s = the style the next conv fuses into its prologue; NULL: of |y|)
 // go there (amax_commit above).  ONE kernel for both forms (a run-time test, not a template parameter): the
 // arithmetic that produces y must be the same instructions with and without the hand-over.
-__global__ void blur_fwd_kernel(const float* u, const float* d, const float* noise, float nw,
-                                const float* bias, float* y, int Bn, int H, int W, int C,
-                                const float* next_s, float* amax_out) {
-  const int C4 = C >> 2, H4 = H >> 2;
+__global__ __launch_bounds__(256) void blur_fwd_kernel(const float* u, const float* d, const float* noise, float nw,
+                                                       const float* bias, float* y, int Bn, int H, int W, int C,
+                                                       const float* next_s, float* amax_out) {
+  const int C4 = C >> 2, H4 = H >> 2, W4 = W >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Bn * H4 * W * C4) return;
+  if (idx >= (size_t)Bn * H4 * W4 * C4) return;
   const int c = (int)(idx % C4) * 4;
   size_t p = idx / C4;
-  const int X = (int)(p % W);
-  p /= W;
+  const int X0 = (int)(p % W4) * 4;
+  p /= W4;
   const int Y0 = (int)(p % H4) * 4;
   const int b = (int)(p / H4);
   const int UW = W + 2, UH = H + 2;
-  f32x4 hrow[7];
+  const f32x4 zero = {0, 0, 0, 0};
+  f32x4 out[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) out[k][x] = zero;
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    const int yy = Y0 + r - 1;
-    f32x4 row = {0, 0, 0, 0};
+    const int yy = Y0 + r - 1;                       // (<= H + 1: inside the frame)
+    f32x4 h[4] = {zero, zero, zero, zero};
     if (yy >= 0) {
+      const float* row = u + (((size_t)b * UH + yy) * UW) * C + c;
+      f32x4 in[7];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int xx = X + i - 1;
-        if (xx < 0) continue;
-        row += *reinterpret_cast<const f32x4*>(u + (((size_t)b * UH + yy) * UW + xx) * C + c) * fir_a(i);
+      for (int i = 0; i < 7; ++i) {
+        const int xx = X0 + i - 1;                   // (<= W + 1)
+        in[i] = xx >= 0 ? *reinterpret_cast<const f32x4*>(row + (size_t)xx * C) : zero;
       }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (X0 + x + i - 1 >= 0) h[x] += in[x + i] * fir_a(i);
     }
-    hrow[r] = row;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = r - k;
+      if (j < 0 || j > 3) continue;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) out[k][x] += h[x] * fir_a(j);
+    }
   }
   const f32x4 d4 = *reinterpret_cast<const f32x4*>(d + (size_t)b * C + c);
   const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c);
@@ -157,17 +176,18 @@ __global__ void blur_fwd_kernel(const float* u, const float* d, const float* noi
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int Y = Y0 + k;
-    f32x4 acc = {0, 0, 0, 0};
+    f32x4 nz4 = zero;
+    if (noise) nz4 = *reinterpret_cast<const f32x4*>(noise + ((size_t)b * H + Y) * W + X0) * nw;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc += hrow[k + j] * fir_a(j);
-    const float nz = noise ? nw * noise[((size_t)b * H + Y) * W + X] : 0.f;
-    f32x4 v = acc * d4 + b4 + nz;
-    v.x *= v.x > 0.f ? kSqrt2 : kSlope * kSqrt2;
-    v.y *= v.y > 0.f ? kSqrt2 : kSlope * kSqrt2;
-    v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
-    v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
-    *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X) * C + c) = v;
-    if (amax_out) m = absmax4s(m, next_s ? v * ns4 : v);
+    for (int x = 0; x < 4; ++x) {
+      f32x4 v = out[k][x] * d4 + b4 + nz4[x];
+      v.x *= v.x > 0.f ? kSqrt2 : kSlope * kSqrt2;
+      v.y *= v.y > 0.f ? kSqrt2 : kSlope * kSqrt2;
+      v.z *= v.z > 0.f ? kSqrt2 : kSlope * kSqrt2;
+      v.w *= v.w > 0.f ? kSqrt2 : kSlope * kSqrt2;
+      *reinterpret_cast<f32x4*>(y + (((size_t)b * H + Y) * W + X0 + x) * C + c) = v;
+      if (amax_out) m = absmax4s(m, next_s ? v * ns4 : v);
+    }
   }
   if (amax_out) amax_commit(m, b, blockIdx.x * 4u + (threadIdx.x >> 6), amax_out);
 }
@@ -259,45 +279,67 @@ __global__ void noise_grad_finish_kernel(const float* strips, float* dnoise, flo
   dnoise[i] = nw * a;
 }
 
-// transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d).  As the forward
-// kernel: four vertically adjacent rows of du per thread (rows yy0 .. yy0+3 of the H+2; the frame
-// height is even but not always a multiple of 4: rows past the end are skipped).
-__global__ void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out) {
-  const int C4 = C >> 2, UH = H + 2, UW = W + 2, UH4 = (UH + 3) >> 2;
+// transpose of the blur: du[B,H+2,W+2,C] from g[B,H,W,C] (g already scaled by d).  As the forward kernel: a
+// 4 x 4 patch of du per thread from the 7 x 7 gradients that reach it (the frame is (H+2)^2: patches past its
+// end are cut), rows walked downwards so that the vertical taps add in the order j = 0..3 of the earlier forms.
+__global__ __launch_bounds__(256) void blur_bwd_kernel(const float* g, float* du, int Bn, int H, int W, int C,
+                                                       float* amax_out) {
+  const int C4 = C >> 2, UH = H + 2, UW = W + 2, UH4 = (UH + 3) >> 2, UW4 = (UW + 3) >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Bn * UH4 * UW * C4) return;
+  if (idx >= (size_t)Bn * UH4 * UW4 * C4) return;
   const int c = (int)(idx % C4) * 4;
   size_t p = idx / C4;
-  const int xx = (int)(p % UW);
-  p /= UW;
+  const int xx0 = (int)(p % UW4) * 4;
+  p /= UW4;
   const int yy0 = (int)(p % UH4) * 4;
   const int b = (int)(p / UH4);
-  // u[yy,xx] feeds y[Y,X] with Y = yy - j + 1, X = xx - i + 1: rows Y = yy0 - 2 .. yy0 + 4
-  f32x4 hrow[7];
+  const f32x4 zero = {0, 0, 0, 0};
+  f32x4 out[4][4];
 #pragma unroll
-  for (int r = 0; r < 7; ++r) {
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) out[k][x] = zero;
+  // u[yy,xx] feeds y[Y,X] with Y = yy - j + 1, X = xx - i + 1: rows Y = yy0 - 2 .. yy0 + 4, columns likewise
+#pragma unroll
+  for (int r = 6; r >= 0; --r) {
     const int Y = yy0 + r - 2;
-    f32x4 row = {0, 0, 0, 0};
+    f32x4 h[4] = {zero, zero, zero, zero};
     if (Y >= 0 && Y < H) {
+      const float* row = g + (((size_t)b * H + Y) * W) * C + c;
+      f32x4 in[7];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int X = xx - i + 1;
-        if (X < 0 || X >= W) continue;
-        row += *reinterpret_cast<const f32x4*>(g + (((size_t)b * H + Y) * W + X) * C + c) * fir_a(i);
+      for (int q = 0; q < 7; ++q) {
+        const int X = xx0 + q - 2;
+        in[q] = (X >= 0 && X < W) ? *reinterpret_cast<const f32x4*>(row + (size_t)X * C) : zero;
       }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                 // X = (xx0 + x) - i + 1 = xx0 + (x - i + 3) - 2
+          const int X = xx0 + x - i + 1;
+          if (X >= 0 && X < W) h[x] += in[x - i + 3] * fir_a(i);
+        }
     }
-    hrow[r] = row;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = k + 3 - r;                        // Y = yy - j + 1 = yy0 + (k + 3 - j) - 2
+      if (j < 0 || j > 3) continue;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) out[k][x] += h[x] * fir_a(j);
+    }
   }
   float m = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int yy = yy0 + k;
     if (yy >= UH) break;
-    f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc += hrow[k + 3 - j] * fir_a(j);       // Y = yy - j + 1 = yy0 + (k + 3 - j) - 2
-    *reinterpret_cast<f32x4*>(du + ((((size_t)b * UH + yy) * UW + xx) * C4) * 4 + c) = acc;
-    if (amax_out) m = absmax4s(m, acc);
+    for (int x = 0; x < 4; ++x) {
+      const int xx = xx0 + x;
+      if (xx >= UW) break;
+      *reinterpret_cast<f32x4*>(du + (((size_t)b * UH + yy) * UW + xx) * C + c) = out[k][x];
+      if (amax_out) m = absmax4s(m, out[k][x]);
+    }
   }
   if (amax_out) amax_commit(m, b, blockIdx.x * 4u + (threadIdx.x >> 6), amax_out);
 }
@@ -451,8 +493,8 @@ extern "C" int p2l_sg2_blur_fwd_amax(const float* u, const float* d, const float
                                      const float* bias, float* y, int Bn, int H, int W, int C,
                                      const float* next_s, float* amax_out, void* stream) {
   if (C % 4) return P2L_EINVAL;
-  if (H % 4) return P2L_EINVAL;
-  const dim3 grid(cdiv((size_t)Bn * (H / 4) * W * (C / 4), 256));
+  if (H % 4 || W % 4) return P2L_EINVAL;
+  const dim3 grid(cdiv((size_t)Bn * (H / 4) * (W / 4) * (C / 4), 256));
   hipLaunchKernelGGL(blur_fwd_kernel, grid, dim3(256), 0, ST(stream), u, d, noise, nw, bias, y, Bn, H, W, C,
                      amax_out ? next_s : nullptr, amax_out);
   return p2l_check_launch();
@@ -496,7 +538,7 @@ extern "C" int p2l_sg2_styled_act_bwd_amax(const float* dy, const float* y, cons
 extern "C" int p2l_sg2_blur_bwd_amax(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out,
                                      void* stream) {
   if (C % 4) return P2L_EINVAL;
-  const dim3 grid(cdiv((size_t)Bn * ((H + 5) / 4) * (W + 2) * (C / 4), 256));
+  const dim3 grid(cdiv((size_t)Bn * ((H + 5) / 4) * ((W + 5) / 4) * (C / 4), 256));
   hipLaunchKernelGGL(blur_bwd_kernel, grid, dim3(256), 0, ST(stream), g, du, Bn, H, W, C, amax_out);
   return p2l_check_launch();
 }

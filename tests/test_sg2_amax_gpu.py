@@ -52,6 +52,17 @@ def test_tail_kernels_leave_exact_maxima(dev, B, H, C):
         assert torch.equal(y0, y1)
         want = (y0 * ns.view(B, 1, 1, C) if ns is not None else y0).abs().amax(dim=(1, 2, 3))
         assert torch.equal(am.amax(dim=1), want), (am.amax(dim=1), want)
+    # ---- ... and both against torch: the 4x4 FIR [1,3,3,1]^2 / 16 x 4 on the frame (its first row / column are the
+    #      only padding the transposed conv's output needs), demodulation, noise, bias, leaky ReLU x sqrt 2
+    import torch.nn.functional as F
+    a4 = torch.tensor([0.25, 0.75, 0.75, 0.25], device=dev)
+    kern = torch.outer(a4, a4).view(1, 1, 4, 4).repeat(C, 1, 1, 1)
+    u_ref = u.permute(0, 3, 1, 2).double().requires_grad_(True)
+    blurred = F.conv2d(F.pad(u_ref, (1, 0, 1, 0)), kern.double(), groups=C)
+    pre = blurred * d.double().view(B, C, 1, 1) + 0.3 * noise.double().view(B, 1, H, H) + bias.double().view(1, C, 1, 1)
+    y_ref = _lrelu(pre)
+    err = (y0.permute(0, 3, 1, 2).double() - y_ref).abs().amax(dim=(1, 2, 3)) / y_ref.abs().amax(dim=(1, 2, 3))
+    assert err.max().item() < 1e-5, err
     # ---- activation backward: gd and max |gd|
     P = H * H
     dy = (torch.randn(B, H, H, C, generator=g) * mag.flip(0)).to(dev)
@@ -82,6 +93,9 @@ def test_tail_kernels_leave_exact_maxima(dev, B, H, C):
     N.check(lib.p2l_sg2_blur_bwd_amax(N.ptr(gd), N.ptr(du1), B, H, H, C, N.ptr(am), st), 'blur_bwd_amax')
     assert torch.equal(du0, du1)
     assert torch.equal(am.amax(dim=1), du0.abs().amax(dim=(1, 2, 3)))
+    du_ref, = torch.autograd.grad(blurred, u_ref, gd.permute(0, 3, 1, 2).double())
+    err = (du0.permute(0, 3, 1, 2).double() - du_ref).abs().amax(dim=(1, 2, 3)) / du_ref.abs().amax(dim=(1, 2, 3))
+    assert err.max().item() < 1e-5, err
 
 
 @pytest.mark.parametrize('widths', ['wide', 'narrow'])
