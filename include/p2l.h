@@ -113,7 +113,11 @@ size_t p2l_conv_workspace_bytes(const P2LConv* d);
  * never of d->B -- the slices are summed in a fixed order that follows their count, so a count that
  * followed the batch would make a candidate's low bits depend on who shares its launch (it did for
  * the 4^2 ... 16^2 layers until round 5).  With the suggested count a candidate's result is
- * bit-identical for every batch size and position in the batch.  */
+ * bit-identical for every batch size and position in the batch.
+ * Sub-pixel launches: only the input-gradient form of a stride-2 transposed conv (ups = 3, ext = 1: StyleGAN2's
+ * up convs) in the fp16 x 2 kernel takes slices (its 8^2 ... 32^2 layers; round 6) -- the finish kernel then runs
+ * on the low-resolution grid, p2l_conv_arb_nblk_ws counts ITS quads, and such a launch leaves no maxima
+ * (p2l_conv_amax_slots = 0).  ups = 2 and the nearest-upsample gradient (ups = 3, ext = 0) never split.  */
 int p2l_conv_suggest_splitk(const P2LConv* d);
 int p2l_conv_fwd(const P2LConv* d, const float* x, const float* w,
                  const float* bias, const float* pro_s, const float* pro_t,

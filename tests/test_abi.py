@@ -168,6 +168,34 @@ def test_host_side_planning_calls(lib):
             assert len(got) == 1, ((taps, H, cin, cout, ups), got)
             n_split += got.pop() > 1
     assert n_split >= 10
+    # ... and the sub-pixel input-gradient form of StyleGAN2's transposed convs (ups 3, ext 1; round 6): slices from
+    # the shape only, at 8^2 ... 32^2, none where the grid fills the chip; workspace and partial counts follow
+    sliced = {}
+    for H, c in ((8, 512), (16, 512), (32, 512), (64, 512), (128, 256), (512, 64), (1024, 32)):
+        got = set()
+        for B in (1, 3, 9, 22, 32):
+            d = N.P2LConv()
+            d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.ups, d.ext = B, H, H, c, c, 9, 3, 1
+            d.wfmt, d.x_ld, d.n_store, d.y_ld = 2, c, c, c
+            got.add(lib.p2l_conv_suggest_splitk(C.byref(d)))
+        assert len(got) == 1, (H, c, got)
+        sliced[H] = got.pop()
+    assert sliced[8] > 1 and sliced[16] > 1 and sliced[32] > 1 and sliced[128] == sliced[512] == sliced[1024] == 1
+    d = N.P2LConv()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.taps, d.ups, d.ext = 3, 16, 16, 512, 512, 9, 3, 1
+    d.wfmt, d.x_ld, d.n_store, d.y_ld = 2, 512, 512, 512
+    d.splitk = sliced[16]
+    assert lib.p2l_conv_arb_nblk_ws(C.byref(d)) == 4 * 4          # quads of the LOW-res 8x8 grid the finish kernel walks
+    assert lib.p2l_conv_arb_split_fusable(C.byref(d)) == 1
+    assert lib.p2l_conv_amax_slots(C.byref(d)) == 0                # (a sliced sub-pixel launch leaves no maxima)
+    assert lib.p2l_conv_workspace_bytes(C.byref(d)) >= 3 * 64 * 4 + sliced[16] * 3 * 8 * 8 * 512 * 4
+    d.ext = 0                                                     # BigGAN's nearest-upsample gradients: never sliced
+    assert lib.p2l_conv_suggest_splitk(C.byref(d)) == 1
+    # the noise relayout validates its descriptor on the host
+    m = N.P2LStyleGAN2()
+    fake = C.c_void_p(4096)
+    assert lib.p2l_sg2_noise_relayout(C.byref(m), fake, fake, 2, 1, None) == -1        # no layers
+    assert lib.p2l_sg2_noise_relayout(None, fake, fake, 2, 1, None) == -1
     assert lib.p2l_projloss_ws_bytes(2, 256, 256) > 0
     assert lib.p2l_projloss_ws_bytes(2, 100, 100) == 0          # not a power of two
     # P2LConv.w_floats (version 101): a sub-pixel launch of a P2L_WFMT_BF16X3W model reads
