@@ -331,9 +331,14 @@ def test_tracking_leaves_the_device(dev):
     grown = torch.cuda.memory_allocated() - base
     per_step = 3 * (n_noise + 512) * 4
     assert grown <= (opt.TRACK_RING + 0.5) * per_step, 'tracking holds %.0f MB on the device' % (grown / 2**20)
+    # 50 x 33.6 MB is past the pinned budget (TRACK_PIN_TOTAL): the later steps go through the pinned staging ring
+    # into pageable tensors -- asynchronously, the host is not held until the step's values exist
+    assert opt._track_pinned <= opt.TRACK_PIN_TOTAL and len(opt._track_ring['noises']['stage']) == opt.TRACK_STAGE
     hist = opt.tracked
+    assert not opt._track_pending
+    assert not hist['noises'][49].is_pinned() and hist['noises'][0].is_pinned()
     assert len(hist['noises']) == len(hist['z']) == 50
-    for step in (0, 1, 17, 49):
+    for step in (0, 1, 6, 7, 8, 17, 48, 49):
         t = hist['noises'][step]
         assert not t.is_cuda and tuple(t.shape) == (3, n_noise)
         assert float(t.min()) == float(t.max()) == float(step)
