@@ -845,6 +845,12 @@ int p2l_sg2_styled_act_bwd_amax(const float* dy, const float* y, const float* d,
                                 float* partial, float* strips, int Bn, int P, int C, float* amax_out,
                                 void* stream);
 int p2l_sg2_blur_bwd_amax(const float* g, float* du, int Bn, int H, int W, int C, float* amax_out, void* stream);
+/* Deferred form of the second reduction stage of p2l_sg2_styled_act_bwd (partial -> dd), per host thread: between
+ * _begin and _flush it is only recorded and _flush runs all of them in ONE launch (same sums, same order).  Every
+ * deferred layer needs its own `partial` buffer, untouched until _flush; _cancel drops what was recorded. */
+void p2l_sg2_rows_defer_begin(void);
+int p2l_sg2_rows_defer_flush(void* stream);
+void p2l_sg2_rows_defer_cancel(void);
 /* RGB skip upsample (upfirdn2d up=2, [1,3,3,1]) on NHWC16 images and its transpose */
 int p2l_sg2_rgb_up_fwd(const float* skip, float* out, int Bn, int h, int w, void* stream);
 int p2l_sg2_rgb_up_bwd(const float* dout, float* dskip, int Bn, int h, int w, int accumulate,

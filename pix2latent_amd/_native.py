@@ -304,6 +304,7 @@ EXPORTS = [
     'p2l_pack_gconv_weight', 'p2l_sqz_cache_floats', 'p2l_sqzloss_ws_bytes', 'p2l_sqzloss_prepare', 'p2l_sqzloss_fwd',
     'p2l_sqzloss_bwd', 'p2l_sqzloss_ws_lookup',
     'p2l_sg2_blur_fwd_amax', 'p2l_sg2_styled_act_bwd_amax', 'p2l_sg2_blur_bwd_amax', 'p2l_sg2_noise_relayout',
+    'p2l_sg2_rows_defer_begin', 'p2l_sg2_rows_defer_flush', 'p2l_sg2_rows_defer_cancel',
 ]
 
 _lib = None

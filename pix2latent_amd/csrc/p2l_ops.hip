@@ -1120,9 +1120,10 @@ extern "C" int p2l_scale_bwd(const float* da, int da_ld, const float* x, int x_l
   k.Bn = Bn; k.P = H * W; k.C = C; k.H = H; k.W = W; k.nomask = 1;
   k.nblk = cdiv(k.P, ARB_SLAB);
   hipLaunchKernelGGL(affine_relu_bwd_kernel, dim3(k.nblk, cdiv(C, 64), Bn), dim3(256), 0, ST(stream), k);
-  hipLaunchKernelGGL(arb_finish_kernel, dim3(cdiv(C, 64), Bn), dim3(ARB_SEGS * 16), 0, ST(stream), partial, ds,
-                     dt_scratch, Bn, k.nblk, C, dsdt_bstride);
-  return p2l_check_launch();
+  const int rc = p2l_check_launch();
+  if (rc) return rc;
+  // (through p2l_arb_finish: recorded only while the caller defers the finishes, p2l_arb_defer_begin)
+  return p2l_arb_finish(partial, ds, dt_scratch, Bn, k.nblk, C, dsdt_bstride, stream);
 }
 
 extern "C" int p2l_softmax_fwd(const float* S, float* P, int64_t rows, int cols,

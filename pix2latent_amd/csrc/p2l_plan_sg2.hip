@@ -30,7 +30,10 @@ struct SgLayout {
   size_t s[P2L_SG2_MAX_CONVS], d[P2L_SG2_MAX_CONVS], y[P2L_SG2_MAX_CONVS];
   size_t ds[P2L_SG2_MAX_CONVS], dd[P2L_SG2_MAX_CONVS];
   size_t rs[P2L_SG2_MAX_RGBS], rds[P2L_SG2_MAX_RGBS], skip[P2L_SG2_MAX_RGBS];
-  size_t x0, zeros, ubuf, upbuf, g_a, g_b, g_c, g_d, gs_a, gs_b, part, part2, strips, scratch;
+  size_t x0, zeros, ubuf, upbuf, g_a, g_b, g_c, g_d, gs_a, gs_b, strips, scratch;
+  // partial sums of the two deferred second-stage reductions (modulation backward: ds; demodulation: dd): one
+  // buffer per layer, untouched until the flush at the end of the backward pass
+  size_t part_l[P2L_SG2_MAX_CONVS], part_r[P2L_SG2_MAX_RGBS], part2_l[P2L_SG2_MAX_CONVS];
   size_t cws, cws_floats;   // conv workspace: the per-image maxima of the fp16 x 2 Winograd form
   // maxima handed from the kernel that writes a tensor to the fp16 x 2 conv that reads it (P2LAmax, round 6):
   //   amax_f [n_conv][B][64]     y[l] x s[l+1] left by the blur kernel of an up conv (atomic slots)
@@ -67,7 +70,7 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
     return P2L_EINVAL;
   g_sg_wfmt = m->wfmt;
   Arena a;
-  size_t max_act = 0, max_u = 0, max_c = 0, max_part = 0, max_part2 = 0, max_strips = 0;
+  size_t max_act = 0, max_u = 0, max_c = 0, max_strips = 0;
   size_t max_cws = (size_t)B * 64;
   for (int l = 0; l < m->n_conv; ++l) {
     const P2LSg2Conv& c = m->conv[l];
@@ -108,9 +111,8 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
       const size_t pq = 2 * (size_t)B * p2l_conv_arb_nblk_ws(&g) * cm;
       if (pq > p1) p1 = pq;
     }
-    if (p1 > max_part) max_part = p1;
-    const size_t p2 = (size_t)B * p2l_sg2_act_bwd_nblk((int)P) * c.cout;
-    if (p2 > max_part2) max_part2 = p2;
+    L.part_l[l] = a.take(p1);
+    L.part2_l[l] = a.take((size_t)B * p2l_sg2_act_bwd_nblk((int)P) * c.cout);
     const size_t st = (size_t)(c.cout / ((c.cout % 64) ? 32 : 64)) * B * P;
     if (st > max_strips) max_strips = st;
   }
@@ -119,6 +121,7 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
     L.rs[j] = a.take((size_t)B * r.cin);
     L.rds[j] = a.take((size_t)B * r.cin);
     L.skip[j] = a.take((size_t)B * r.res * r.res * 16);
+    L.part_r[j] = a.take(2 * (size_t)B * cdiv((size_t)r.res * r.res, 128) * r.cin);
   }
   L.x0 = a.take((size_t)B * 16 * m->conv[0].cin);
   L.zeros = a.take((size_t)B * max_c);
@@ -131,8 +134,6 @@ int sg_layout(const P2LStyleGAN2* m, int B, SgLayout& L) {
   L.g_d = a.take(max_u > max_act ? max_u : max_act);
   L.gs_a = a.take(img);
   L.gs_b = a.take(img);
-  L.part = a.take(max_part);
-  L.part2 = a.take(max_part2);
   L.strips = a.take(max_strips);
   L.scratch = a.take((size_t)B * max_c * 2);
   L.cws_floats = max_cws;
@@ -358,8 +359,13 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
   float* gd = W + L.g_b;     // activation-backward result
   float* gx = W + L.g_c;     // gradient flowing to the previous layer
   float* tmp = W + L.g_d;    // blur transpose / unfused temp
-  float* part = W + L.part;
   float* scratch = W + L.scratch;
+  // the second stage of every per-(sample, channel) reduction of the pass (26 + 17 launches of a few blocks) is
+  // recorded and runs as two launches in front of the style-gradient linears
+  struct Defer {
+    Defer() { p2l_arb_defer_begin(); p2l_sg2_rows_defer_begin(); }
+    ~Defer() { p2l_arb_defer_cancel(); p2l_sg2_rows_defer_cancel(); }     // (no-ops after the flushes)
+  } defer;
   bool have_next = false;    // gx holds a gradient for the current layer's output
   int rj = m->n_rgb - 1;
   for (int l = m->n_conv - 1; l >= 0; --l) {
@@ -373,7 +379,7 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       P2LConv t = mk(B, r.res, 16, r.cin, 1);
       t.algo_flops = 2.0 * B * r.res * r.res * (double)r.cin * 3;
       RET_IF(dgrad_scale(t, gs_cur, r.wt, W + L.y[l], W + L.rs[rj], r.cin,
-                         have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, part, scratch, B, r.res,
+                         have_next ? gx : nullptr, gy, W + L.rds[rj], tmp, W + L.part_r[rj], scratch, B, r.res,
                          W + L.cws, L.cws_floats, nullptr, st));
       if (rj > 0) {
         RET_IF(p2l_sg2_rgb_up_bwd(gs_cur, gs_prev, B, r.res / 2, r.res / 2, 0, st));
@@ -392,7 +398,7 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
     float* am_gd = hand ? W + L.amax_b + (size_t)(2 * l) * B * P2L_SG2_AMAX_SLOTS : nullptr;
     float* am_du = hand ? W + L.amax_b + (size_t)(2 * l + 1) * B * P2L_SG2_AMAX_SLOTS : nullptr;
     RET_IF(p2l_sg2_styled_act_bwd_amax(dy, W + L.y[l], W + L.d[l], nz, c.noise_w, c.act_b, gd, W + L.dd[l],
-                                       dnz, W + L.part2, W + L.strips, B, c.res * c.res, c.cout,
+                                       dnz, W + L.part2_l[l], W + L.strips, B, c.res * c.res, c.cout,
                                        c.up ? nullptr : am_gd, st));
     // gx may alias dy (when !gy_ready): the dgrad below writes gx only after gd was produced
     float* gout = (dy == gx) ? gy : gx;
@@ -401,11 +407,11 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
       P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
       d.ups = 3; d.ext = 1;
       // unfused temp must not alias the conv input (tmp): use gd
-      RET_IF(dgrad_scale(d, tmp, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], gd, part,
+      RET_IF(dgrad_scale(d, tmp, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], gd, W + L.part_l[l],
                          scratch, B, res_in, W + L.cws, L.cws_floats, am_du, st));
     } else {
       P2LConv d = mk(B, c.res, c.cout, c.cin, 9);
-      RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, part,
+      RET_IF(dgrad_scale(d, gd, c.wt, x_in, W + L.s[l], c.cin, nullptr, gout, W + L.ds[l], tmp, W + L.part_l[l],
                          scratch, B, res_in, W + L.cws, L.cws_floats, am_gd, st));
     }
     if (gout != gx) { float* t2 = gy; gy = gx; gx = t2; }   // keep "gx = gradient for layer l-1"
@@ -431,6 +437,8 @@ extern "C" int p2l_sg2_synthesis_bwd(const P2LStyleGAN2* m, const float* latent,
     e.W = r.mod_w; e.dy = W + L.rds[j]; e.dx = dlatent + (size_t)r.latent_idx * D;
     e.K = D; e.N = r.cin; e.dx_ld = lat_ld; e.accumulate = 1;
   }
+  RET_IF(p2l_arb_defer_flush(st));
+  RET_IF(p2l_sg2_rows_defer_flush(st));
   RET_IF(p2lsg2::grouped_linear_bwd(gm, st));
   RET_IF(p2lsg2::grouped_linear_bwd(gc, st));
   RET_IF(p2lsg2::grouped_linear_bwd(gr, st));
