@@ -343,10 +343,15 @@ enum {
    * (csrc/p2l_h2r.hip: persistent blocks, one per CU); the results are bit-identical to the chunked      *
    * direct kernel, which this bit keeps (tests, A/B)                                                     */
   P2L_FORM_NO_H2R = 256,
-  P2L_FORM_H2R_SEQ_EPI = 512    /* ... that kernel with the shared epilogue item between two tiles: instead of the  *
+  P2L_FORM_H2R_SEQ_EPI = 512,   /* ... that kernel with the shared epilogue item between two tiles: instead of the  *
                                  * forward-style epilogue pipelined under the next tile's stream, and for the      *
                                  * launches (fused activation backward, residual ...) that otherwise stay on the   *
                                  * chunked kernel (tests, A/B)                                                     */
+  /* P2LConv.ext = 1 declares the weights of a stride-2 TRANSPOSED 3x3 conv (p2l_pack_conv_weight_subpix* mode 1):
+   * 7 of the 16 (phase, window tap) slabs are zero by construction, and the fp16 x 2 sub-pixel kernel skips their
+   * products (round 6: 16 -> 9 matrix products per 2x2 output quad, bit-identical).  This bit multiplies them
+   * anyway (tests, A/B).                                                                                        */
+  P2L_FORM_NO_SP_SKIP = 1024
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

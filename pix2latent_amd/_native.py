@@ -174,6 +174,7 @@ WFMT_FLAG_PW, WFMT_FLAG_THIN, WFMT_FLAG_ATTN_GEMM, WFMT_FLAG_NO_AMAX = 0x10, 0x2
 FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN, FORM_WINO_BF3 = 0, 1, 2, 4, 8, 16, 32
 FORM_WINO_H2_8X16, FORM_WINO_H2_16X16 = 64, 128      # block shape of the fp16 x 2 Winograd kernel (default: from the grid)
 FORM_H2R_SEQ_EPI = 512
+FORM_NO_SP_SKIP = 1024
 FORM_NO_H2R = 256                                    # the chunked direct kernel where the register-resident one would run
 
 

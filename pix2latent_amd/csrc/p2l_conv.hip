@@ -1607,6 +1607,7 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
       }
     }
     k.sp_mode = d->ups - 1;
+    k.sp_skip = (d->ext && !(d->form & P2L_FORM_NO_SP_SKIP)) ? 1 : 0;
     k.sp_ncc = d->Cin / 16;
     k.nchunks = (d->ups == 3) ? 4 * k.sp_ncc : k.sp_ncc;
     k.chunks_per_split = cdiv(k.nchunks, sk3);

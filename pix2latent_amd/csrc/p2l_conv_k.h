@@ -41,6 +41,7 @@ struct ConvK {
   //   1 = forward: low-res input, 4 output phases (blockIdx.y), output stride 2
   //   2 = input-gradient: the 4 phase planes of the high-res dY are 4 K-slices
   int sp_mode, sp_ncc;   // sp_ncc = channel chunks per phase plane (mode 2)
+  int sp_skip;           // 1: the weights are those of a stride-2 TRANSPOSED conv (ext = 1): 7 of the 16 phase taps are zero
   // LDS pitch (in rows) of one line of the staged input patch; >= tile width + 2.  bf16x3:
   // 24 for 16-wide tiles, which puts the two pixel rows a wave's ds_read_b128 lane group
   // touches on disjoint banks (with tile width + 2 = 18 every activation-fragment read was a

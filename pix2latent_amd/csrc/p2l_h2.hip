@@ -328,6 +328,20 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       }
       win_row = oy * HP + ox;
     }
+    // Stride-2 transposed conv (StyleGAN2's up convs, k.sp_skip): per dimension an output of phase 1 has ONE source
+    // pixel, an input-gradient plane 1 one too -- pack_subpix_kernel (mode 1) leaves the other window tap's slab
+    // zero: 9 live taps of the 16 of a 2x2 quad of phases.  Their products are skipped (adding exact zeros changes
+    // no bit); the zero slabs still travel with the weight tile (the vmcnt bookkeeping counts DMA instructions).
+    // Bit t of `live`: tap t = (ty, tx) of this block's phase (forward) / of this chunk's phase plane (gradient).
+    unsigned live = 0xFu;
+    if (TAPS == 4 && k.sp_skip) {
+      if (sp_fwd) {
+        live = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);          // phase 1: window tap 0 only
+      } else {
+        const int cls = c / k.sp_ncc;
+        live = ((cls >> 1) ? 0xCu : 0xFu) & ((cls & 1) ? 0xAu : 0xFu);   // plane 1: window tap 1 only
+      }
+    }
     h16x8 af[2][2], bq[2][2];
     auto lda = [&](int tap, h16x8 (&a)[2]) {
       const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
@@ -361,12 +375,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       }
       if (u + 1 < NU && u + 1 != U0) {
         const int tn = (u + 1) / NT, jn = (u + 1) - tn * NT;
-        if (jn == 0) lda(tn, af[tn & 1]);
-        ldb(u + 1, bq[(u + 1) & 1]);
+        if (TAPS != 4 || ((live >> tn) & 1u)) {
+          if (jn == 0) lda(tn, af[tn & 1]);
+          ldb(u + 1, bq[(u + 1) & 1]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       const h16x8 (&a)[2] = af[tap & 1];
       const h16x8 (&b)[2] = bq[u & 1];
+      if (TAPS == 4 && !((live >> tap) & 1u)) continue;        // (uniform: a scalar branch over the three MFMAs)
       if (!(P2L_H2_ABL & 8)) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[j], 0, 0, 0);   // smallest terms first
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[j], 0, 0, 0);

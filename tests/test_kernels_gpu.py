@@ -974,6 +974,45 @@ def test_transposed_conv_subpixel(dev, O, h, Cin, Cout):
     assert relerr(nchw(dx), x.grad) < 2e-5
 
 
+@pytest.mark.parametrize('B,h,Cin,Cout', [(2, 8, 64, 64), (3, 16, 128, 64), (2, 32, 64, 128), (9, 4, 64, 64),
+                                          (1, 64, 32, 32)])
+def test_transposed_conv_fp16x2_skips_its_zero_taps_bit_identically(dev, O, B, h, Cin, Cout):
+    """The fp16 x 2 sub-pixel kernel on the weights of a stride-2 transposed conv (ext = 1): 7 of the 16 (phase,
+    window tap) slabs are zero by construction (pack_subpix_kernel mode 1) and their products are skipped -- 9 matrix
+    products per 2x2 output quad instead of 16.  Same bits as multiplying them (P2L_FORM_NO_SP_SKIP), forward and
+    input gradient, K slices included; and right against F.conv_transpose2d / autograd."""
+    from pix2latent_amd import _native as N
+    g = torch.Generator().manual_seed(B * 100 + h)
+    x = torch.randn(B, Cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    u_ref = F.conv_transpose2d(x, w.transpose(0, 1), stride=2)
+    du = torch.randn_like(u_ref)
+    u_ref.backward(du)
+    H = 2 * h
+    wsp = O.pack_conv_weight_subpix(w.to(dev), Cout, Cin, mode=1, wfmt=2)
+    wtsp = O.pack_conv_weight_subpix(w.to(dev), Cin, Cout, flip=True, mode=1, wfmt=2)
+    dup = torch.zeros(B, Cout, H + 2, H + 2)
+    dup[:, :, :H + 1, :H + 1] = du
+    xd, dud = nhwc(x.detach(), dev), nhwc(dup, dev)
+    outs = {}
+    for form in (0, N.FORM_NO_SP_SKIP):
+        (u, _), mm_f = _mfma_products(N, lambda: O.conv(xd, wsp, B, H, H, Cin, Cout, 9, ups=2, ext=1, splitk=1, wfmt=2,
+                                                     form=form))
+        dxs = []
+        for sk in (1, None):               # (None: the shape's own slice count -- 8^2 ... 32^2 gradients are sliced)
+            (dx, _), mm_b = _mfma_products(N, lambda: O.conv(dud, wtsp, B, H, H, Cout, Cin, 9, ups=3, ext=1,
+                                                           splitk=sk, wfmt=2, form=form))
+            dxs.append(dx)
+        torch.cuda.synchronize()
+        assert abs(mm_f - 3) < 1e-6 and abs(mm_b - 3) < 1e-6       # the fp16 x 2 arithmetic ran
+        outs[form] = (u, dxs[0], dxs[1])
+    for a, b in zip(outs[0], outs[N.FORM_NO_SP_SKIP]):
+        assert torch.equal(a, b)
+    u, dx, dx_sliced = outs[0]
+    assert relerr(nchw(u)[:, :, :H + 1, :H + 1], u_ref.detach()) < 2e-5
+    assert relerr(nchw(dx), x.grad) < 2e-5 and relerr(nchw(dx_sliced), x.grad) < 2e-5
+
+
 # ---- 3-channel image convs (csrc/p2l_thin.hip, P2L_WFMT_BF16X3T) --------------------------------
 def _pad_c(x, C):
     """[B,c,H,W] -> NHWC with the channels zero-padded to C"""
