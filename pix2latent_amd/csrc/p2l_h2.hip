@@ -49,7 +49,9 @@ __device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3)
 // s_waitcnt immediate (gfx9 encoding): vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14
 #define P2L_WAIT(VM, LGKM) __builtin_amdgcn_s_waitcnt(((VM) & 15) | (7 << 4) | ((LGKM) << 8) | (((VM) >> 4) << 14))
 
-template <int TAPS, int BN, int A_ITERS, int PRO>
+// SKIP (TAPS = 4 only): the transposed-conv form that leaves out its structurally zero taps -- an instantiation of
+// its own: as a run-time flag the test sat in every unit of BigGAN's sub-pixel launches too (+ 5 % on them)
+template <int TAPS, int BN, int A_ITERS, int PRO, bool SKIP = false>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   constexpr int NT = BN / 32;                        // accumulators per wave
   constexpr int B_ITEMS = TAPS * BN * 4;             // 16-byte items of the weight tile
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     // no bit); the zero slabs still travel with the weight tile (the vmcnt bookkeeping counts DMA instructions).
     // Bit t of `live`: tap t = (ty, tx) of this block's phase (forward) / of this chunk's phase plane (gradient).
     unsigned live = 0xFu;
-    if (TAPS == 4 && k.sp_skip) {
+    if (TAPS == 4 && SKIP) {
       if (sp_fwd) {
         live = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);          // phase 1: window tap 0 only
       } else {
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       }
       if (u + 1 < NU && u + 1 != U0) {
         const int tn = (u + 1) / NT, jn = (u + 1) - tn * NT;
-        if (TAPS != 4 || ((live >> tn) & 1u)) {
+        if (!(TAPS == 4 && SKIP) || ((live >> tn) & 1u)) {
           if (jn == 0) lda(tn, af[tn & 1]);
           ldb(u + 1, bq[(u + 1) & 1]);
         }
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       __builtin_amdgcn_sched_barrier(0);
       const h16x8 (&a)[2] = af[tap & 1];
       const h16x8 (&b)[2] = bq[u & 1];
-      if (TAPS == 4 && !((live >> tap) & 1u)) continue;        // (uniform: a scalar branch over the three MFMAs)
+      if (TAPS == 4 && SKIP && !((live >> tap) & 1u)) continue;        // (uniform: a scalar branch over the three MFMAs)
       if (!(P2L_H2_ABL & 8)) {
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[j], 0, 0, 0);   // smallest terms first
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[j], 0, 0, 0);
@@ -583,7 +585,12 @@ int p2l_h2_launch(const ConvK& k, int pro, int taps, int bn, bool small, hipStre
   const size_t lds = p2l_h2_lds_bytes(k, taps, bn);
 #define P2L_H2L(TAPS, BNV, AIT, PROV)                                                         \
   do {                                                                                        \
-    auto kfn = conv_h2_kernel<TAPS, BNV, AIT, PROV>;                                          \
+    if (TAPS == 4 && k.sp_skip) P2L_H2K(TAPS, BNV, AIT, PROV, (TAPS == 4));                   \
+    else P2L_H2K(TAPS, BNV, AIT, PROV, false);                                                \
+  } while (0)
+#define P2L_H2K(TAPS, BNV, AIT, PROV, SKIPV)                                                  \
+  do {                                                                                        \
+    auto kfn = conv_h2_kernel<TAPS, BNV, AIT, PROV, SKIPV>;                                   \
     static std::atomic<bool> attr_set{false};                                                 \
     if (!attr_set) {                                                                          \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -607,5 +614,6 @@ int p2l_h2_launch(const ConvK& k, int pro, int taps, int bn, bool small, hipStre
   }
 #undef P2L_H2P
 #undef P2L_H2L
+#undef P2L_H2K
   return p2l_check_launch();
 }
