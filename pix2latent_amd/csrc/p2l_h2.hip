@@ -178,6 +178,16 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         // (inline asm: through the builtin hipcc drains vmcnt in front of the next LDS access;
         //  the waits are placed by hand below, see p2l_conv.hip)
         const float* src = base + b_goff[it];
+        if (TAPS == 4 && SKIP) {
+          // a dead tap's slab is all zeros and its products are skipped: the DMA instruction still issues (the
+          // waits count instructions) but every lane fetches the SAME 16 bytes -- one L2 request per wave
+          // instead of 1 KB: 7 / 16 of the weight traffic of a transposed conv gone
+          unsigned lv;
+          if (sp_fwd) lv = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);
+          else { const int cls = c / k.sp_ncc; lv = ((cls >> 1) ? 0xCu : 0xFu) & ((cls & 1) ? 0xAu : 0xFu); }
+          const int tap = (jj >> 7) / NT;                       // (wave-uniform: 64 consecutive items)
+          if (!((lv >> tap) & 1u)) src = base;
+        }
         const unsigned lds_wave_base = __builtin_amdgcn_readfirstlane(
             (unsigned)(size_t)(__attribute__((address_space(3))) char*)(Bs + (size_t)(jj - lane) * 16));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
