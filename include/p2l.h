@@ -351,7 +351,12 @@ enum {
    * 7 of the 16 (phase, window tap) slabs are zero by construction, and the fp16 x 2 sub-pixel kernel skips their
    * products (round 6: 16 -> 9 matrix products per 2x2 output quad, bit-identical).  This bit multiplies them
    * anyway (tests, A/B).                                                                                        */
-  P2L_FORM_NO_SP_SKIP = 1024
+  P2L_FORM_NO_SP_SKIP = 1024,
+  /* the fp16 x 2 sub-pixel FORWARD kernel with one output phase per block (four blocks stage the same patch) instead *
+   * of two on one staged patch (round 6, bit-identical; tests, A/B)                                              */
+  P2L_FORM_NO_SP_PAIR = 2048,
+  P2L_FORM_SP_PAIR = 4096       /* ... two phases per block for every sub-pixel forward launch (default: the        *
+                                 * transposed convs with 64-channel tiles only)                                   */
 };
 /* K slices of a small-grid Winograd layer: 3x3 layers with 16..63 blocks of 8x16 pixels x 64
  * channels per image (H, W multiples of 16) run the 16x16 Winograd kernel with the input channels

@@ -175,6 +175,8 @@ FORM_AUTO, FORM_NO_WINO, FORM_WINO_ANY, FORM_WINO_8X16, FORM_NO_PW, FORM_NO_THIN
 FORM_WINO_H2_8X16, FORM_WINO_H2_16X16 = 64, 128      # block shape of the fp16 x 2 Winograd kernel (default: from the grid)
 FORM_H2R_SEQ_EPI = 512
 FORM_NO_SP_SKIP = 1024
+FORM_NO_SP_PAIR = 2048
+FORM_SP_PAIR = 4096
 FORM_NO_H2R = 256                                    # the chunked direct kernel where the register-resident one would run
 
 

@@ -1628,7 +1628,17 @@ static int conv_launch_impl(const P2LConv* d, const P2LArb* arb, const P2LConvEx
         rc = p2l_amax_launch(ka, d->pro, st);
         if (rc) return rc;
       }
-      rc = p2l_h2_launch(kh, d->pro, 4, bn, small_sp, st);
+      // Forward: two output phases per block on one staged patch -- for the transposed convs with 64-channel
+      // tiles (tools/bench_subpix.py: 1.10 - 1.18 x per launch; BigGAN's nearest-upsample convs, whose 16 taps are
+      // all live and whose launches are 60 - 100 us, lose 5 - 15 % to the halved grid; 32-channel tiles 3 %), or
+      // wherever P2L_FORM_SP_PAIR asks for it (tests); P2L_FORM_NO_SP_PAIR: never.  Shape and form only.
+#ifdef P2L_AB_NO_SP_PAIR
+      const bool pair = d->ups == 2 && !(d->form & P2L_FORM_NO_SP_PAIR) && (d->form & P2L_FORM_SP_PAIR);
+#else
+      const bool pair = d->ups == 2 && !(d->form & P2L_FORM_NO_SP_PAIR) &&
+                        ((d->ext && bn == 64) || (d->form & P2L_FORM_SP_PAIR));
+#endif
+      rc = p2l_h2_launch(kh, d->pro, pair ? 8 : 4, bn, small_sp, st);
       if (rc == P2L_OK && k.splitk > 1) {
         // the slices meet in the finish kernel of the direct path, on the low-res grid this launch tiled
         const bool arb_al = !arb || (k.arb_x_ld % 4 == 0 && (!k.arb_skip || k.arb_skip_ld % 4 == 0));

@@ -51,13 +51,19 @@ __device__ __forceinline__ int h2c(int c, int row) { return c ^ ((row >> 2) & 3)
 
 // SKIP (TAPS = 4 only): the transposed-conv form that leaves out its structurally zero taps -- an instantiation of
 // its own: as a run-time flag the test sat in every unit of BigGAN's sub-pixel launches too (+ 5 % on them)
+// TAPS = 8: the sub-pixel FORWARD form with TWO output phases per block ((ph_y, 0) and (ph_y, 1): 2 x 4 window taps on
+// one staged patch, two sets of accumulators, the epilogue once per phase; blockIdx.y = ph_y).  With a phase per block
+// (TAPS = 4) four blocks split and wrote the same patch: these launches are bound by staging and the global -> LDS
+// path, not by the matrix pipe.  Same products in the same order per output: bit-identical (P2L_FORM_NO_SP_PAIR).
 template <int TAPS, int BN, int A_ITERS, int PRO, bool SKIP = false>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
-  constexpr int NT = BN / 32;                        // accumulators per wave
+  constexpr bool SUBPIX = (TAPS == 4 || TAPS == 8);
+  constexpr int NP = (TAPS == 8) ? 2 : 1;            // output phases per block
+  constexpr int NT = BN / 32;                        // accumulators per wave and phase
   constexpr int B_ITEMS = TAPS * BN * 4;             // 16-byte items of the weight tile
   constexpr int B_ITERS = (B_ITEMS + 255) / 256;
-  constexpr int SL = (TAPS == 4) ? 16 : TAPS;        // slabs per (chunk, 32-channel tile) of the image
-  constexpr int T0 = (TAPS == 9) ? 4 : 2;            // taps in half 0 of the weight tile
+  constexpr int SL = SUBPIX ? 16 : TAPS;             // slabs per (chunk, 32-channel tile) of the image
+  constexpr int T0 = (TAPS == 4) ? 2 : 4;            // taps in half 0 of the weight tile (TAPS = 8: phase 0)
   constexpr int NU = TAPS * NT, U0 = T0 * NT;        // MFMA units (tap-major), units in half 0
   constexpr int H0 = U0 * 128;                       // 16-byte items in half 0
   static_assert(H0 % 256 == 0, "half 0 must be whole DMA instructions");
@@ -94,10 +100,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   const int y0 = ty << k.th_log, x0 = tx << k.tw_log, b0 = bt << k.tb_log;
 
   // blockIdx.y: split-K slice, or (sub-pixel forward) the output phase
-  const bool sp_fwd = (TAPS == 4) && k.sp_mode == 1;
+  const bool sp_fwd = SUBPIX && (TAPS == 8 || k.sp_mode == 1);
   const bool sp_bwd = (TAPS == 4) && k.sp_mode == 2;
   const int z = sp_fwd ? 0 : blockIdx.y;
-  const int ph_y = sp_fwd ? (int)(blockIdx.y >> 1) : 0, ph_x = sp_fwd ? (int)(blockIdx.y & 1) : 0;
+  const int ph_y = sp_fwd ? (TAPS == 8 ? (int)blockIdx.y : (int)(blockIdx.y >> 1)) : 0;
+  const int ph_x = (sp_fwd && TAPS == 4) ? (int)(blockIdx.y & 1) : 0;          // (TAPS = 8: both, tap >> 2)
   const int c_begin = z * k.chunks_per_split;
   const int c_end = min(k.nchunks, c_begin + k.chunks_per_split);
 
@@ -145,14 +152,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   // input-gradient walks over (phase plane cls, channel chunk cc)
   auto geom = [&](int c, int& cc, int& wslab, int& a_extra) {
     cc = c; wslab = 0; a_extra = 0;
-    if (TAPS == 4) {
+    if (SUBPIX) {
       if (sp_bwd) {
         const int cls = c / k.sp_ncc;
         cc = c - cls * k.sp_ncc;
         wslab = cls * 4;
         a_extra = ((cls >> 1) * k.ibW + (cls & 1)) * k.x_ld;
       } else {
-        wslab = (ph_y * 2 + ph_x) * 4;
+        wslab = (ph_y * 2 + ph_x) * 4;               // (TAPS = 8: ph_x = 0, the slabs of both phases follow)
       }
     }
   };
@@ -178,12 +185,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
         // (inline asm: through the builtin hipcc drains vmcnt in front of the next LDS access;
         //  the waits are placed by hand below, see p2l_conv.hip)
         const float* src = base + b_goff[it];
-        if (TAPS == 4 && SKIP) {
+        if (SUBPIX && SKIP) {
           // a dead tap's slab is all zeros and its products are skipped: the DMA instruction still issues (the
           // waits count instructions) but every lane fetches the SAME 16 bytes -- one L2 request per wave
           // instead of 1 KB: 7 / 16 of the weight traffic of a transposed conv gone
           unsigned lv;
-          if (sp_fwd) lv = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);
+          if (TAPS == 8) { const unsigned my = ph_y ? 0x3u : 0xFu; lv = my | ((my & 0x5u) << 4); }
+          else if (sp_fwd) lv = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);
           else { const int cls = c / k.sp_ncc; lv = ((cls >> 1) ? 0xCu : 0xFu) & ((cls & 1) ? 0xAu : 0xFu); }
           const int tap = (jj >> 7) / NT;                       // (wave-uniform: 64 consecutive items)
           if (!((lv >> tap) & 1u)) src = base;
@@ -246,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   // weight rows are u * 32 + l31: the swizzle bits come from l31 alone
   const int b_h = l31 * 64 + h2c(lhi, l31) * 16, b_m = l31 * 64 + h2c(2 + lhi, l31) * 16;
 
-  f32x16 acc[NT];
+  f32x16 acc[NP * NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NP * NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = (c + 1 < c_end);
     int win_row = 0;
-    if (TAPS == 4) {
+    if (SUBPIX) {
       int oy = ph_y, ox = ph_x;
       if (sp_bwd) {
         const int cls = c / k.sp_ncc;
@@ -345,9 +353,12 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     // zero: 9 live taps of the 16 of a 2x2 quad of phases.  Their products are skipped (adding exact zeros changes
     // no bit); the zero slabs still travel with the weight tile (the vmcnt bookkeeping counts DMA instructions).
     // Bit t of `live`: tap t = (ty, tx) of this block's phase (forward) / of this chunk's phase plane (gradient).
-    unsigned live = 0xFu;
-    if (TAPS == 4 && SKIP) {
-      if (sp_fwd) {
+    unsigned live = 0xFFu;
+    if (SUBPIX && SKIP) {
+      if (TAPS == 8) {
+        const unsigned my = ph_y ? 0x3u : 0xFu;
+        live = my | ((my & 0x5u) << 4);                              // taps 4 .. 7: phase (ph_y, 1)
+      } else if (sp_fwd) {
         live = (ph_y ? 0x3u : 0xFu) & (ph_x ? 0x5u : 0xFu);          // phase 1: window tap 0 only
       } else {
         const int cls = c / k.sp_ncc;
@@ -356,9 +367,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     }
     h16x8 af[2][2], bq[2][2];
     auto lda = [&](int tap, h16x8 (&a)[2]) {
-      const int dy = (TAPS == 9) ? tap / 3 : (tap >> 1);
+      const int dy = (TAPS == 9) ? tap / 3 : ((tap & 3) >> 1);
       const int dx = (TAPS == 9) ? tap - dy * 3 : (tap & 1);
-      const int arow = a_row0 + win_row + dy * HP + dx;
+      const int arow = a_row0 + win_row + dy * HP + dx + ((TAPS == 8) ? (tap >> 2) : 0);   // (+ the phase's window column)
       const char* ar = As + arow * 64;
       a[0] = *reinterpret_cast<const h16x8*>(ar + h2c(lhi, arow) * 16);
       a[1] = *reinterpret_cast<const h16x8*>(ar + h2c(2 + lhi, arow) * 16);
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       }
       if (u + 1 < NU && u + 1 != U0) {
         const int tn = (u + 1) / NT, jn = (u + 1) - tn * NT;
-        if (!(TAPS == 4 && SKIP) || ((live >> tn) & 1u)) {
+        if (!(SUBPIX && SKIP) || ((live >> tn) & 1u)) {
           if (jn == 0) lda(tn, af[tn & 1]);
           ldb(u + 1, bq[(u + 1) & 1]);
         }
@@ -395,12 +406,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       __builtin_amdgcn_sched_barrier(0);
       const h16x8 (&a)[2] = af[tap & 1];
       const h16x8 (&b)[2] = bq[u & 1];
-      if (TAPS == 4 && SKIP && !((live >> tap) & 1u)) continue;        // (uniform: a scalar branch over the three MFMAs)
+      if (SUBPIX && SKIP && !((live >> tap) & 1u)) continue;        // (uniform: a scalar branch over the three MFMAs)
+      const int ja = (TAPS == 8) ? (tap >> 2) * NT + j : j;            // (compile-time: the loop is unrolled)
       if (!(P2L_H2_ABL & 8)) {
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[j], 0, 0, 0);   // smallest terms first
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[j], 0, 0, 0);
-      } else { acc[j][0] += (float)a[0][0] * (float)b[0][0]; }
+      acc[ja] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc[ja], 0, 0, 0);   // smallest terms first
+      acc[ja] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc[ja], 0, 0, 0);
+      acc[ja] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc[ja], 0, 0, 0);
+      } else { acc[ja][0] += (float)a[0][0] * (float)b[0][0]; }
       __builtin_amdgcn_sched_barrier(0);
     }
     P2L_WAIT(63, 0);                      // my LDS reads are done
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
   if (S_UNI) {
     const float os = scl[1];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NP * NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] *= os;          // (exact: a power of two)
   } else {
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
       const int Q = wave * 8 + 2 * g + lhi;
       const float os = scl[2 * (Q >> (k.tw_log + k.th_log - 2)) + 1];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NP * NT; ++j)
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[j][4 * g + s] *= os;
     }
@@ -463,9 +475,19 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(const ConvK k) {
     }
   } else {
     __syncthreads();                      // (scl read above by every wave before the dumps start)
-    if (!(P2L_H2_ABL & 32) || acc[0][0] == 12345.678f)
-    epilogue_vec<NT>(k, acc, smem, wave, lane, b0, y0, x0, n0, tile_in_image,
-                     sp_fwd ? 1 : 0, ph_y, ph_x);
+    if (!(P2L_H2_ABL & 32) || acc[0][0] == 12345.678f) {
+      if (TAPS == 8) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          if (p) __syncthreads();             // (the dumps of the first phase have been read)
+          epilogue_vec<NT>(k, reinterpret_cast<f32x16 (&)[NT]>(acc[p * NT]), smem, wave, lane, b0, y0, x0, n0,
+                           tile_in_image, 1, ph_y, p);
+        }
+      } else {
+        epilogue_vec<NT>(k, reinterpret_cast<f32x16 (&)[NT]>(acc[0]), smem, wave, lane, b0, y0, x0, n0, tile_in_image,
+                         sp_fwd ? 1 : 0, ph_y, ph_x);
+      }
+    }
   }
 }
 #undef P2L_WAIT
@@ -591,11 +613,11 @@ size_t p2l_h2_lds_bytes(const ConvK& k, int taps, int bn) {
 // k: the ConvK conv_launch_impl built for the direct / sub-pixel kernel (tile geometry, k.hp, sp_mode,
 // nchunks, splitk ...) with k.w = the fp16 x 2 image, k.w_tail, k.amax | k.amax_in set.  taps = 9 | 4.
 int p2l_h2_launch(const ConvK& k, int pro, int taps, int bn, bool small, hipStream_t st) {
-  dim3 grid(k.n_mtiles * k.n_ntiles, (taps == 4 && k.sp_mode == 1) ? 4 : k.splitk), block(256);
+  dim3 grid(k.n_mtiles * k.n_ntiles, taps == 8 ? 2 : (taps == 4 && k.sp_mode == 1) ? 4 : k.splitk), block(256);
   const size_t lds = p2l_h2_lds_bytes(k, taps, bn);
 #define P2L_H2L(TAPS, BNV, AIT, PROV)                                                         \
   do {                                                                                        \
-    if (TAPS == 4 && k.sp_skip) P2L_H2K(TAPS, BNV, AIT, PROV, (TAPS == 4));                   \
+    if ((TAPS == 4 || TAPS == 8) && k.sp_skip) P2L_H2K(TAPS, BNV, AIT, PROV, (TAPS == 4 || TAPS == 8)); \
     else P2L_H2K(TAPS, BNV, AIT, PROV, false);                                                \
   } while (0)
 #define P2L_H2K(TAPS, BNV, AIT, PROV, SKIPV)                                                  \
@@ -618,6 +640,9 @@ int p2l_h2_launch(const ConvK& k, int pro, int taps, int bn, bool small, hipStre
   if (taps == 9) {
     if (bn == 64) { if (small) P2L_H2P(9, 64, 3); else P2L_H2P(9, 64, 5); }
     else          { if (small) P2L_H2P(9, 32, 3); else P2L_H2P(9, 32, 5); }
+  } else if (taps == 8) {
+    if (bn == 64) { if (small) P2L_H2P(8, 64, 3); else P2L_H2P(8, 64, 5); }
+    else          { if (small) P2L_H2P(8, 32, 3); else P2L_H2P(8, 32, 5); }
   } else {
     if (bn == 64) { if (small) P2L_H2P(4, 64, 3); else P2L_H2P(4, 64, 5); }
     else          { if (small) P2L_H2P(4, 32, 3); else P2L_H2P(4, 32, 5); }

@@ -995,7 +995,8 @@ def test_transposed_conv_fp16x2_skips_its_zero_taps_bit_identically(dev, O, B, h
     dup[:, :, :H + 1, :H + 1] = du
     xd, dud = nhwc(x.detach(), dev), nhwc(dup, dev)
     outs = {}
-    for form in (0, N.FORM_NO_SP_SKIP):
+    for form in (0, N.FORM_SP_PAIR, N.FORM_NO_SP_SKIP | N.FORM_SP_PAIR, N.FORM_NO_SP_PAIR, N.FORM_NO_SP_SKIP | N.FORM_NO_SP_PAIR):
+        # (FORM_NO_SP_PAIR: one output phase per block of the forward launch instead of two on one staged patch)
         (u, _), mm_f = _mfma_products(N, lambda: O.conv(xd, wsp, B, H, H, Cin, Cout, 9, ups=2, ext=1, splitk=1, wfmt=2,
                                                      form=form))
         dxs = []
@@ -1006,8 +1007,9 @@ def test_transposed_conv_fp16x2_skips_its_zero_taps_bit_identically(dev, O, B, h
         torch.cuda.synchronize()
         assert abs(mm_f - 3) < 1e-6 and abs(mm_b - 3) < 1e-6       # the fp16 x 2 arithmetic ran
         outs[form] = (u, dxs[0], dxs[1])
-    for a, b in zip(outs[0], outs[N.FORM_NO_SP_SKIP]):
-        assert torch.equal(a, b)
+    for form in outs:
+        for a, b in zip(outs[0], outs[form]):
+            assert torch.equal(a, b), form
     u, dx, dx_sliced = outs[0]
     assert relerr(nchw(u)[:, :, :H + 1, :H + 1], u_ref.detach()) < 2e-5
     assert relerr(nchw(dx), x.grad) < 2e-5 and relerr(nchw(dx_sliced), x.grad) < 2e-5
@@ -1408,6 +1410,26 @@ def test_direct_kernel_fp16x2_subpixel_and_maxima(dev, O):
     assert abs(mm - 3.0) < 1e-6
     for b in range(B):
         assert (nchw(y)[b].double() - ref[b]).abs().max().item() < 2e-5 * ref[b].abs().max().item()
+    # two output phases per block (the default of the forward launch) = one phase per block, bit for bit; also with
+    # a prologue, bias + ReLU, 32-channel tiles, multi-image tiles, and the maxima the launch leaves
+    for Bp, hp, ci, co, kw in ((2, 16, 64, 64, dict(bias=True, act=N.ACT_RELU, want_amax=True)),
+                               (3, 32, 128, 32, dict(pro=N.PRO_AFFINE_RELU)),
+                               (9, 4, 64, 128, dict(bias=True)), (2, 64, 32, 64, dict(want_amax=True))):
+        xp = nhwc(torch.randn(Bp, ci, hp, hp, generator=g), dev)
+        wq = O.pack_conv_weight_subpix((torch.randn(co, ci, 3, 3, generator=g) / math.sqrt(9 * ci)).to(dev), co, ci, wfmt=2)
+        kw = dict(kw)
+        if kw.pop('bias', False):
+            kw['bias'] = torch.randn(co, generator=g).to(dev)
+        if kw.get('pro'):
+            kw.update(pro_s=(0.5 + torch.rand(Bp, ci, generator=g)).to(dev), pro_t=torch.randn(Bp, ci, generator=g).to(dev),
+                      pro_bstride=ci)
+        pair = O.conv(xp, wq, Bp, 2 * hp, 2 * hp, ci, co, 9, wfmt=2, ups=2, form=N.FORM_SP_PAIR, **kw)
+        single = O.conv(xp, wq, Bp, 2 * hp, 2 * hp, ci, co, 9, wfmt=2, ups=2, form=N.FORM_NO_SP_PAIR, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(pair[0], single[0]), (Bp, hp, ci, co)
+        if kw.get('want_amax') and pair[2][0] is not None:
+            assert torch.equal(pair[2][0], single[2][0])
+            assert torch.equal(pair[2][0].amax(dim=1), pair[0].abs().amax(dim=(1, 2, 3)))
     # input-gradient form: dx[low res] of the same conv for a gradient dy at high resolution
     dy = torch.randn(B, Cout, H, H, generator=g)
     xr = x.double().requires_grad_(True)
