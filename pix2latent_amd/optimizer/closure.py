@@ -21,6 +21,8 @@ Two execution paths:
     -- stack the per-sample leaves, `opt.step(closure)` -- used by the golden
     trace tests and for user-supplied optimizers.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -128,6 +130,21 @@ def _step_fused(model, vars, loss_fn, optimize, max_batch_size, grad_scale, popu
         if grad_scale is None:
             grad_scale = _const_scale(n, next(iter(vars.input.values())).data[0].device)
         chunks, offsets = [slice_vars(vars, 0, h), slice_vars(vars, h, n)], [0, h]
+    split = int(os.environ.get('P2L_LANE_SPLIT', '1') or 1)
+    if split > 1 and len(chunks) >= 2 and not one_pass:
+        # (measurement, tools/ab_lanes.sh) every reference chunk in `split` parts on as many lanes as P2L_STREAMS
+        # allows, each part with the gradient factor of its chunk
+        dev0 = next(iter(vars.input.values())).data[0].device
+        if grad_scale is None:
+            grad_scale = torch.cat([_const_scale(c.num_samples, dev0) for c in chunks])
+        parts, offs = [], []
+        for ci, c in enumerate(chunks):
+            b = c.num_samples
+            cuts = [offsets[ci] + (b * j) // split for j in range(split + 1)]
+            for lo_, hi_ in zip(cuts[:-1], cuts[1:]):
+                if hi_ > lo_:
+                    parts.append(slice_vars(vars, lo_, hi_)); offs.append(lo_)
+        chunks, offsets = parts, offs
     # the reference chunks of a step are independent (own rows, own Adam update): with more than one they
     # run on side streams, each lane with its own workspaces in the model and the loss -- same bits, the
     # latency-bound layers of one chunk under the busy ones of the other (lanes.py)
