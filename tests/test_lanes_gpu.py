@@ -64,6 +64,23 @@ def test_two_chunks_two_lanes_same_bits(monkeypatch):
     assert torch.equal(z1, z2), 'latents after two Adam steps differ'
 
 
+def test_chunks_cut_into_parts_on_more_lanes_same_bits(monkeypatch):
+    """P2L_LANE_SPLIT (the measurement hook of profiles/round6_lane_split.txt): every reference chunk in parts, each
+    with the gradient factor of its chunk, on up to P2L_STREAMS lanes -- the bits of one stream"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    monkeypatch.setenv('P2L_STREAMS', '1')
+    monkeypatch.delenv('P2L_LANE_SPLIT', raising=False)
+    _, _, l1, z1 = _run(dev, 7)
+    monkeypatch.setenv('P2L_STREAMS', '3')
+    monkeypatch.setenv('P2L_LANE_SPLIT', '2')
+    model, eng, l3, z3 = _run(dev, 7)                     # chunks 3, 3, 1 -> parts 1, 2, 1, 2, 1 on three lanes
+    assert sorted(model._lanes) == [0, 1, 2] and sorted(eng._lanes) == [0, 1, 2]
+    assert torch.equal(l1, l3), 'losses of the parts differ from the chunks on one stream'
+    assert torch.equal(z1, z3), 'latents after two Adam steps differ'
+
+
 def test_one_chunk_opens_no_lane(monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
